@@ -1,0 +1,392 @@
+// Masked multi-head self-attention of the denoiser (K6), forward and backward, for the tiny sequences of this path
+// (Tk = 16+2 CLIP rows; 12 heads of dh = 64).  hf:136-147 (eager_attention_forward), hf:183-185 head split,
+// ref CLIP-DDPM.py:296-297 key-padding mask.
+//
+// bf16 path: ONE 64-lane wave per (sequence, head), MFMA 32x32x16 with the sequence padded to one 32x32 tile.
+//   * scores are computed TRANSPOSED (S^T = K.Q^T) so each lane owns one query column and 16 of its 32 keys in
+//     registers: the row softmax is 16 in-register ops + one __shfl_xor(32); no LDS round trip for P.
+//   * the P registers are already in the A-operand k-slot order of the following P.V MFMA if V's B-operand is read with
+//     the matching key order -- which is what two ds_read_b64_tr_b16 transpose-reads of the LDS-staged V tile give.
+//   * Q and K fragments are loaded straight from HBM into MFMA operand registers (16 B per lane, each byte read once);
+//     only V (fwd) / K,Q,dO (bwd) are staged through LDS because they are consumed k-major.
+//   * backward recomputes P from Q,K (cheaper than storing 12x18x18 probabilities per sequence), runs the score / dP
+//     tiles in both orientations (query-major for dQ, key-major for dK,dV) and never leaves registers in between.
+// f32 path: exact-fp32 VALU kernel (one wave per (sequence, head), LDS-resident Q,K,V): the parity path.
+#include "common.h"
+#include "../../include/dic_hip.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int VSTRIDE = 192;            // bytes per LDS row of a [32][64] bf16 tile (128 data + 64 pad): tr reads conflict-free
+constexpr int TILE = 32 * VSTRIDE;      // 6 KB
+
+__device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p, bool valid) {
+    i32x4 v = valid ? *(const i32x4*)p : i32x4{0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// stage a [Tk][64] bf16 head slice (row stride `ld` elements) into LDS rows of VSTRIDE bytes, zero-filling rows >= Tk
+__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int ld, int Tk, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = lane + 64 * j, row = c >> 3, ch = c & 7;
+        i32x4 v = row < Tk ? *(const i32x4*)(src + (size_t)row * ld + ch * 8) : i32x4{0, 0, 0, 0};
+        *(i32x4*)(lds + row * VSTRIDE + ch * 16) = v;
+    }
+}
+// B-operand (k-major) fragment for MFMA step s (16 tokens) and 32-column block db, token order matching the
+// register order of a transposed-score accumulator: slots 0-3 <-> tokens 16s+4hi+{0..3}, slots 4-7 <-> +8.
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds, int s, int db, int lane) {
+    const int hi = lane >> 5, half = (lane >> 4) & 1, t = lane & 15;
+    const char* p = lds + (16 * s + 4 * hi + (t >> 2)) * VSTRIDE + (db * 32 + half * 16 + 4 * (t & 3)) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p));
+    s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p + 8 * VSTRIDE));
+    s16x8 v = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+    s16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(a[8 * s + e]);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ int reg_tok(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }   // 32x32 C/D row of register r
+__device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
+
+// D[i][j] = sum_d X[i][d] * Y[j][d] over dh=64 with X rows as MFMA "A" (row index in registers after the MFMA) and
+// Y rows as "B" (column index = lane&31).  Both loaded from HBM; rows >= Tk read as zero.
+__device__ __forceinline__ f32x16 rowdot(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Tk, int lane) {
+    const int r = lane & 31, hi = lane >> 5;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        bf16x8 a = ld_frag_global(X + (size_t)r * ldx + 16 * s + 8 * hi, r < Tk);
+        bf16x8 b = ld_frag_global(Y + (size_t)r * ldy + 16 * s + 8 * hi, r < Tk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 forward
+__global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* ctx, int N, int Tk, int H,
+                                                      float scale, float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= N * H) return;
+    const int n = pair / H, h = pair - n * H;
+    const int ld = 3 * H * DH, Dm = H * DH;
+    const bf16_t* Q = qkv + (size_t)n * Tk * ld + h * DH;
+    const bf16_t* K = Q + Dm;
+    const bf16_t* V = Q + 2 * Dm;
+    char* vt = smem + wave * TILE;
+    stage_tile(vt, V, ld, Tk, lane);
+
+    const int q = lane & 31, hi = lane >> 5;
+    // S^T[key][query]: lane = query column, register r = key reg_tok(r,hi)
+    f32x16 st = rowdot(K, ld, Q, ld, Tk, lane);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = reg_tok(r, hi);
+        const bool ok = key < Tk && key_mask[(size_t)n * Tk + key] != 0;
+        st[r] = ok ? st[r] * scale : -INFINITY;
+        mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = (mx == -INFINITY) ? 0.f : __expf(st[r] - mx); sum += st[r]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        st[r] *= inv;
+        if (p_drop > 0.f)
+            st[r] = dropout1(st[r], seed, ((unsigned long long)pair * Tk + q) * Tk + reg_tok(r, hi), p_drop, inv_keep);
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // V tile stores by this wave are complete (wave-private LDS region, no barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    // O[query][d] = sum_key P[query][key] V[key][d]
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        f32x16 o = zero16();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(st, s), tr_frag(vt, s, db, lane), o, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = reg_tok(r, hi);
+            if (qi < Tk) ctx[((size_t)n * Tk + qi) * Dm + h * DH + db * 32 + q] = f2bf(o[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 backward
+__global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
+                                                      int H, float scale, float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= N * H) return;
+    const int n = pair / H, h = pair - n * H;
+    const int ld = 3 * H * DH, Dm = H * DH;
+    const bf16_t* Q = qkv + (size_t)n * Tk * ld + h * DH;
+    const bf16_t* K = Q + Dm;
+    const bf16_t* V = Q + 2 * Dm;
+    const bf16_t* dO = dctx + (size_t)n * Tk * Dm + h * DH;
+    bf16_t* dQ = dqkv + (size_t)n * Tk * ld + h * DH;
+    bf16_t* dK = dQ + Dm;
+    bf16_t* dV = dQ + 2 * Dm;
+    char* base = smem + wave * (3 * TILE + 512);
+    char* kt = base;
+    char* qt = base + TILE;
+    char* dot = base + 2 * TILE;
+    float* stats = (float*)(base + 3 * TILE);       // [0..31] row max, [32..63] 1/rowsum, [64..95] delta
+    stage_tile(kt, K, ld, Tk, lane);
+    stage_tile(qt, Q, ld, Tk, lane);
+    stage_tile(dot, dO, Dm, Tk, lane);
+
+    const int c = lane & 31, hi = lane >> 5;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const uint8_t* km = key_mask + (size_t)n * Tk;
+
+    // ---- pass 1 (query-major): lane = query c, registers = keys.  P, delta, dS -> dQ
+    {
+        f32x16 st = rowdot(K, ld, Q, ld, Tk, lane);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = reg_tok(r, hi);
+            const bool ok = key < Tk && km[key] != 0;
+            st[r] = ok ? st[r] * scale : -INFINITY;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = (mx == -INFINITY) ? 0.f : __expf(st[r] - mx); sum += st[r]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        // dPd^T[key][query] = sum_d V[key][d] dO[query][d]
+        f32x16 dpt = rowdot(V, ld, dO, Dm, Tk, lane);
+        float delta = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] *= inv;                                                          // P
+            if (p_drop > 0.f) dpt[r] = dropout1(dpt[r], seed, ((unsigned long long)pair * Tk + c) * Tk + reg_tok(r, hi), p_drop, inv_keep);
+            delta += dpt[r] * st[r];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        if (hi == 0) { stats[c] = mx; stats[32 + c] = inv; stats[64 + c] = delta; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = st[r] * (dpt[r] - delta) * scale;      // dS[query][key] (scaled for dQ/dK)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // dQ[query][d] = sum_key dS[query][key] K[key][d]
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            f32x16 o = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(st, s), tr_frag(kt, s, db, lane), o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = reg_tok(r, hi);
+                if (qi < Tk) dQ[(size_t)qi * ld + db * 32 + c] = f2bf(o[r]);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 2 (key-major): lane = key c, registers = queries.  Pd -> dV, dS -> dK
+    {
+        f32x16 s2 = rowdot(Q, ld, K, ld, Tk, lane);                               // S[query(reg)][key(lane)]
+        f32x16 dp2 = rowdot(dO, Dm, V, ld, Tk, lane);                             // dPd[query][key] = sum_d dO[query][d] V[key][d]
+        const bool kok = c < Tk && km[c < Tk ? c : 0] != 0;
+        f32x16 pd, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = reg_tok(r, hi);
+            const float m_ = stats[qi], inv = stats[32 + qi], delta = stats[64 + qi];
+            float p = (kok && m_ > -INFINITY) ? __expf(s2[r] * scale - m_) * inv : 0.f;
+            float dpr = dp2[r], pdr = p;
+            if (p_drop > 0.f) {
+                const unsigned long long idx = ((unsigned long long)pair * Tk + qi) * Tk + c;
+                dpr = dropout1(dpr, seed, idx, p_drop, inv_keep);
+                pdr = dropout1(p, seed, idx, p_drop, inv_keep);
+            }
+            pd[r] = pdr;
+            ds[r] = p * (dpr - delta) * scale;
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            f32x16 ov = zero16(), ok_ = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ov = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pd, s), tr_frag(dot, s, db, lane), ov, 0, 0, 0);
+                ok_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ds, s), tr_frag(qt, s, db, lane), ok_, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ki = reg_tok(r, hi);
+                if (ki < Tk) {
+                    dV[(size_t)ki * ld + db * 32 + c] = f2bf(ov[r]);
+                    dK[(size_t)ki * ld + db * 32 + c] = f2bf(ok_[r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ f32 VALU path
+constexpr int TMAX = 64, PADW = 65;
+__global__ __launch_bounds__(64) void attn_fwd_f32(const float* qkv, const uint8_t* key_mask, float* ctx, int N, int Tk, int H, float scale,
+                                                    float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* q = (float*)smem;
+    float* k = q + Tk * PADW;
+    float* v = k + Tk * PADW;
+    float* p = v + Tk * PADW;          // [Tk][Tk+1]
+    const int lane = threadIdx.x, pair = blockIdx.x, n = pair / H, h = pair - n * H;
+    const int ld = 3 * H * DH, Dm = H * DH, PW = Tk + 1;
+    const float* src = qkv + (size_t)n * Tk * ld + h * DH;
+    for (int i = lane; i < Tk * DH; i += 64) {
+        int r = i >> 6, d = i & 63;
+        q[r * PADW + d] = src[(size_t)r * ld + d];
+        k[r * PADW + d] = src[(size_t)r * ld + Dm + d];
+        v[r * PADW + d] = src[(size_t)r * ld + 2 * Dm + d];
+    }
+    __syncthreads();
+    for (int e = lane; e < Tk * Tk; e += 64) {
+        int i = e / Tk, j = e - i * Tk;
+        float s = 0.f;
+        for (int d = 0; d < DH; ++d) s = fmaf(q[i * PADW + d], k[j * PADW + d], s);
+        p[i * PW + j] = key_mask[(size_t)n * Tk + j] ? s * scale : -INFINITY;
+    }
+    __syncthreads();
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int i = lane; i < Tk; i += 64) {
+        float mx = -INFINITY;
+        for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, p[i * PW + j]);
+        float sum = 0.f;
+        for (int j = 0; j < Tk; ++j) { float e = (mx == -INFINITY) ? 0.f : expf(p[i * PW + j] - mx); p[i * PW + j] = e; sum += e; }
+        float inv = sum > 0.f ? 1.f / sum : 0.f;
+        for (int j = 0; j < Tk; ++j) {
+            float pr = p[i * PW + j] * inv;
+            if (p_drop > 0.f) pr = dropout1(pr, seed, ((unsigned long long)pair * Tk + i) * Tk + j, p_drop, inv_keep);
+            p[i * PW + j] = pr;
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < Tk; ++i) {
+        float o = 0.f;
+        for (int j = 0; j < Tk; ++j) o = fmaf(p[i * PW + j], v[j * PADW + lane], o);
+        ctx[((size_t)n * Tk + i) * Dm + h * DH + lane] = o;
+    }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_f32(const float* qkv, const uint8_t* key_mask, const float* dctx, float* dqkv, int N, int Tk, int H,
+                                                    float scale, float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* q = (float*)smem;
+    float* k = q + Tk * PADW;
+    float* v = k + Tk * PADW;
+    float* go = v + Tk * PADW;
+    float* p = go + Tk * PADW;         // P (no dropout)      [Tk][Tk+1]
+    float* ds = p + Tk * (Tk + 1);     // dPd then dS         [Tk][Tk+1]
+    const int lane = threadIdx.x, pair = blockIdx.x, n = pair / H, h = pair - n * H;
+    const int ld = 3 * H * DH, Dm = H * DH, PW = Tk + 1;
+    const float* src = qkv + (size_t)n * Tk * ld + h * DH;
+    const float* gsrc = dctx + (size_t)n * Tk * Dm + h * DH;
+    for (int i = lane; i < Tk * DH; i += 64) {
+        int r = i >> 6, d = i & 63;
+        q[r * PADW + d] = src[(size_t)r * ld + d];
+        k[r * PADW + d] = src[(size_t)r * ld + Dm + d];
+        v[r * PADW + d] = src[(size_t)r * ld + 2 * Dm + d];
+        go[r * PADW + d] = gsrc[(size_t)r * Dm + d];
+    }
+    __syncthreads();
+    for (int e = lane; e < Tk * Tk; e += 64) {
+        int i = e / Tk, j = e - i * Tk;
+        float s = 0.f, g = 0.f;
+        for (int d = 0; d < DH; ++d) { s = fmaf(q[i * PADW + d], k[j * PADW + d], s); g = fmaf(go[i * PADW + d], v[j * PADW + d], g); }
+        p[i * PW + j] = key_mask[(size_t)n * Tk + j] ? s * scale : -INFINITY;
+        ds[i * PW + j] = g;
+    }
+    __syncthreads();
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int i = lane; i < Tk; i += 64) {
+        float mx = -INFINITY;
+        for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, p[i * PW + j]);
+        float sum = 0.f;
+        for (int j = 0; j < Tk; ++j) { float e = (mx == -INFINITY) ? 0.f : expf(p[i * PW + j] - mx); p[i * PW + j] = e; sum += e; }
+        float inv = sum > 0.f ? 1.f / sum : 0.f;
+        float delta = 0.f;
+        for (int j = 0; j < Tk; ++j) {
+            float pr = p[i * PW + j] * inv;
+            float dp = ds[i * PW + j];
+            if (p_drop > 0.f) dp = dropout1(dp, seed, ((unsigned long long)pair * Tk + i) * Tk + j, p_drop, inv_keep);
+            p[i * PW + j] = pr;
+            ds[i * PW + j] = dp;
+            delta += dp * pr;
+        }
+        for (int j = 0; j < Tk; ++j) ds[i * PW + j] = p[i * PW + j] * (ds[i * PW + j] - delta) * scale;
+    }
+    __syncthreads();
+    float* dst = dqkv + (size_t)n * Tk * ld + h * DH;
+    for (int i = 0; i < Tk; ++i) {       // dQ[i][lane]
+        float o = 0.f;
+        for (int j = 0; j < Tk; ++j) o = fmaf(ds[i * PW + j], k[j * PADW + lane], o);
+        dst[(size_t)i * ld + lane] = o;
+    }
+    for (int j = 0; j < Tk; ++j) {       // dK[j][lane], dV[j][lane]
+        float ok_ = 0.f, ov = 0.f;
+        for (int i = 0; i < Tk; ++i) {
+            ok_ = fmaf(ds[i * PW + j], q[i * PADW + lane], ok_);
+            float pd = p[i * PW + j];
+            if (p_drop > 0.f) pd = dropout1(pd, seed, ((unsigned long long)pair * Tk + i) * Tk + j, p_drop, inv_keep);
+            ov = fmaf(pd, go[i * PADW + lane], ov);
+        }
+        dst[(size_t)j * ld + Dm + lane] = ok_;
+        dst[(size_t)j * ld + 2 * Dm + lane] = ov;
+    }
+}
+
+}  // namespace
+
+extern "C" int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask, void* ctx, int N, int Tk, int H, int dh, float p_drop,
+                            uint64_t seed, void* stream) {
+    DIC_REQUIRE(dh == DH && N > 0 && H > 0, "dic_attn: head dim must be 64");
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DIC_BF16) {
+        DIC_REQUIRE(Tk <= 32, "dic_attn (bf16 MFMA path): at most 32 tokens per sequence");
+        hipLaunchKernelGGL(attn_fwd_bf16, dim3((N * H + 3) / 4), dim3(256), 4 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    } else {
+        DIC_REQUIRE(Tk <= TMAX, "dic_attn (f32 path): at most 64 tokens per sequence");
+        size_t lds = (size_t)(3 * Tk * PADW + Tk * (Tk + 1)) * sizeof(float);
+        hipLaunchKernelGGL(attn_fwd_f32, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (float*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    }
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask, const void* dctx, void* dqkv, int N, int Tk, int H, int dh,
+                            float p_drop, uint64_t seed, void* stream) {
+    DIC_REQUIRE(dh == DH && N > 0 && H > 0, "dic_attn: head dim must be 64");
+    const float scale = 0.125f;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DIC_BF16) {
+        DIC_REQUIRE(Tk <= 32, "dic_attn (bf16 MFMA path): at most 32 tokens per sequence");
+        size_t lds = 4 * (3 * TILE + 512);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL(attn_bwd_bf16, dim3((N * H + 3) / 4), dim3(256), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    } else {
+        DIC_REQUIRE(Tk <= TMAX, "dic_attn (f32 path): at most 64 tokens per sequence");
+        size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);
+        hipLaunchKernelGGL(attn_bwd_f32, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (const float*)dctx, (float*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    }
+    DIC_CHECK_LAUNCH();
+    return 0;
+}

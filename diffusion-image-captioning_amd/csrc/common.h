@@ -1,0 +1,124 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+#define DIC_F32 0
+#define DIC_BF16 1
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ---------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int dtype = DIC_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    // 4 consecutive elements
+    __device__ static __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+    __device__ static __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int dtype = DIC_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ f32x4 ld4(const bf16_t* p) {
+        uint2 u = *(const uint2*)p;
+        f32x4 r;
+        r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+        r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+        return r;
+    }
+    __device__ static __forceinline__ void st4(bf16_t* p, f32x4 v) {
+        uint2 u;
+        u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)p = u;
+    }
+};
+
+// ---- wave / block reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- exact (erf) GELU, hf get_activation("gelu") -------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- counter-based RNG ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011): used for q_sample noise and for dropout keep-masks, keyed by
+// (seed, element index) so a backward kernel regenerates exactly the mask its forward used.
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+// keep-mask for 4 consecutive elements starting at element index e4*4 (one Philox call per 4 elements)
+__device__ __forceinline__ uint4 rng4(unsigned long long seed, unsigned long long e4) {
+    return philox4x32(make_uint4((unsigned)e4, (unsigned)(e4 >> 32), 0x0d1c5eedu, 0u),
+                      make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// dropout on 4 consecutive values whose flat index starts at idx (idx % 4 == 0)
+__device__ __forceinline__ f32x4 dropout4(f32x4 v, unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    uint4 r = rng4(seed, idx >> 2);
+    v[0] = (u01(r.x) >= p) ? v[0] * inv_keep : 0.f;
+    v[1] = (u01(r.y) >= p) ? v[1] * inv_keep : 0.f;
+    v[2] = (u01(r.z) >= p) ? v[2] * inv_keep : 0.f;
+    v[3] = (u01(r.w) >= p) ? v[3] * inv_keep : 0.f;
+    return v;
+}
+__device__ __forceinline__ float dropout1(float v, unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    uint4 r = rng4(seed, idx >> 2);
+    unsigned w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    return (u01(w) >= p) ? v * inv_keep : 0.f;
+}
+
+// ---- error plumbing for the C-ABI ----------------------------------------------------------------
+extern "C" void dic_set_error(const char* msg);
+#define DIC_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) {                            \
+            dic_set_error(hipGetErrorString(e__));          \
+            return (int)e__;                                \
+        }                                                   \
+    } while (0)
+#define DIC_REQUIRE(cond, msg)                              \
+    do {                                                    \
+        if (!(cond)) {                                      \
+            dic_set_error(msg);                             \
+            return 1001;                                    \
+        }                                                   \
+    } while (0)

@@ -1,0 +1,390 @@
+// MFMA GEMM for gfx950 with fused epilogues -- the FLOP carrier of the denoiser (K3,K5,K7,K8,K9,K11,K14).
+//
+//   C[m][n] = sum_k A(m,k) * B(n,k)           (then an epilogue)
+//
+// Operand storage is chosen per operand:
+//   k-contiguous ("KC"):  X[row][k]   -- activations as A in the forward, Linear weights [out][in] as B
+//   k-major      ("KM"):  X[k][row]   -- weights [out][in] as B of dX = dY.W, and both operands of dW = dY^T.X
+// so forward (KC,KC), input-gradient (KC,KM) and weight-gradient (KM,KM) all run on this one kernel without
+// ever materialising a transposed tensor in HBM.
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA fragments),
+// K-step 128 bytes (64 bf16 / 32 f32).  Global->register->LDS staging with `buffer_load_dwordx4`
+// (the buffer descriptor's bounds check zero-fills rows beyond M/N/K, so ragged shapes need no branches),
+// double-buffered LDS, one barrier per K-step.
+//   bf16: v_mfma_f32_16x16x32_bf16.  KC fragments are two ds_read_b64 (k = 4g..4g+3 and 16+4g..), KM fragments
+//         are two ds_read_b64_tr_b16 hardware-transpose reads giving the same k-slot mapping, so any mix of
+//         KC/KM operands contracts consistently.  LDS row strides (144 B KC, 288 B KM) make both reads
+//         bank-conflict-free.
+//   f32:  v_mfma_f32_16x16x4_f32 -- exact fp32, accumulating k in ascending order (bit-identical to an
+//         fmaf chain), which is what lets the rounding head reproduce the oracle's token ids bit-for-bit.
+// The MFMA is issued with operands swapped (D = Bfrag x Afrag) so that each lane ends up holding 4
+// CONSECUTIVE n for one m: epilogue loads/stores are 8-byte (bf16) or 16-byte (f32) vectors.
+#include "common.h"
+#include "../../include/dic_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int TILE_BYTES = 18432;      // one operand tile in LDS (either layout, either dtype)
+constexpr int KC_STRIDE = 144;         // bytes: 128 data + 16 pad
+template <typename T> struct KCfg;
+template <> struct KCfg<bf16_t> { static constexpr int BK = 64, KM_STRIDE = 288, KM_CHUNKS_LOG2 = 4; };
+template <> struct KCfg<float>  { static constexpr int BK = 32, KM_STRIDE = 576, KM_CHUNKS_LOG2 = 5; };
+
+__device__ __forceinline__ i32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+}
+
+// ---- staging: global -> 4 x 16B registers per operand per thread ---------------------------------
+template <typename T, bool KM>
+__device__ __forceinline__ void stage_load(i32x4 (&r)[4], __amdgpu_buffer_rsrc_t rs, int ld, int k0, int tid) {
+    constexpr int S = sizeof(T);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = tid + NT * j;
+        unsigned off;
+        if (!KM) {
+            int row = c >> 3, kc = c & 7;
+            off = ((unsigned)row * (unsigned)ld + (unsigned)k0) * S + kc * 16;
+        } else {
+            constexpr int L2 = KCfg<T>::KM_CHUNKS_LOG2;
+            int row = c >> L2, cc = c & ((1 << L2) - 1);
+            off = ((unsigned)(k0 + row) * (unsigned)ld) * S + cc * 16;
+        }
+        r[j] = buf_load16(rs, off);
+    }
+}
+template <typename T, bool KM>
+__device__ __forceinline__ void stage_store(const i32x4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = tid + NT * j;
+        int off;
+        if (!KM) {
+            off = (c >> 3) * KC_STRIDE + (c & 7) * 16;
+        } else {
+            constexpr int L2 = KCfg<T>::KM_CHUNKS_LOG2;
+            off = (c >> L2) * KCfg<T>::KM_STRIDE + (c & ((1 << L2) - 1)) * 16;
+        }
+        *(i32x4*)(lds + off) = r[j];
+    }
+}
+
+// ---- fragment reads ------------------------------------------------------------------------------
+// bf16: returns the 8-element operand for k sub-step kk (32 k's) of 16 rows/cols starting at `base`.
+template <bool KM>
+__device__ __forceinline__ bf16x8 frag_bf16(const char* lds, int base, int kk, int lane) {
+    int g = lane >> 4, t = lane & 15;
+    s16x4 lo, hi;
+    if (!KM) {
+        const char* p = lds + (base + t) * KC_STRIDE + (kk * 32 + 4 * g) * 2;
+        lo = *(const s16x4*)p;
+        hi = *(const s16x4*)(p + 32);
+    } else {
+        const char* p = lds + (kk * 32 + 4 * g + (t >> 2)) * 288 + (base + 4 * (t & 3)) * 2;
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p));
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(p + 16 * 288));
+    }
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// f32: one value per lane for k = k4*4 + (lane>>4)
+template <bool KM>
+__device__ __forceinline__ float frag_f32(const char* lds, int base, int k4, int lane) {
+    int g = lane >> 4, t = lane & 15;
+    if (!KM) return *(const float*)(lds + (base + t) * KC_STRIDE + (k4 * 4 + g) * 4);
+    return *(const float*)(lds + (k4 * 4 + g) * 576 + (base + t) * 4);
+}
+
+__device__ __forceinline__ float row_scale(const DicGemmParams& p, int m) { return m < p.ce_rows_a ? p.ce_scale_a : p.ce_scale_b; }
+
+template <typename T, bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S = sizeof(T);
+    constexpr int BK = KCfg<T>::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware block order: consecutive logical tiles (same A row-panel) share one XCD's L2.
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM, nwg = nbm * nbn;
+    int pid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, slot = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bm = pid / nbn, bn = pid % nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // buffer descriptors anchored at the tile origin; num_records ends at the matrix end => OOB rows read 0
+    const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
+    const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
+    long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
+    long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
+    if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
+    if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    i32x4 ra[4], rb[4];
+    stage_load<T, AKM>(ra, rsA, p.lda, 0, tid);
+    stage_load<T, BKM>(rb, rsB, p.ldb, 0, tid);
+    stage_store<T, AKM>(ra, smem, tid);
+    stage_store<T, BKM>(rb, smem + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* lb = la + TILE_BYTES;
+        if (kt + 1 < nk) {
+            stage_load<T, AKM>(ra, rsA, p.lda, (kt + 1) * BK, tid);
+            stage_load<T, BKM>(rb, rsB, p.ldb, (kt + 1) * BK, tid);
+        }
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<AKM>(la, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag_bf16<BKM>(lb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag_f32<AKM>(la, wm * 64 + i * 16, k4, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag_f32<BKM>(lb, wn * 64 + j * 16, k4, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            char* na = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
+            stage_store<T, AKM>(ra, na, tid);
+            stage_store<T, BKM>(rb, na + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // acc[i][j][r]  <->  m = m0 + wm*64 + i*16 + (lane&15),  n = n0 + wn*64 + j*16 + (lane>>4)*4 + r
+    const int g = lane >> 4, t = lane & 15;
+    if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_GELU_BWD) {
+        const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + t;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + g * 4;
+                if (n >= p.N) continue;
+                f32x4 v = acc[i][j];
+                if constexpr (EPI == DIC_EPI_AFFINE) {
+                    if (p.bias) v += *(const f32x4*)(p.bias + n);
+                    if (p.p_drop > 0.f) v = dropout4(v, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
+                    if (p.R) v += Elem<T>::ld4((const T*)p.R + (size_t)m * p.ldr + n);
+                    if (p.out_f32) {
+                        float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                        if (p.accumulate) v += *(const f32x4*)c;
+                        *(f32x4*)c = v;
+                    } else {
+                        Elem<T>::st4((T*)p.C + (size_t)m * p.ldc + n, v);
+                    }
+                } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {
+                    v += *(const f32x4*)(p.bias + n);
+                    Elem<T>::st4((T*)p.aux + (size_t)m * p.ldaux + n, v);   // pre-activation u (for GELU')
+                    f32x4 gl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gl[r] = gelu_f(v[r]);
+                    Elem<T>::st4((T*)p.C + (size_t)m * p.ldc + n, gl);
+                } else {   // GELU_BWD: dU = acc * gelu'(U)
+                    f32x4 u = Elem<T>::ld4((const T*)p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(u[r]);
+                    Elem<T>::st4((T*)p.C + (size_t)m * p.ldc + n, v);
+                }
+            }
+        }
+    } else if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
+        // per (row, 64-column half-tile): running max / first argmax / sum exp(x - max); target logit scattered
+        const int np = 2 * nbn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + t;
+            const long long tg = (m < p.M && p.tgt) ? p.tgt[m] : -1;
+            float mx = -INFINITY;
+            int ix = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + j * 16 + g * 4 + r;
+                    const float x = acc[i][j][r];
+                    if (n < p.N) {
+                        if (x > mx) { mx = x; ix = n; }
+                        if ((long long)n == tg) p.tgt_logit[m] = x;
+                    }
+                }
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + j * 16 + g * 4 + r;
+                    if (n < p.N) sm += __expf(acc[i][j][r] - mx);
+                }
+            // merge the 4 lanes (g = 0..3) that share row m
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                float mx2 = __shfl_xor(mx, o, 64), sm2 = __shfl_xor(sm, o, 64);
+                int ix2 = __shfl_xor(ix, o, 64);
+                float M = fmaxf(mx, mx2);
+                float s1 = (mx == -INFINITY) ? 0.f : sm * __expf(mx - M);
+                float s2 = (mx2 == -INFINITY) ? 0.f : sm2 * __expf(mx2 - M);
+                ix = (mx > mx2) ? ix : (mx2 > mx) ? ix2 : min(ix, ix2);
+                mx = M; sm = s1 + s2;
+            }
+            if (g == 0 && m < p.M) {
+                float4 o4 = make_float4(mx, sm, __int_as_float(ix), 0.f);
+                *(float4*)(p.partial + ((size_t)m * np + bn * 2 + wn) * 4) = o4;
+            }
+        }
+    } else if constexpr (EPI == DIC_EPI_CE_DLOGITS) {
+        // dlogits = (softmax - onehot) * row_scale ; columns >= V (padding up to ldc) are written as zeros
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + t;
+            if (m >= p.M) continue;
+            const float lse = p.lse[m], sc = row_scale(p, m);
+            const long long tg = p.tgt[m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + g * 4;
+                if (n >= p.ldc) continue;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = (n + r < p.N) ? __expf(acc[i][j][r] - lse) : 0.f;
+                    if ((long long)(n + r) == tg) pr -= 1.0f;
+                    v[r] = pr * sc;
+                }
+                Elem<T>::st4((T*)p.C + (size_t)m * p.ldc + n, v);
+            }
+        }
+    }
+}
+
+template <typename T, bool AKM, bool BKM, int E>
+void launch_one(dim3 grid, hipStream_t st, const DicGemmParams& q) {
+    constexpr size_t lds = 4 * TILE_BYTES;   // 72 KB: two stages x (A tile + B tile) -> 2 workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<T, AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, AKM, BKM, E>), grid, dim3(NT), lds, st, q);
+}
+
+template <typename T, bool AKM, bool BKM>
+int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    dim3 grid(nbm * nbn);
+    switch (epi) {
+        case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(grid, st, p); break;
+        case DIC_EPI_BIAS_GELU: launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(grid, st, p); break;
+        case DIC_EPI_GELU_BWD: launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(grid, st, p); break;
+        case DIC_EPI_CE_PARTIAL: launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(grid, st, p); break;
+        case DIC_EPI_CE_DLOGITS: launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(grid, st, p); break;
+        default: dic_set_error("dic_gemm: unknown epilogue"); return 1002;
+    }
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int launch_layout(const DicGemmParams& p, int a_km, int b_km, int epi, hipStream_t st) {
+    if (!a_km && !b_km) return launch_epi<T, false, false>(p, epi, st);
+    if (!a_km && b_km) return launch_epi<T, false, true>(p, epi, st);
+    if (a_km && b_km) return launch_epi<T, true, true>(p, epi, st);
+    dic_set_error("dic_gemm: (A k-major, B k-contiguous) is not used by the path and not built");
+    return 1003;
+}
+
+}  // namespace
+
+// ---- optional per-launch timing (bench.py roofline leg): hipEvents recorded on the launch stream around each GEMM
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+ProfRec* g_prof = nullptr;
+int g_prof_cap = 0, g_prof_n = 0;
+}  // namespace
+extern "C" int dic_prof_begin(int max_launches) {
+    if (g_prof) return 0;
+    g_prof = new ProfRec[max_launches];
+    for (int i = 0; i < max_launches; ++i) { (void)hipEventCreate(&g_prof[i].a); (void)hipEventCreate(&g_prof[i].b); }
+    g_prof_cap = max_launches; g_prof_n = 0;
+    return 0;
+}
+// Sums the recorded launches (caller has synchronised the stream), frees the events.
+extern "C" int dic_prof_end(double* total_ms, double* total_flops, int* n_launches) {
+    double ms = 0, fl = 0;
+    for (int i = 0; i < g_prof_n; ++i) { float t = 0; (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b); ms += t; fl += g_prof[i].flops; }
+    *total_ms = ms; *total_flops = fl; *n_launches = g_prof_n;
+    for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+    delete[] g_prof; g_prof = nullptr; g_prof_cap = g_prof_n = 0;
+    return 0;
+}
+
+static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream);
+extern "C" int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream) {
+    if (g_prof && g_prof_n < g_prof_cap) {
+        ProfRec& r = g_prof[g_prof_n];
+        (void)hipEventRecord(r.a, (hipStream_t)stream);
+        int rc = dic_gemm_impl(dtype, a_km, b_km, epi, pp, stream);
+        (void)hipEventRecord(r.b, (hipStream_t)stream);
+        r.flops = 2.0 * pp->M * pp->N * pp->K;
+        ++g_prof_n;
+        return rc;
+    }
+    return dic_gemm_impl(dtype, a_km, b_km, epi, pp, stream);
+}
+
+static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream) {
+    const DicGemmParams& p = *pp;
+    DIC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "dic_gemm: empty problem");
+    const int es = dtype == DIC_BF16 ? 2 : 4;
+    const int bk = dtype == DIC_BF16 ? 64 : 32;
+    if (!a_km || !b_km) DIC_REQUIRE(p.K % bk == 0, "dic_gemm: K must be a multiple of the K-step for k-contiguous operands (pad with zeros)");
+    DIC_REQUIRE(((size_t)p.lda * es) % 16 == 0 && ((size_t)p.ldb * es) % 16 == 0, "dic_gemm: leading dimensions must be 16-byte multiples");
+    DIC_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "dic_gemm: operands must be 16-byte aligned");
+    if (a_km) DIC_REQUIRE((long long)p.K * p.lda * es < 0x7FFFFFFFll && p.M % 8 == 0, "dic_gemm: k-major A too large for 32-bit buffer offsets");
+    if (b_km) DIC_REQUIRE((long long)p.K * p.ldb * es < 0x7FFFFFFFll, "dic_gemm: k-major B too large for 32-bit buffer offsets");
+    if (!a_km) DIC_REQUIRE((long long)BM * p.lda * es < 0x7FFFFFFFll, "dic_gemm: lda too large");
+    if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
+    if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % 4 == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DIC_BF16) return launch_layout<bf16_t>(p, a_km, b_km, epi, st);
+    if (dtype == DIC_F32) return launch_layout<float>(p, a_km, b_km, epi, st);
+    dic_set_error("dic_gemm: unknown dtype");
+    return 1004;
+}

@@ -1,0 +1,352 @@
+// HBM-bound helpers of the hot path: embedding gather (K1), q_sample (K2), embedding losses (K13), the
+// rounding-loss combine (K12), CFG mix (K10), column reductions for bias / LayerNorm / embedding gradients,
+// and the fused AdamW (K15).  All are streaming kernels: 16-byte accesses per lane, grid-stride, no reuse.
+#include "common.h"
+#include "../../include/dic_hip.h"
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+extern "C" void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
+extern "C" const char* dic_last_error(void) { return g_err; }
+extern "C" int dic_version(void) { return 10; }
+
+static inline int grid_for(long long work_items, int per_block, int cap = 4096) {
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------ K1 embedding gather
+// ref CLIP-DDPM.py:459  x_0 = model.embedding(ids).  One wave per token row, 16 B per lane.
+__global__ void embed_gather_kernel(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n_tokens; row += gridDim.x * wpb) {
+        long long id = ids[row];
+        if (id < 0) id = 0;
+        if (id >= V) id = V - 1;
+        const f32x4* src = (const f32x4*)(E + (size_t)id * D);
+        f32x4* dst = (f32x4*)(out + (size_t)row * D);
+        for (int c = lane; c < D / 4; c += 64) dst[c] = src[c];
+    }
+}
+extern "C" int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, void* stream) {
+    DIC_REQUIRE(D % 4 == 0 && n_tokens > 0, "dic_embed_gather: D must be a multiple of 4");
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, ids, E, out, n_tokens, D, V);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K2 q_sample
+// ref CLIP-DDPM.py:356-362.  Each thread owns 4 consecutive elements of one [B][LD] slab position, draws (or
+// reads) its noise ONCE and writes the S noised copies (s-major output), so x0/eps are read once, not S times.
+__global__ void qsample_kernel(const float* x0, const float* noise, const int64_t* t, const float* ac, float* out,
+                               float* noise_out, int S, long long BLD, int step_tot, unsigned long long seed) {
+    const long long n4 = BLD >> 2;
+    for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
+        f32x4 x = *(const f32x4*)(x0 + i4 * 4);
+        f32x4 e;
+        if (noise) {
+            e = *(const f32x4*)(noise + i4 * 4);
+        } else {
+            uint4 r = rng4(seed, (unsigned long long)i4);
+            // Box-Muller on two uniform pairs
+            float u1 = fmaxf(u01(r.x), 5.9604645e-8f), u2 = u01(r.y), u3 = fmaxf(u01(r.z), 5.9604645e-8f), u4 = u01(r.w);
+            float r1 = sqrtf(-2.f * __logf(u1)), r2 = sqrtf(-2.f * __logf(u3));
+            float s1, c1, s2, c2;
+            __sincosf(6.283185307179586f * u2, &s1, &c1);
+            __sincosf(6.283185307179586f * u4, &s2, &c2);
+            e = f32x4{r1 * c1, r1 * s1, r2 * c2, r2 * s2};
+        }
+        if (noise_out) *(f32x4*)(noise_out + i4 * 4) = e;
+        for (int s = 0; s < S; ++s) {
+            long long ts = t[s];
+            ts = ts < 0 ? 0 : (ts >= step_tot ? step_tot - 1 : ts);
+            const float a = ac[ts];
+            const float ca = sqrtf(a), cb = sqrtf(1.0f - a);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(ca, x[k]), __fmul_rn(e[k], cb));   // un-fused, same op order as ref :360-362 => bit-exact
+            *(f32x4*)(out + (size_t)s * BLD + i4 * 4) = o;
+        }
+    }
+}
+extern "C" int dic_qsample(const float* x0, const float* noise, const int64_t* t, const float* alpha_cumprod, float* out,
+                           float* noise_out, int S, int B, int LD, int step_tot, uint64_t seed, void* stream) {
+    long long BLD = (long long)B * LD;
+    DIC_REQUIRE(BLD % 4 == 0 && S > 0, "dic_qsample: B*L*D must be a multiple of 4");
+    hipLaunchKernelGGL(qsample_kernel, dim3(grid_for(BLD / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
+                       alpha_cumprod, out, noise_out, S, BLD, step_tot, (unsigned long long)seed);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K13 embedding losses
+// ref CLIP-DDPM.py:77-87, 418, 428.  One workgroup per sequence: reduce |d| or d^2 over the L*D elements of rows
+// t<L, then (training) write the gradient  grad_scale[n] * (sign(d) | d / norm)  into dx_out and zero the CLIP rows.
+template <typename T>
+__global__ __launch_bounds__(256) void emb_loss_kernel(int kind, const float* x_out, const float* target, int tgt_rows,
+                                                        float* per_seq, float* dx_out, const float* grad_scale, T* xr,
+                                                        int L, int Tk, int D) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* xo = x_out + (size_t)n * Tk * D;
+    const float* tg = target + (size_t)(n % tgt_rows) * L * D;
+    const int n4 = L * D / 4;
+    const bool l2 = kind >= 2;
+    float acc = 0.f;
+    for (int i = tid; i < n4; i += 256) {
+        f32x4 a = *(const f32x4*)(xo + i * 4), b = *(const f32x4*)(tg + i * 4);
+        if (xr) Elem<T>::st4(xr + (size_t)n * L * D + i * 4, a);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { float d = a[k] - b[k]; acc += l2 ? d * d : fabsf(d); }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    float tot = red[0] + red[1] + red[2] + red[3];
+    float val = l2 ? sqrtf(tot) : tot;
+    if (tid == 0) per_seq[n] = val;
+    if (dx_out) {
+        const float gs = grad_scale[n];
+        const float inv = l2 ? (val > 0.f ? gs / val : 0.f) : gs;
+        float* dx = dx_out + (size_t)n * Tk * D;
+        for (int i = tid; i < n4; i += 256) {
+            f32x4 a = *(const f32x4*)(xo + i * 4), b = *(const f32x4*)(tg + i * 4), g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d = a[k] - b[k];
+                g[k] = l2 ? d * inv : (d > 0.f ? inv : (d < 0.f ? -inv : 0.f));
+            }
+            *(f32x4*)(dx + i * 4) = g;
+        }
+        for (int i = n4 + tid; i < Tk * D / 4; i += 256) *(f32x4*)(dx + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+extern "C" int dic_emb_loss(int dtype, int kind, const float* x_out, const float* target, int tgt_rows, float* per_seq,
+                            float* dx_out, const float* grad_scale, void* xr, int N, int L, int Tk, int D, void* stream) {
+    DIC_REQUIRE(D % 4 == 0 && N > 0 && tgt_rows > 0 && kind >= 0 && kind < 4, "dic_emb_loss: bad arguments");
+    if (dtype == DIC_BF16)
+        hipLaunchKernelGGL(emb_loss_kernel<bf16_t>, dim3(N), dim3(256), 0, (hipStream_t)stream, kind, x_out, target, tgt_rows, per_seq, dx_out, grad_scale, (bf16_t*)xr, L, Tk, D);
+    else
+        hipLaunchKernelGGL(emb_loss_kernel<float>, dim3(N), dim3(256), 0, (hipStream_t)stream, kind, x_out, target, tgt_rows, per_seq, dx_out, grad_scale, (float*)xr, L, Tk, D);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void add_rows_kernel(float* dx_out, const float* dxr, long long n4_total, int LD4, int TkD4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4_total; i += (long long)gridDim.x * blockDim.x) {
+        long long n = i / LD4, r = i - n * LD4;
+        f32x4* d = (f32x4*)dx_out + n * TkD4 + r;
+        *d = *d + ((const f32x4*)dxr)[i];
+    }
+}
+extern "C" int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int Tk, int D, void* stream) {
+    long long n4 = (long long)N * L * D / 4;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx_out, dxr, n4, L * D / 4, Tk * D / 4);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[0] = scale_a * sum in[0:n_a], out[1] = scale_b * sum in[n_a:n], out[2] = out[0]+out[1]  (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, int n_a, float sa, float sb, float* out2) {
+    __shared__ double red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { float v = in[i]; if (i < n_a) a += v; else b += v; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a_ = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) * sa);
+        float b_ = (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) * sb);
+        out2[0] = a_; out2[1] = b_; out2[2] = a_ + b_;
+    }
+}
+extern "C" int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out2, void* stream) {
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, n_a, scale_a, scale_b, out2);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K12 rounding combine
+// One wave per row: merge the per-half-tile {max, sumexp, argmax} partials (ordered by column range, so the first
+// partial holding the global max carries the lowest index -- torch.argmax's tie rule).
+__global__ void ce_combine_kernel(const float* partial, const float* tgt_logit, int M, int np, float* lse, int64_t* argmax, float* nll) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int m = blockIdx.x * wpb + (threadIdx.x >> 6); m < M; m += gridDim.x * wpb) {
+        const float4* pr = (const float4*)partial + (size_t)m * np;
+        float mx = -INFINITY, sm = 0.f;
+        int ix = 0x7fffffff;
+        for (int i = lane; i < np; i += 64) {
+            float4 q = pr[i];
+            int qi = __float_as_int(q.z);
+            if (q.x > mx) { sm = sm * __expf(mx - q.x) + q.y; mx = q.x; ix = qi; }
+            else if (q.x > -INFINITY) { sm += q.y * __expf(q.x - mx); if (q.x == mx) ix = min(ix, qi); }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            float mx2 = __shfl_xor(mx, o, 64), sm2 = __shfl_xor(sm, o, 64);
+            int ix2 = __shfl_xor(ix, o, 64);
+            float Mx = fmaxf(mx, mx2);
+            float s1 = (mx == -INFINITY) ? 0.f : sm * __expf(mx - Mx);
+            float s2 = (mx2 == -INFINITY) ? 0.f : sm2 * __expf(mx2 - Mx);
+            ix = (mx > mx2) ? ix : (mx2 > mx) ? ix2 : min(ix, ix2);
+            mx = Mx; sm = s1 + s2;
+        }
+        if (lane == 0) {
+            float l = mx + logf(sm);
+            lse[m] = l;
+            argmax[m] = ix;
+            if (nll) nll[m] = l - tgt_logit[m];
+        }
+    }
+}
+extern "C" int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_partials, float* lse, int64_t* argmax,
+                              float* nll, void* stream) {
+    hipLaunchKernelGGL(ce_combine_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, partial, tgt_logit, M, n_partials, lse, argmax, nll);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K10 classifier-free-guidance mix
+__global__ void cfg_mix_fwd_kernel(float* x_out, const float* g_out, const int64_t* idx, long long n4, int row4, float w) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / row4, c = i - r * row4;
+        f32x4* x = (f32x4*)x_out + idx[r] * row4 + c;
+        f32x4 g = ((const f32x4*)g_out)[i];
+        *x = (1.0f + w) * g - w * (*x);            // ref :315-317
+    }
+}
+__global__ void cfg_mix_bwd_kernel(float* dx_out, float* dg_out, const int64_t* idx, long long n4, int row4, float w) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / row4, c = i - r * row4;
+        f32x4* x = (f32x4*)dx_out + idx[r] * row4 + c;
+        f32x4 d = *x;
+        ((f32x4*)dg_out)[i] = (1.0f + w) * d;
+        *x = -w * d;
+    }
+}
+extern "C" int dic_cfg_mix_fwd(float* x_out, const float* g_out, const int64_t* idx, int n_g, int row_elems, float w, void* stream) {
+    long long n4 = (long long)n_g * row_elems / 4;
+    hipLaunchKernelGGL(cfg_mix_fwd_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x_out, g_out, idx, n4, row_elems / 4, w);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_cfg_mix_bwd(float* dx_out, float* dg_out, const int64_t* idx, int n_g, int row_elems, float w, void* stream) {
+    long long n4 = (long long)n_g * row_elems / 4;
+    hipLaunchKernelGGL(cfg_mix_bwd_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx_out, dg_out, idx, n4, row_elems / 4, w);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// "add" fusion backward (ref :306-307): the projected CLIP row was broadcast over the L sequence rows, so its gradient
+// is the sum over t; out_txt gets the same sum only where the text row was added (classifier-free-guided rows).
+__global__ void seq_sum_kernel(const float* in, const uint8_t* flags, float* out_all, float* out_flag, int N, int L, int D4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)N * D4; i += (long long)gridDim.x * blockDim.x) {
+        int n = (int)(i / D4), c = (int)(i - (long long)n * D4);
+        f32x4 acc{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < L; ++t) acc += ((const f32x4*)in)[((size_t)n * L + t) * D4 + c];
+        ((f32x4*)out_all)[i] = acc;
+        if (out_flag) ((f32x4*)out_flag)[i] = (flags && flags[n]) ? acc : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+extern "C" int dic_seq_sum(const float* in, const uint8_t* flags, float* out_all, float* out_flag, int N, int L, int D, void* stream) {
+    DIC_REQUIRE(D % 4 == 0 && N > 0, "dic_seq_sum: D must be a multiple of 4");
+    hipLaunchKernelGGL(seq_sum_kernel, dim3(grid_for((long long)N * D / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, in, flags, out_all, out_flag, N, L, D / 4);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// Stage 1: grid (col groups of 256, slabs); the 4 waves of a block take rows slab*4+w, +4*nslab, ...; LDS-reduce the
+// 4 waves; write ws[slab][cols].  Stage 2: sum the slabs in fixed order.  Deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1(const T* in, int rows, int cols, int ld, float* ws, int nslab) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + w; r < rows; r += nslab * 4) acc += Elem<T>::ld4(in + (size_t)r * ld + c);
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < cols) *(f32x4*)(ws + (size_t)blockIdx.y * cols + c) = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void colsum_stage2(const float* ws, int nslab, int cols, float* out, int accumulate) {
+    int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (c >= cols) return;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nslab; ++s) acc += *(const f32x4*)(ws + (size_t)s * cols + c);
+    if (accumulate) acc += *(const f32x4*)(out + c);
+    *(f32x4*)(out + c) = acc;
+}
+extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream) {
+    DIC_REQUIRE(cols % 4 == 0 && rows > 0, "dic_colsum: cols must be a multiple of 4");
+    int nslab = (rows + 3) / 4;
+    if (nslab > 64) nslab = 64;
+    dim3 grid((cols + 255) / 256, nslab);
+    if (in_dtype == DIC_BF16)
+        hipLaunchKernelGGL(colsum_stage1<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, rows, cols, ld, ws, nslab);
+    else
+        hipLaunchKernelGGL(colsum_stage1<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, rows, cols, ld, ws, nslab);
+    hipLaunchKernelGGL(colsum_stage2, dim3((cols / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nslab, cols, out, accumulate);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ K15 AdamW
+// torch.optim.AdamW semantics (ref :335): p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  One pass over the flat buffers: 16 B/param read, 12(+2) B written.
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, uint16_t* shadow, long long n4, float lr, float b1,
+                             float b2, float eps, float wd, float bc1, float rsqrt_bc2, float gscale) {
+    const float step = lr / bc1, decay = 1.0f - lr * wd;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 P = ((f32x4*)p)[i], G = ((const f32x4*)g)[i] * gscale, Mo = ((f32x4*)m)[i], Vo = ((f32x4*)v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = P[k] * decay;
+            float mk = Mo[k] * b1 + (1.0f - b1) * G[k];
+            float vk = Vo[k] * b2 + (1.0f - b2) * G[k] * G[k];
+            float denom = sqrtf(vk) * rsqrt_bc2 + eps;
+            P[k] = pk - step * (mk / denom);
+            Mo[k] = mk; Vo[k] = vk;
+        }
+        ((f32x4*)p)[i] = P; ((f32x4*)m)[i] = Mo; ((f32x4*)v)[i] = Vo;
+        if (shadow) Elem<bf16_t>::st4(shadow + i * 4, P);
+    }
+}
+extern "C" int dic_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+    DIC_REQUIRE(n % 4 == 0 && n > 0, "dic_adamw: flat length must be a multiple of 4");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, (long long)(n / 4),
+                       lr, beta1, beta2, eps, weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), grad_scale);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+__global__ void cast_bf16_kernel(const float* in, uint16_t* out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        Elem<bf16_t>::st4(out + i * 4, ((const f32x4*)in)[i]);
+}
+extern "C" int dic_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {
+    DIC_REQUIRE(n % 4 == 0 && n > 0, "dic_cast_bf16: length must be a multiple of 4");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, in, out, (long long)(n / 4));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ layout probe
+// out[lane*4+j] = element j returned to `lane` by ds_read_b64_tr_b16 when lane supplies address lds + lane*8 over
+// in[0..255].  The GPU test asserts the mapping gemm.hip/attn.hip rely on:  out[l*4+j] == in[(l&15) + 16*j + 64*(l>>4)].
+__global__ void probe_tr16_kernel(const uint16_t* in, uint16_t* out) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[256];
+    const int l = threadIdx.x;
+    for (int i = l; i < 256; i += 64) lds[i] = in[i];
+    __syncthreads();
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + l * 4));
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
+}
+extern "C" int dic_probe_tr16(const uint16_t* in, uint16_t* out, void* stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,370 @@
+// LayerNorm family (K4, K7/K8 epilogue LN, K9) for D = 768: one 64-lane wave per token row, each lane owning
+// 3 chunks of 4 consecutive features (cols c*256 + lane*4 ..), i.e. 16-byte (f32) / 8-byte (bf16) coalesced accesses,
+// statistics by wave shuffles in fp32 (two-pass mean/variance in registers), eps = 1e-12 as hf:100,236,239,439.
+// Backward kernels are persistent: each wave walks rows with a grid stride, keeps its dgamma/dbeta/bias-grad partial
+// sums in registers, and the block writes ONE partial row; dic_colsum folds the partial rows (deterministic).
+#include "common.h"
+#include "../../include/dic_hip.h"
+
+namespace {
+constexpr int D = 768, NCH = 3;
+
+template <typename T>
+__device__ __forceinline__ void load_row(const T* p, int lane, f32x4 (&v)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) v[c] = Elem<T>::ld4(p + c * 256 + lane * 4);
+}
+template <typename T>
+__device__ __forceinline__ void store_row(T* p, int lane, const f32x4 (&v)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) Elem<T>::st4(p + c * 256 + lane * 4, v[c]);
+}
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[NCH], float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { float d = v[c][k] - mean; q += d * d; }
+    rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+}
+
+// block-level fold of per-wave register partials: acc[K][NCH] f32x4 per lane -> partial[blockIdx][K*D]
+template <int K>
+__device__ __forceinline__ void fold_partials(f32x4 (&acc)[K][NCH], float* partial, float* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *(f32x4*)(lds + ((w * K + k) * D) + c * 256 + lane * 4) = acc[k][c];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * D; i += 256) {
+        float s = lds[i] + lds[K * D + i] + lds[2 * K * D + i] + lds[3 * K * D + i];
+        partial[(size_t)blockIdx.x * K * D + i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- fused input rows
+// mode 0 concat (ref :299-300): rows t<L: x + seg0 + pos[t]; row L: img + seg1 + pos[L]; row L+1: txt + seg1 + pos[L+1]
+// mode 1 add    (ref :306-307): rows t<L: x + img (+ txt if add_txt[n]) + pos[t]
+__device__ __forceinline__ void fused_row(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                                          const float* seg, const float* pos, int n, int t, int L, int lane, f32x4 (&v)[NCH]) {
+    f32x4 p[NCH];
+    load_row<float>(pos + (size_t)t * D, lane, p);
+    if (mode == 0) {
+        const float* src = t < L ? x + ((size_t)n * L + t) * D : (t == L ? img + (size_t)n * D : txt + (size_t)n * D);
+        f32x4 s[NCH];
+        load_row<float>(src, lane, v);
+        load_row<float>(seg + (t < L ? 0 : D), lane, s);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = (v[c] + s[c]) + p[c];     // hstack + segment (ref :300), then + position (hf:115)
+    } else {
+        f32x4 a[NCH];
+        load_row<float>(x + ((size_t)n * L + t) * D, lane, v);
+        load_row<float>(img + (size_t)n * D, lane, a);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = v[c] + a[c];
+        if (add_txt && add_txt[n]) {
+            load_row<float>(txt + (size_t)n * D, lane, a);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) v[c] = v[c] + a[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = v[c] + p[c];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                                                           const float* seg, const float* pos, const float* gamma, const float* beta, T* h,
+                                                           float* mean, float* rstd, int N, int L, int Tk, float eps, float p_drop,
+                                                           unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const int rows = N * Tk;
+    f32x4 g[NCH], b[NCH];
+    load_row<float>(gamma, lane, g);
+    load_row<float>(beta, lane, b);
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int n = row / Tk, t = row - n * Tk;
+        f32x4 v[NCH];
+        fused_row(mode, x, img, txt, add_txt, seg, pos, n, t, L, lane, v);
+        float mu, rs;
+        row_stats(v, eps, mu, rs);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[c][k] = (v[c][k] - mu) * rs * g[c][k] + b[c][k];
+            if (p_drop > 0.f) v[c] = dropout4(v[c], seed, (unsigned long long)row * D + c * 256 + lane * 4, p_drop, inv_keep);
+        }
+        store_row<T>(h + (size_t)row * D, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_ln_bwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                                                           const float* seg, const float* pos, const float* gamma, const T* dh,
+                                                           const float* mean, const float* rstd, float* dy, float* partial, int N, int L, int Tk,
+                                                           float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int rows = N * Tk;
+    f32x4 g[NCH];
+    load_row<float>(gamma, lane, g);
+    f32x4 acc[2][NCH];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int n = row / Tk, t = row - n * Tk;
+        f32x4 v[NCH], d[NCH];
+        fused_row(mode, x, img, txt, add_txt, seg, pos, n, t, L, lane, v);
+        load_row<T>(dh + (size_t)row * D, lane, d);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (p_drop > 0.f) d[c] = dropout4(d[c], seed, (unsigned long long)row * D + c * 256 + lane * 4, p_drop, inv_keep);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xh = (v[c][k] - mu) * rs;
+                float gg = d[c][k] * g[c][k];
+                acc[0][c][k] += d[c][k] * xh;
+                acc[1][c][k] += d[c][k];
+                c1 += gg; c2 += gg * xh;
+                v[c][k] = xh; d[c][k] = gg;
+            }
+        }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[c][k] = rs * (d[c][k] - c1 - v[c][k] * c2);
+        store_row<float>(dy + (size_t)row * D, lane, d);
+    }
+    fold_partials<2>(acc, partial, lds);
+}
+
+// ---------------------------------------------------------------------------------------------- plain LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* y, const float* gamma, const float* beta, T* h, float* mean, float* rstd, int rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    f32x4 g[NCH], b[NCH];
+    load_row<float>(gamma, lane, g);
+    load_row<float>(beta, lane, b);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        f32x4 v[NCH];
+        load_row<T>(y + (size_t)row * D, lane, v);
+        float mu, rs;
+        row_stats(v, eps, mu, rs);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[c][k] = (v[c][k] - mu) * rs * g[c][k] + b[c][k];
+        store_row<T>(h + (size_t)row * D, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dh, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
+                                                      float p_drop, unsigned long long seed, float* partial, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    f32x4 g[NCH];
+    load_row<float>(gamma, lane, g);
+    f32x4 acc[3][NCH];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        f32x4 v[NCH], d[NCH];
+        load_row<T>(y + (size_t)row * D, lane, v);
+        load_row<T>(dh + (size_t)row * D, lane, d);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xh = (v[c][k] - mu) * rs;
+                float gg = d[c][k] * g[c][k];
+                acc[0][c][k] += d[c][k] * xh;
+                acc[1][c][k] += d[c][k];
+                c1 += gg; c2 += gg * xh;
+                v[c][k] = xh; d[c][k] = gg;
+            }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[c][k] = rs * (d[c][k] - c1 - v[c][k] * c2);
+        store_row<T>(dx + (size_t)row * D, lane, d);
+        if (dx_drop) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) d[c] = dropout4(d[c], seed, (unsigned long long)row * D + c * 256 + lane * 4, p_drop, inv_keep);
+            store_row<T>(dx_drop + (size_t)row * D, lane, d);
+        }
+        // bias gradient of the Linear that produced y: column sum of what flows into it
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[2][c] += d[c];
+    }
+    fold_partials<3>(acc, partial, lds);
+}
+
+// ---------------------------------------------------------------------------------------------- GELU + LayerNorm (hf:511-512)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const T* u, const float* gamma, const float* beta, float* x_out, float* mean, float* rstd, int rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    f32x4 g[NCH], b[NCH];
+    load_row<float>(gamma, lane, g);
+    load_row<float>(beta, lane, b);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        f32x4 v[NCH];
+        load_row<T>(u + (size_t)row * D, lane, v);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[c][k] = gelu_f(v[c][k]);
+        float mu, rs;
+        row_stats(v, eps, mu, rs);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[c][k] = (v[c][k] - mu) * rs * g[c][k] + b[c][k];
+        store_row<float>(x_out + (size_t)row * D, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dx_out, const T* u, const float* gamma, const float* mean, const float* rstd, T* du,
+                                                           float* partial, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    f32x4 g[NCH];
+    load_row<float>(gamma, lane, g);
+    f32x4 acc[3][NCH];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        f32x4 uu[NCH], v[NCH], d[NCH];
+        load_row<T>(u + (size_t)row * D, lane, uu);
+        load_row<float>(dx_out + (size_t)row * D, lane, d);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xh = (gelu_f(uu[c][k]) - mu) * rs;
+                float gg = d[c][k] * g[c][k];
+                acc[0][c][k] += d[c][k] * xh;
+                acc[1][c][k] += d[c][k];
+                c1 += gg; c2 += gg * xh;
+                v[c][k] = xh; d[c][k] = gg;
+            }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[c][k] = rs * (d[c][k] - c1 - v[c][k] * c2) * gelu_grad_f(uu[c][k]);
+            acc[2][c] += d[c];
+        }
+        store_row<T>(du + (size_t)row * D, lane, d);
+    }
+    fold_partials<3>(acc, partial, lds);
+}
+
+inline int rows_grid(int rows, int cap) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > cap ? cap : g); }
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF, CALL_F32) do { if ((dtype) == DIC_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
+
+extern "C" int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                               const float* seg, const float* pos, const float* gamma, const float* beta, void* h, float* mean,
+                               float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
+    DIC_REQUIRE(Dd == D, "dic_fuse_ln_fwd: D must be 768");
+    const int Tk = mode == 0 ? L + 2 : L;
+    dim3 grid(rows_grid(N * Tk, 2048)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed),
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                               const float* seg, const float* pos, const float* gamma, const void* dh, const float* mean,
+                               const float* rstd, float* dy, float* partial, int n_partial_blocks, int N, int L, int Dd, float p_drop,
+                               uint64_t seed, void* stream) {
+    DIC_REQUIRE(Dd == D && n_partial_blocks > 0, "dic_fuse_ln_bwd: D must be 768");
+    const int Tk = mode == 0 ? L + 2 : L;
+    dim3 grid(n_partial_blocks), block(256);
+    const size_t lds = 4 * 2 * D * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(fuse_ln_bwd_kernel<bf16_t>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, gamma, (const bf16_t*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed),
+               hipLaunchKernelGGL(fuse_ln_bwd_kernel<float>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, gamma, (const float*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_ln_fwd(int dtype, const void* y, const float* gamma, const float* beta, void* h, float* mean, float* rstd, int T,
+                          int Dd, float eps, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0, "dic_ln_fwd: D must be 768");
+    dim3 grid(rows_grid(T, 2048)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)y, gamma, beta, (bf16_t*)h, mean, rstd, T, eps),
+               hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, (const float*)y, gamma, beta, (float*)h, mean, rstd, T, eps));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx,
+                          void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks, int T, int Dd, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0 && n_partial_blocks > 0, "dic_ln_bwd: D must be 768");
+    dim3 grid(n_partial_blocks), block(256);
+    const size_t lds = 4 * 3 * D * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, (unsigned long long)seed, partial, T),
+               hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, lds, st, (const float*)dh, (const float*)y, gamma, mean, rstd, (float*)dx, (float*)dx_drop, p_drop, (unsigned long long)seed, partial, T));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_gelu_ln_fwd(int dtype, const void* u, const float* gamma, const float* beta, float* x_out, float* mean, float* rstd,
+                               int T, int Dd, float eps, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0, "dic_gelu_ln_fwd: D must be 768");
+    dim3 grid(rows_grid(T, 2048)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(gelu_ln_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)u, gamma, beta, x_out, mean, rstd, T, eps),
+               hipLaunchKernelGGL(gelu_ln_fwd_kernel<float>, grid, block, 0, st, (const float*)u, gamma, beta, x_out, mean, rstd, T, eps));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_gelu_ln_bwd(int dtype, const float* dx_out, const void* u, const float* gamma, const float* mean, const float* rstd,
+                               void* du, float* partial, int n_partial_blocks, int T, int Dd, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0 && n_partial_blocks > 0, "dic_gelu_ln_bwd: D must be 768");
+    dim3 grid(n_partial_blocks), block(256);
+    const size_t lds = 4 * 3 * D * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(gelu_ln_bwd_kernel<bf16_t>, grid, block, lds, st, dx_out, (const bf16_t*)u, gamma, mean, rstd, (bf16_t*)du, partial, T),
+               hipLaunchKernelGGL(gelu_ln_bwd_kernel<float>, grid, block, lds, st, dx_out, (const float*)u, gamma, mean, rstd, (float*)du, partial, T));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,335 @@
+"""Diffusion schedule, q_sample, loss, training step, validation and sampling with the reference's call
+signatures (ref CLIP-DDPM.py:337-501, 611-621), executed by the HIP kernels behind `engine.Denoiser`.
+
+Signatures kept:
+    diffuse_t(x, t) -> [t.numel()*B, L, C]            generate_diffuse_pair(x_0, t, t_next=None)
+    loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, loss_func) -> (x_t_loss, x_1_loss, prob_loss)
+    train_func(model, trainer, x, train=True) -> (l, x_t_loss, x_1_loss, prob_loss)
+    validate(model) -> (val_x_t, val_x_1, val_prob)   sample(model, image_clip, steps=5) -> LongTensor[B, L]
+Optional keyword-only arguments (`noise=`, `t=`, `noises=`, `cfg_uniform=`) inject the random draws so parity
+tests can feed the exact values the CPU reference used; without them the draws come from the device RNG
+(Philox inside the q_sample / dropout kernels, torch.randint/rand for the handful of host-side scalars).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from .config import LOSS_KINDS, cfg
+from .engine import Denoiser, _p
+
+_state = {"ac_key": None, "ac": None, "noise_seed": 0xD1FF0000, "val_loader": None, "trainer": None}
+
+
+# ------------------------------------------------------------------ schedule (ref :337-346)
+def alpha_cumprod_table(device=None) -> torch.Tensor:
+    """alpha-bar[t], computed on the host exactly as the reference does (cosine: :338-342, linear: :344-346)."""
+    key = (cfg.COSIN_SCHEDULE, cfg.STEP_TOT, cfg.BETA_MIN, cfg.BETA_MAX, str(device))
+    if _state["ac_key"] != key:
+        if cfg.COSIN_SCHEDULE:
+            s = 0.008
+
+            def sched(t):
+                return torch.cos(math.pi / 2 * (t / cfg.STEP_TOT + s) / (1 + s)) ** 2
+            ac = sched(torch.arange(cfg.STEP_TOT)) / sched(torch.zeros(1))
+        else:
+            betas = torch.hstack([torch.zeros(1), torch.linspace(cfg.BETA_MIN, cfg.BETA_MAX, cfg.STEP_TOT)])
+            ac = torch.cumprod((1 - betas)[:-1], 0)
+        _state["ac"] = ac.to(torch.float32).to(device if device is not None else "cuda:0").contiguous()
+        _state["ac_key"] = key
+    return _state["ac"]
+
+
+def seed_noise(seed: int):
+    _state["noise_seed"] = int(seed)
+
+
+def _next_seed():
+    _state["noise_seed"] += 0x9E3779B1
+    return _state["noise_seed"] & 0xFFFFFFFFFFFFFFFF
+
+
+# ------------------------------------------------------------------ q_sample (ref :347-362)
+def diffuse_t(x, t, *, noise=None, out=None):
+    """x [B,L,C] fp32, t [S,...] int64 -> [S*B, L, C]; ONE noise tensor per call shared by all S (ref :359)."""
+    _lib.require_gpu()
+    L = _lib.lib()
+    b, seq_len, c = x.shape
+    dev = x.device
+    x = x.contiguous()
+    t = t.to(dev, torch.int64).reshape(-1).contiguous()
+    S = t.numel()
+    ac = alpha_cumprod_table(dev)
+    if out is None:
+        out = torch.empty(S * b, seq_len, c, dtype=torch.float32, device=dev)
+    nz = noise.to(dev, torch.float32).contiguous() if noise is not None else None
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.dic_qsample(_p(x), _p(nz), _p(t), _p(ac), _p(out), 0, S, b, seq_len * c, cfg.STEP_TOT, _next_seed(), st), "qsample")
+    return out
+
+
+def generate_diffuse_pair(x_0, t, t_next=None, *, noises=(None, None)):
+    """ref :364-380."""
+    if cfg.X_0_PREDICTION:
+        return diffuse_t(x_0, t, noise=noises[0]), x_0
+    return diffuse_t(x_0, t, noise=noises[0]), diffuse_t(x_0, t_next, noise=noises[1])
+
+
+# ------------------------------------------------------------------ loss (ref :382-445)
+def _loss_kind(loss_func):
+    name = loss_func if isinstance(loss_func, str) else getattr(loss_func, "__name__", None)
+    if name is None:
+        name = cfg.LOSS_FUNC
+    if name not in LOSS_KINDS:
+        raise NotImplementedError(f"loss function {name}")
+    return LOSS_KINDS[name]
+
+
+def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, loss_func=None, *, cfg_uniform=None):
+    S, B, L, C_ = cfg.SAMPLE_SIZE, cfg.BATCH_SIZE, cfg.MAX_LENGTH, cfg.IN_CHANNEL
+    assert x_t.shape == (S * B, L, C_)
+    assert x_1.shape == x_0.shape == (B, L, C_)
+    assert image_clip.shape == text_clip.shape == (B, 512)
+    assert mask.shape == (B, L)
+    assert idx.shape == (B, L)
+    kind = _loss_kind(loss_func)
+    dev = model.device
+    lib = _lib.lib()
+    Nt = S * B
+    w = float(cfg.CLASSIFIER_FREE_WEIGHT)
+    want_grad = torch.is_grad_enabled()
+
+    # ---- classifier-free-guidance draw (ref :406-412)
+    gi = None
+    if w > 0:
+        u = cfg_uniform.to(dev) if cfg_uniform is not None else torch.rand((Nt, 1), device=dev)
+        cm = (u > cfg.CLASSIFIER_FREE_PROB).reshape(Nt)
+        if model.rank_rows_forced:
+            cm[0] = False
+            cm[1] = True
+        gi = cm.nonzero().squeeze(1)
+        if gi.numel() == 0:
+            gi = None
+    Ng = 0 if gi is None else int(gi.numel())
+    N = Nt + Ng + B
+    ws = model._workspace(N, L)
+    Tk = ws["Tk"]
+
+    # ---- one stacked encoder batch: [x_t rows | guided copies | x_1 rows]
+    xin = ws["xin"]
+    xin[:Nt].copy_(x_t)
+    xin[Nt + Ng:].copy_(x_1)
+    img = image_clip.to(dev, torch.float32)
+    txt = text_clip.to(dev, torch.float32)
+    img_rep, txt_rep = img.repeat(S, 1), txt.repeat(S, 1)
+    m = (mask.to(dev) != 0).to(torch.uint8)
+    m_rep = m.repeat(S, 1)
+    if model.concat:
+        one_t, one_b = torch.ones(Nt, 1, dtype=torch.uint8, device=dev), torch.ones(B, 1, dtype=torch.uint8, device=dev)
+        plain_t = torch.cat([m_rep, one_t, 0 * one_t], 1)
+        plain_b = torch.cat([m, one_b, 0 * one_b], 1)
+    else:
+        plain_t, plain_b = m_rep, m
+    add_txt = torch.zeros(N, dtype=torch.uint8, device=dev)
+    if Ng:
+        xin[Nt:Nt + Ng].copy_(x_t[gi])
+        g_mask = torch.cat([m_rep[gi], one_t[:Ng], one_t[:Ng]], 1) if model.concat else m_rep[gi]
+        ic = torch.cat([img_rep, img_rep[gi], img])
+        tc = torch.cat([txt_rep, txt_rep[gi], txt])
+        km = torch.cat([plain_t, g_mask, plain_b])
+        add_txt[Nt:Nt + Ng] = 1
+    else:
+        ic, tc, km = torch.cat([img_rep, img]), torch.cat([txt_rep, txt]), torch.cat([plain_t, plain_b])
+    x_out = model.encode(xin, ic, tc, km, add_txt)
+    st = model.ops.stream
+    row = Tk * 768
+    if Ng:
+        _lib.check(lib.dic_cfg_mix_fwd(_p(x_out), _p(x_out) + Nt * row * 4, _p(gi), Ng, row, w, st), "cfg_mix_fwd")
+
+    # ---- embedding losses (ref :77-87, 418, 428) + compact rows for the rounding head
+    sc = ws.get("loss_sc")
+    if sc is None:
+        sc = ws["loss_sc"] = dict(per_seq=torch.zeros(N, dtype=torch.float32, device=dev),
+                                  gscale=torch.zeros(N, dtype=torch.float32, device=dev),
+                                  out=torch.zeros(8, dtype=torch.float32, device=dev))
+    inv768 = 1.0 / 768.0
+    if kind == 0:
+        sa, sb = inv768 / Nt, inv768 / B
+    elif kind == 1:
+        sa = sb = 1.0 / cfg.BATCH_SIZE / 768 / 100
+    elif kind == 2:
+        sa, sb = 1.0 / Nt, 1.0 / B
+    else:
+        sa = sb = 1.0 / cfg.BATCH_SIZE
+    if not cfg.USE_X_T_LOSS:
+        sa = 0.0
+    if not cfg.USE_X_1_LOSS:
+        sb = 0.0
+    M = (Nt + B) * L
+    cw = model._ce_workspace(M)
+    dx = ws["dx_out"]
+    if want_grad:
+        sc["gscale"][:Nt].fill_(sa)
+        sc["gscale"][Nt:Nt + B].fill_(sb)
+        if Ng:
+            dx[Nt:Nt + Ng].zero_()
+    tgt_t, tgt_rows = (x_0, B) if cfg.X_0_PREDICTION else (x_tgt, Nt)
+    if not cfg.X_0_PREDICTION:
+        assert x_tgt.shape == x_t.shape
+    tgt_t = tgt_t.contiguous()
+    x_0c = x_0.contiguous()
+    es = model.es
+    _lib.check(lib.dic_emb_loss(model.dt, kind, _p(x_out), _p(tgt_t), tgt_rows, _p(sc["per_seq"]), _p(dx) if want_grad else 0,
+                                _p(sc["gscale"]), _p(cw["xr"]), Nt, L, Tk, 768, st), "emb_loss")
+    off = (Nt + Ng) * row * 4
+    _lib.check(lib.dic_emb_loss(model.dt, kind, _p(x_out) + off, _p(x_0c), B, _p(sc["per_seq"]) + Nt * 4, (_p(dx) + off) if want_grad else 0,
+                                _p(sc["gscale"]) + Nt * 4, _p(cw["xr"]) + Nt * L * 768 * es, B, L, Tk, 768, st), "emb_loss")
+    _lib.check(lib.dic_seg_sum(_p(sc["per_seq"]), Nt + B, Nt, sa, sb, _p(sc["out"]), st), "seg_sum")
+
+    # ---- rounding loss (ref :432-445): streaming GEMM + logsumexp + gather, logits never materialised
+    if cfg.USE_PROB_LOSS:
+        ids = idx.to(dev, torch.int64)
+        cw["tgt"][:Nt * L].copy_(ids.repeat(S, 1).reshape(-1))
+        cw["tgt"][Nt * L:].copy_(ids.reshape(-1))
+        model.rounding(cw["xr"], M, cw["tgt"], cw)
+        ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
+        cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
+        rw = float(cfg.ROUNDING_WEIGHT)
+        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(sc["out"]) + 4 * 4, st), "seg_sum")
+        if want_grad:
+            dxr = model.rounding_backward(cw, M, Nt * L, rw * ca, rw * cb)
+            _lib.check(lib.dic_add_rows(_p(dx), _p(dxr), Nt, L, Tk, 768, st), "add_rows")
+            _lib.check(lib.dic_add_rows(_p(dx) + off, _p(dxr) + Nt * L * 768 * 4, B, L, Tk, 768, st), "add_rows")
+        prob = sc["out"][6]
+    else:
+        prob = torch.zeros((), dtype=torch.float32, device=dev)
+    if want_grad and Ng:
+        _lib.check(lib.dic_cfg_mix_bwd(_p(dx), _p(dx) + Nt * row * 4, _p(gi), Ng, row, w, st), "cfg_mix_bwd")
+    model._pending = want_grad
+    return sc["out"][0], sc["out"][1], prob
+
+
+# ------------------------------------------------------------------ AdamW (ref :335)
+class AdamW:
+    """torch.optim.AdamW semantics (lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0.01, one param group covering
+    every tensor) as ONE fused HIP launch over the flat parameter buffer.  `param_groups[0]['lr']` is mutable, as the
+    reference's epoch loop expects (ref :520-522)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        params = list(params)
+        store = getattr(params[0], "_dic_store", None)
+        if store is None:
+            raise TypeError("dic.AdamW needs the tensors returned by Denoiser.parameters()")
+        self.store = store
+        self.param_groups = [dict(params=params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.m = torch.zeros_like(store.P)
+        self.v = torch.zeros_like(store.P)
+        self.t = 0
+        self.grad_scale = 1.0          # 1/world_size after the RCCL sum (parallel.py)
+
+    def zero_grad(self, set_to_none=False):
+        self.store.G.zero_()
+
+    def step(self):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.t += 1
+        s = self.store
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().dic_adamw(_p(s.P), _p(s.G), _p(self.m), _p(self.v), _p(s.Pb), s.numel, float(g["lr"]), b1, b2, g["eps"],
+                                        g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, self.grad_scale, st), "adamw")
+
+    def state_dict(self):
+        return dict(t=self.t, m=self.m.clone(), v=self.v.clone(), param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self.t = sd["t"]
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.param_groups[0].update(sd["param_groups"][0])
+
+
+# ------------------------------------------------------------------ training step (ref :458-486)
+def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, cfg_uniform=None):
+    from . import parallel
+    dev = model.device
+    x_0 = model.embedding(x["input_ids"].to(dev))
+    S = cfg.SAMPLE_SIZE
+    if t is None:
+        t = parallel.shared_randint(0, cfg.STEP_TOT, (S, 1, 1), dev)     # one t-vector per step shared by the batch (ref :461)
+    t = t.to(dev)
+    nz = list(noises) if noises is not None else [None, None, None]
+    if cfg.X_0_PREDICTION:
+        x_t = diffuse_t(x_0, t, noise=nz.pop(0))
+        x_tgt = None
+    else:
+        t_next = torch.max(t - cfg.X_T_STEP_INTERVAL, torch.zeros_like(t))
+        x_t, x_tgt = generate_diffuse_pair(x_0, t, t_next, noises=(nz.pop(0), nz.pop(0)))
+    x_1 = diffuse_t(x_0, torch.ones(1, dtype=torch.int64, device=dev), noise=nz.pop(0))
+    if train:
+        trainer.zero_grad()
+    x_t_loss, x_1_loss, prob_loss = loss(model, x_t, x_1, x_tgt, x_0, x["image_clip"], x["text_clip"], x["attention_mask"],
+                                         x["input_ids"], cfg.LOSS_FUNC, cfg_uniform=cfg_uniform)
+    l = x_t_loss + x_1_loss + prob_loss
+    if train:
+        if not model._pending:
+            raise RuntimeError("train_func(train=True) called under torch.no_grad()")
+        model.backward()
+        parallel.allreduce_grads(model, trainer)
+        if not isinstance(trainer, AdamW):
+            model.params.relink_grads()
+        trainer.step()
+        if not isinstance(trainer, AdamW):
+            model.refresh_shadows()
+    return l, x_t_loss, x_1_loss, prob_loss
+
+
+# ------------------------------------------------------------------ validation (ref :488-501)
+def set_loaders(val_loader=None, trainer=None):
+    _state["val_loader"], _state["trainer"] = val_loader, trainer
+
+
+def validate(model: Denoiser, val_loader=None):
+    val_loader = val_loader if val_loader is not None else _state["val_loader"]
+    acc = [0, 0, 0]
+    model.eval()
+    with torch.no_grad():
+        n = 0
+        for x in val_loader:
+            _, a, b, c = train_func(model, _state["trainer"], x, train=False)
+            acc = [acc[0] + a.clone(), acc[1] + b.clone(), acc[2] + c.clone()]
+            n += 1
+    model.train()
+    return acc[0] / n, acc[1] / n, acc[2] / n
+
+
+# ------------------------------------------------------------------ sampling loop (ref :611-621, COCO_BLEU.py:249-256)
+@torch.no_grad()
+def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=False):
+    """x_0-prediction refinement from pure noise: `steps` encoder passes feeding the prediction straight back in,
+    then round to token ids.  The logits are only needed after the last pass, and only their argmax: the
+    rounding GEMM runs in exact fp32 (MFMA f32) with a streaming arg-max, so ids match the CPU oracle bit-for-bit."""
+    dev = model.device
+    B, L = image_clip.shape[0], cfg.MAX_LENGTH
+    Tk = L + 2 if model.concat else L
+    img = image_clip.to(dev, torch.float32)
+    restored = start.to(dev, torch.float32) if start is not None else torch.randn(B, L + 2, cfg.IN_CHANNEL, device=dev)
+    one = torch.ones(B, 1, dtype=torch.uint8, device=dev)
+    km = torch.cat([torch.ones(B, L, dtype=torch.uint8, device=dev), one, 0 * one], 1) if model.concat else torch.ones(B, L, dtype=torch.uint8, device=dev)
+    zeros = torch.zeros_like(img)
+    x = restored[:, :L, :].contiguous()
+    for _ in range(steps):
+        x_out = model.encode(x, img, zeros, km)
+        x = x_out[:, :L, :].contiguous()
+    xr = x.reshape(B * L, 768)
+    _, ids, _ = model.rounding(xr, B * L, dtype=_lib.DIC_F32)
+    ids = ids.clone().reshape(B, L)
+    return (ids, x_out.clone()) if return_hidden else ids
+
+
+def dedup_columns(ids: torch.Tensor) -> torch.Tensor:
+    """`indexes.unique_consecutive(dim=-1)` (ref :621): removes a COLUMN only when it repeats the previous column
+    across the whole batch (per-token de-duplication only when B == 1)."""
+    return ids.unique_consecutive(dim=-1)

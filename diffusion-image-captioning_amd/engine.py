@@ -1,0 +1,397 @@
+"""`DistilBertModel` drop-in (ref CLIP-DDPM.py:227-323) driven entirely by the HIP library.
+
+There is no autograd here: `encode()` keeps the activations the backward kernels need in a pre-allocated
+workspace and `backward()` walks the layers in reverse, launching the hand-written HIP kernels through the C-ABI
+(`include/dic_hip.h`).  torch is used for device memory, the current stream and (in parallel.py) RCCL only.
+
+Batching trick: the reference runs up to three encoder passes per training step (x_t rows, the classifier-free-
+guidance subset again with the text key unmasked, and the x_1 rows; ref :312, :316, :426).  The encoder is
+row-independent, so this engine stacks them into ONE batch with a per-sequence key mask; every weight then sees
+one forward GEMM, one dX GEMM and one dW GEMM per step, which is what fills 256 CUs at small B.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DIC_BF16, DIC_F32, EPI_AFFINE, EPI_BIAS_GELU, EPI_CE_DLOGITS, EPI_CE_PARTIAL, EPI_GELU_BWD, GemmParams
+from .config import LOSS_KINDS, cfg
+from .params import ParamStore
+
+LN_EPS = 1e-12
+NPART = 256          # persistent blocks (= partial rows) of the LayerNorm backward kernels
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Ops:
+    """Thin callers of the C-ABI on the current torch stream."""
+
+    def __init__(self, dtype_flag: int):
+        self.L = _lib.lib()
+        self.dt = dtype_flag
+        self._gp = GemmParams()
+        self.stream = None
+
+    def begin(self):
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
+             ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None):
+        g = self._gp
+        g.A, g.B, g.C = A, B, Cc
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
+        g.bias, g.R, g.ldr, g.aux, g.ldaux = bias, R, ldr, aux, ldaux
+        g.p_drop, g.seed, g.out_f32, g.accumulate = p_drop, seed, out_f32, accumulate
+        g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
+        g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
+        _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
+
+
+class Denoiser:
+    """Same constructor shape as the reference: `DistilBertModel(embedding, projection, config=...)`.
+
+    embedding / projection: objects with `.weight` ([V,768]; nn.Embedding / nn.Linear work) or raw arrays/tensors.
+    The projection bias is zeroed as ref :247 does.  `config` may be a HF DistilBertConfig-like object or a dict with
+    `n_layers`, `dropout`, `attention_dropout`.
+    """
+
+    def __init__(self, embedding=None, projection=None, config=None, *, dtype="bf16", device="cuda:0", seed=0):
+        _lib.require_gpu()
+        get = (lambda k, d: config.get(k, d)) if isinstance(config, dict) else (lambda k, d: getattr(config, k, d))
+        self.n_layers = int(get("n_layers", 6)) if config is not None else 6
+        self.p_hidden = float(get("dropout", 0.1)) if config is not None else 0.1
+        self.p_attn = float(get("attention_dropout", 0.1)) if config is not None else 0.1
+        self.n_heads, self.dim, self.hidden = 12, 768, 3072
+        self.device = torch.device(device)
+        self.bf16 = dtype in ("bf16", torch.bfloat16)
+        self.dt = DIC_BF16 if self.bf16 else DIC_F32
+        self.tdtype = torch.bfloat16 if self.bf16 else torch.float32
+        self.es = 2 if self.bf16 else 4
+        self.concat = cfg.CLIP_ADDING_METHOD == "concat"
+        if cfg.CLIP_ADDING_METHOD not in ("concat", "add"):
+            raise NotImplementedError(cfg.CLIP_ADDING_METHOD)
+        self.training = True
+        self.ops = Ops(self.dt)
+        self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16)
+        self.params.init_like_reference(seed)
+        self._set_embedding(embedding, projection)
+        self.refresh_shadows()
+        self._ws = {}
+        self._seed = 0x5EED0000 + seed
+        self._saved = None
+        self._pending = False
+        self.rank_rows_forced = True     # CFG forces rows 0/1 to unguided/guided (ref :408-409); DP: rank 0 only
+
+    # ------------------------------------------------------------------ frozen embedding / rounding head
+    def _set_embedding(self, embedding, projection):
+        def weight_of(x, default_seed):
+            if x is None:
+                from . import synth
+                return torch.from_numpy(synth.vocab_embedding(cfg.VOCAB_SIZE, 768, default_seed))
+            w = getattr(x, "weight", x)
+            w = torch.from_numpy(np.ascontiguousarray(w)) if isinstance(w, np.ndarray) else w
+            return w.detach()
+        E = weight_of(embedding, 0).to(self.device, torch.float32).contiguous()
+        W = E if projection is None else weight_of(projection, 0).to(self.device, torch.float32).contiguous()
+        self.E = E
+        self.vocab = E.shape[0]
+        self.vpad = (self.vocab + 127) // 128 * 128
+        # rounding-head operand, rows zero-padded to a tile multiple so it can be read k-major in the dX GEMM
+        self.W_lm = torch.zeros(self.vpad, 768, dtype=torch.float32, device=self.device)
+        self.W_lm[:self.vocab].copy_(W)
+        self.W_lm_c = self.W_lm.to(torch.bfloat16).contiguous() if self.bf16 else self.W_lm
+
+    def refresh_shadows(self):
+        """bf16 copies of the parameters for the MFMA operands (dic_adamw keeps them fresh itself)."""
+        if self.bf16:
+            self.ops.begin()
+            _lib.check(self.ops.L.dic_cast_bf16(_p(self.params.P), _p(self.params.Pb), self.params.numel, self.ops.stream), "cast")
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def parameters(self):
+        return self.params.parameters()
+
+    def named_parameters(self):
+        return self.params.named_parameters()
+
+    def load_state(self, state):
+        self.params.load_state(state)
+        self.refresh_shadows()
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    def embedding(self, ids):
+        """ref :459 -- frozen nn.Embedding lookup -> fp32 [..., 768]."""
+        ids = ids.to(self.device, torch.int64).contiguous()
+        out = torch.empty(*ids.shape, 768, dtype=torch.float32, device=self.device)
+        self.ops.begin()
+        _lib.check(self.ops.L.dic_embed_gather(_p(ids), _p(self.E), _p(out), ids.numel(), 768, self.vocab, self.ops.stream), "embed")
+        return out
+
+    def lm_head(self, h):
+        """ref :323 -- logits = h @ W^T (bias is zero); materialises [.., V] fp32 (API use; training never does)."""
+        shp = h.shape[:-1]
+        x = h.reshape(-1, 768).to(self.device, self.tdtype).contiguous()
+        M = x.shape[0]
+        out = torch.empty(M, self.vocab + (-self.vocab) % 4, dtype=torch.float32, device=self.device)
+        self.ops.begin()
+        self.ops.gemm(_p(x), _p(self.W_lm_c), _p(out), M, out.shape[1], 768, 768, 768, out.shape[1], out_f32=1)
+        return out[:, :self.vocab].reshape(*shp, self.vocab)
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, N, L):
+        Tk = L + 2 if self.concat else L
+        key = (N, L)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        if len(self._ws) > 8:
+            self._ws.clear()
+        T, D, Hd, dev, td = N * Tk, self.dim, self.hidden, self.device, self.tdtype
+        e = lambda *s, dtype=td: torch.empty(*s, dtype=dtype, device=dev)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        ws = dict(N=N, L=L, Tk=Tk, T=T)
+        ws["img_in"], ws["txt_in"] = f(N, 512), f(N, 512)
+        ws["img_p"], ws["txt_p"] = f(N, D), f(N, D)
+        ws["xin"] = f(N, L, D)
+        ws["kmask"] = torch.empty(N, Tk, dtype=torch.uint8, device=dev)
+        ws["addtxt"] = torch.zeros(N, dtype=torch.uint8, device=dev)
+        ws["h"] = [e(T, D) for _ in range(self.n_layers + 1)]
+        ws["mean0"], ws["rstd0"] = f(T), f(T)
+        ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=e(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
+                             y2=e(T, D), m2=f(T), r2=f(T)) for _ in range(self.n_layers)]
+        ws["uvt"], ws["mv"], ws["rv"] = e(T, D), f(T), f(T)
+        ws["x_out"] = f(N, Tk, D)
+        # backward scratch (shared by all layers)
+        ws["dx_out"] = f(N, Tk, D)
+        ws["dHa"], ws["dHb"] = e(T, D), e(T, D)
+        ws["dy"], ws["dyd"], ws["dsa"], ws["dy1"], ws["dctx"] = e(T, D), e(T, D), e(T, D), e(T, D), e(T, D)
+        ws["du"], ws["dqkv"] = e(T, Hd), e(T, 3 * D)
+        ws["dy0"] = f(N, Tk, D)
+        ws["partial"] = f(NPART, 3 * D)
+        ws["cs_ws"] = f(64 * max(Tk * D, Hd))
+        ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
+        self._ws[key] = ws
+        return ws
+
+    def _ce_workspace(self, M):
+        ws = self._ws.get(("ce", M))
+        if ws is None:
+            dev = self.device
+            np_ = 2 * ((self.vocab + 127) // 128)
+            ws = dict(M=M, np=np_, xr=torch.empty(M, 768, dtype=self.tdtype, device=dev),
+                      partial=torch.empty(M, np_, 4, dtype=torch.float32, device=dev),
+                      tgt_logit=torch.zeros(M, dtype=torch.float32, device=dev), lse=torch.empty(M, dtype=torch.float32, device=dev),
+                      argmax=torch.empty(M, dtype=torch.int64, device=dev), nll=torch.empty(M, dtype=torch.float32, device=dev),
+                      tgt=torch.empty(M, dtype=torch.int64, device=dev), dxr=torch.empty(M, 768, dtype=torch.float32, device=dev),
+                      dlogits=None)
+            self._ws[("ce", M)] = ws
+        return ws
+
+    # ------------------------------------------------------------------ encoder forward (hf:92-118, 150-259, 501-513)
+    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None):
+        """x [N,L,768] fp32; image_clip/text_clip [N,512]; key_mask [N,Tk] uint8 -> x_out [N,Tk,768] fp32.
+        Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training."""
+        N, L, _ = x.shape
+        ws = self._workspace(N, L)
+        Tk, T, D, Hd = ws["Tk"], ws["T"], self.dim, self.hidden
+        o, P, lib = self.ops, self.params, self.ops.L
+        o.begin()
+        st = o.stream
+        wsrc = "Pb" if self.bf16 else "P"
+        ph = self.p_hidden if self.training else 0.0
+        pa = self.p_attn if self.training else 0.0
+        self._seed += 64
+        seed = self._seed
+        ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
+        if x.data_ptr() != ws["xin"].data_ptr():
+            ws["xin"].copy_(x)
+        ws["img_in"].copy_(image_clip.reshape(N, 512))
+        ws["txt_in"].copy_(text_clip.reshape(N, 512))
+        ws["kmask"].copy_(key_mask)
+        if add_txt is not None:
+            ws["addtxt"].copy_(add_txt)
+        mode = 0 if self.concat else 1
+        # K3: CLIP projections, exact fp32 MFMA (tiny)
+        o.gemm(_p(ws["img_in"]), P.ptr("Wimg"), _p(ws["img_p"]), N, D, 512, 512, 512, D, bias=P.ptr("bimg"), out_f32=1, dtype=DIC_F32)
+        o.gemm(_p(ws["txt_in"]), P.ptr("Wtxt"), _p(ws["txt_p"]), N, D, 512, 512, 512, D, bias=P.ptr("btxt"), out_f32=1, dtype=DIC_F32)
+        # K4: concat/add fusion + segment + position + LayerNorm (+ dropout)
+        _lib.check(lib.dic_fuse_ln_fwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
+                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), P.ptr("eln_b"),
+                                       _p(ws["h"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
+        for i in range(self.n_layers):
+            Lw, h = ws["layers"][i], ws["h"][i]
+            pre = f"L{i}."
+            # K5: q|k|v projections as one GEMM
+            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=P.ptr(pre + "bqkv"))
+            # K6: attention
+            _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
+            # K7: out-proj + bias + residual, then LayerNorm
+            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(h), ldr=D)
+            _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
+            # K8: FFN
+            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU, bias=P.ptr(pre + "b1"), aux=_p(Lw["u"]), ldaux=Hd)
+            o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa"]), ldr=D,
+                   p_drop=ph, seed=seed + 4 * i + 2)
+            _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
+        # K9: MLM-head transform: Linear -> GELU -> LayerNorm
+        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"))
+        _lib.check(lib.dic_gelu_ln_fwd(self.dt, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
+        self._saved = ws
+        return ws["x_out"]
+
+    # ------------------------------------------------------------------ encoder backward
+    def backward(self, dx_out=None):
+        """dx_out [N,Tk,768] fp32 (defaults to the workspace buffer the loss kernels filled).  Accumulates nothing:
+        every parameter gradient in `params.G` is overwritten (pos rows >= Tk stay zero from zero_grad)."""
+        ws = self._saved
+        assert ws is not None, "backward() without a saved forward"
+        N, L, Tk, T, D, Hd = ws["N"], ws["L"], ws["Tk"], ws["T"], self.dim, self.hidden
+        o, P, lib = self.ops, self.params, self.ops.L
+        o.begin()
+        st = o.stream
+        wsrc = "Pb" if self.bf16 else "P"
+        seed, ph, pa = ws["seed"], ws["ph"], ws["pa"]
+        dx = ws["dx_out"] if dx_out is None else dx_out
+        csw = _p(ws["cs_ws"])
+        part = _p(ws["partial"])
+
+        def colsum(in_dtype, src, rows, cols, ld, dst, acc=0):
+            _lib.check(lib.dic_colsum(in_dtype, src, rows, cols, ld, dst, acc, csw, st), "colsum")
+
+        # head: GELU+LN backward, vocab_transform
+        _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(ws["dy"]), part, NPART, T, D, st), "gelu_ln_bwd")
+        colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr("vln_g", "G"))                      # [vln_g | vln_b | bvt]
+        o.gemm(_p(ws["dy"]), _p(ws["h"][-1]), P.ptr("Wvt", "G"), D, D, T, D, D, D, a_km=1, b_km=1, out_f32=1)
+        dH, dHn = ws["dHa"], ws["dHb"]
+        o.gemm(_p(ws["dy"]), P.ptr("Wvt", wsrc), _p(dH), T, D, D, D, D, D, b_km=1)
+        for i in reversed(range(self.n_layers)):
+            Lw, h = ws["layers"][i], ws["h"][i]
+            pre = f"L{i}."
+            use_drop = ph > 0.0
+            # output_layer_norm backward; bias grad of lin2 folded in
+            _lib.check(lib.dic_ln_bwd(self.dt, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(ws["dy"]),
+                                      _p(ws["dyd"]) if use_drop else 0, ph, seed + 4 * i + 2, part, NPART, T, D, st), "ln_bwd")
+            colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln2g", "G"))              # [ln2g | ln2b | b2]
+            dyd = ws["dyd"] if use_drop else ws["dy"]
+            o.gemm(_p(dyd), _p(Lw["g"]), P.ptr(pre + "W2", "G"), D, Hd, T, D, Hd, Hd, a_km=1, b_km=1, out_f32=1)          # dW2
+            o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(ws["du"]), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
+            colsum(self.dt, _p(ws["du"]), T, Hd, Hd, P.ptr(pre + "b1", "G"))                  # db1
+            o.gemm(_p(ws["du"]), _p(Lw["sa"]), P.ptr(pre + "W1", "G"), Hd, D, T, Hd, D, D, a_km=1, b_km=1, out_f32=1)      # dW1
+            o.gemm(_p(ws["du"]), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(ws["dy"]), ldr=D)  # + residual
+            # sa_layer_norm backward; bias grad of out_lin folded in
+            _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(ws["dy1"]),
+                                      0, 0.0, 0, part, NPART, T, D, st), "ln_bwd")
+            colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln1g", "G"))              # [ln1g | ln1b | bo]
+            o.gemm(_p(ws["dy1"]), _p(Lw["ctx"]), P.ptr(pre + "Wo", "G"), D, D, T, D, D, D, a_km=1, b_km=1, out_f32=1)       # dWo
+            o.gemm(_p(ws["dy1"]), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
+            _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(ws["dqkv"]), N, Tk, self.n_heads, 64, pa,
+                                        seed + 4 * i + 1, st), "attn_bwd")
+            colsum(self.dt, _p(ws["dqkv"]), T, 3 * D, 3 * D, P.ptr(pre + "bqkv", "G"))        # dbqkv
+            o.gemm(_p(ws["dqkv"]), _p(h), P.ptr(pre + "Wqkv", "G"), 3 * D, D, T, 3 * D, D, D, a_km=1, b_km=1, out_f32=1)    # dWqkv
+            o.gemm(_p(ws["dqkv"]), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(ws["dy1"]), ldr=D)
+            dH, dHn = dHn, dH
+        # embeddings LayerNorm + fusion backward
+        mode = 0 if self.concat else 1
+        _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
+                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
+                                       _p(ws["dy0"]), part, NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
+        colsum(DIC_F32, part, NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"))                       # [eln_g | eln_b]
+        dy0 = _p(ws["dy0"])
+        colsum(DIC_F32, dy0, N, Tk * D, Tk * D, P.ptr("pos", "G"))                            # dpos[0:Tk]
+        if self.concat:
+            gpos = P.ptr("pos", "G")
+            colsum(DIC_F32, gpos, L, D, D, P.ptr("seg", "G"))                                  # dseg[0] = sum_{t<L}
+            colsum(DIC_F32, gpos + L * D * 4, 2, D, D, P.ptr("seg", "G") + D * 4)              # dseg[1] = rows L, L+1
+            dimg, dtxt, ldd = dy0 + L * D * 4, dy0 + (L + 1) * D * 4, Tk * D
+        else:
+            # "add" fusion: the projected CLIP rows were broadcast over the sequence -> sum the row gradients
+            _lib.check(lib.dic_seq_sum(dy0, _p(ws["addtxt"]), _p(ws["dimg"]), _p(ws["dtxt"]), N, L, D, st), "seq_sum")
+            dimg, dtxt, ldd = _p(ws["dimg"]), _p(ws["dtxt"]), D
+        o.gemm(dimg, _p(ws["img_in"]), P.ptr("Wimg", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+        colsum(DIC_F32, dimg, N, D, ldd, P.ptr("bimg", "G"))
+        o.gemm(dtxt, _p(ws["txt_in"]), P.ptr("Wtxt", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+        colsum(DIC_F32, dtxt, N, D, ldd, P.ptr("btxt", "G"))
+
+    # ------------------------------------------------------------------ rounding head: streaming CE / argmax (ref :323, 436-437, 620)
+    def rounding(self, xr, M, tgt=None, ce_ws=None, dtype=None):
+        """xr [M,768] (compute dtype) -> (lse[M], argmax[M], nll[M] or None) without materialising the logits."""
+        cw = ce_ws or self._ce_workspace(M)
+        o = self.ops
+        o.begin()
+        W = self.W_lm_c if dtype is None else (self.W_lm if dtype == DIC_F32 else self.W_lm_c)
+        o.gemm(_p(xr), _p(W), 0, M, self.vocab, 768, 768, 768, 0, epi=EPI_CE_PARTIAL, tgt=_p(tgt) if tgt is not None else 0,
+               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), dtype=dtype)
+        _lib.check(o.L.dic_ce_combine(_p(cw["partial"]), _p(cw["tgt_logit"]), M, cw["np"], _p(cw["lse"]), _p(cw["argmax"]),
+                                      _p(cw["nll"]) if tgt is not None else 0, o.stream), "ce_combine")
+        return cw["lse"], cw["argmax"], (cw["nll"] if tgt is not None else None)
+
+    def rounding_backward(self, cw, M, rows_a, scale_a, scale_b):
+        """dxr = ((softmax - onehot) * row_scale) @ W  via a recompute GEMM with the dlogits epilogue + one (KC,KM) GEMM."""
+        o = self.ops
+        o.begin()
+        if cw["dlogits"] is None:
+            cw["dlogits"] = torch.empty(M, self.vpad, dtype=self.tdtype, device=self.device)
+        o.gemm(_p(cw["xr"]), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_DLOGITS,
+               tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b)
+        o.gemm(_p(cw["dlogits"]), _p(self.W_lm_c), _p(cw["dxr"]), M, 768, self.vpad, self.vpad, 768, 768, b_km=1, out_f32=1)
+        return cw["dxr"]
+
+    # ------------------------------------------------------------------ reference forward (ref :271-323)
+    def _key_masks(self, mask, concat_mask, n):
+        guided = (concat_mask[:, 1] == 1)
+        m = (mask != 0).to(torch.uint8)
+        if self.concat:
+            one = torch.ones(n, 1, dtype=torch.uint8, device=self.device)
+            plain = torch.cat([m, one, torch.zeros_like(one)], 1)
+            gmask = torch.cat([m, one, one], 1)
+        else:
+            plain = gmask = m
+        return guided, plain, gmask
+
+    @torch.no_grad()
+    def forward(self, x, image_clip, text_clip, mask, concat_mask, with_logits=True):
+        """Inference-shaped call with the reference's signature: returns (vocab_logits [N,L,V], x_out [N,Tk,768]).
+        Training goes through `diffusion.loss`, which shares `encode`/`rounding` but never builds the logits."""
+        n = x.shape[0]
+        L = cfg.MAX_LENGTH
+        assert x.shape == (n, L, cfg.IN_CHANNEL)
+        assert image_clip.shape == text_clip.shape == (n, 1, 512)
+        assert mask.shape == (n, L)
+        assert concat_mask.shape == (n, 2)
+        dev = self.device
+        x, mask, concat_mask = x.to(dev, torch.float32), mask.to(dev), concat_mask.to(dev)
+        image_clip, text_clip = image_clip.to(dev, torch.float32), text_clip.to(dev, torch.float32)
+        guided, plain, gmask = self._key_masks(mask, concat_mask, n)
+        w = cfg.CLASSIFIER_FREE_WEIGHT
+        gi = guided.nonzero().squeeze(1) if (w > 0 and bool(guided.any())) else None
+        if gi is not None:
+            xs = torch.cat([x, x[gi]]); ic = torch.cat([image_clip, image_clip[gi]]); tc = torch.cat([text_clip, text_clip[gi]])
+            km = torch.cat([plain, gmask[gi]])
+            add_txt = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev), torch.ones(len(gi), dtype=torch.uint8, device=dev)])
+        else:
+            xs, ic, tc, km, add_txt = x, image_clip, text_clip, plain, torch.zeros(n, dtype=torch.uint8, device=dev)
+        x_all = self.encode(xs.contiguous(), ic, tc, km, add_txt)
+        if gi is not None:
+            Tk = x_all.shape[1]
+            _lib.check(self.ops.L.dic_cfg_mix_fwd(_p(x_all), _p(x_all[n:]), _p(gi), len(gi), Tk * 768, float(w), self.ops.stream), "cfg_mix")
+        x_out = x_all[:n].clone()
+        logits = self.lm_head(x_out[:, :L, :]) if with_logits else None
+        return logits, x_out
+
+    __call__ = forward

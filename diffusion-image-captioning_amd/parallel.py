@@ -1,0 +1,103 @@
+"""Data parallelism over the 8 GPUs of one node: one process per GPU, ONE RCCL all-reduce per step.
+
+The reference is single-device (no torch.distributed anywhere).  The path shards naturally: batch items are
+independent and every loss term is a mean over the batch dimension (ref :78, :436-437), so summing the per-rank
+gradients and dividing by world_size is exact.  All 108 gradient tensors live in one flat fp32 buffer
+(`ParamStore.G`), so the exchange is a single `all_reduce` of that buffer -- on MI355X's fully connected xGMI that is
+one direct reduce-scatter + all-gather across all 7 links, not 108 latency-bound small collectives.  The 1/world
+factor is folded into the AdamW kernel (`grad_scale`), not a separate pass over the buffer.
+
+Reference caveats kept:
+  * one t-vector per step is shared by the whole *global* batch (ref :461) -> rank 0 draws it and broadcasts it;
+  * the noise eps is per item -> each rank seeds its Philox stream differently;
+  * CFG forces rows 0/1 of the batch to unguided/guided (ref :408-409) -> only rank 0 does.
+Backend "nccl" IS RCCL on ROCm; the CPU tests run the same code with "gloo".
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if is_initialized() else 0
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise from torchrun's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment; no-op for a single process."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or is_initialized():
+        return rank(), world_size(), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
+    return dist.get_rank(), ws, local
+
+
+def shard(batch: dict, rank_: int | None = None, world: int | None = None) -> dict:
+    """Even split of a global batch dict along dim 0 (global B must be divisible by world_size)."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    out = {}
+    for k, v in batch.items():
+        n = len(v)
+        assert n % w == 0, f"global batch {n} not divisible by world size {w}"
+        out[k] = v[r * (n // w):(r + 1) * (n // w)]
+    return out
+
+
+def shared_randint(lo: int, hi: int, shape, device) -> torch.Tensor:
+    """torch.randint whose result is identical on every rank (drawn on rank 0, broadcast)."""
+    t = torch.randint(lo, hi, shape, device=device)
+    if is_initialized() and world_size() > 1:
+        dist.broadcast(t, src=0)
+    return t
+
+
+def allreduce_flat(flat: torch.Tensor) -> torch.Tensor:
+    """Sum `flat` across ranks in place with ONE collective."""
+    if is_initialized() and world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def allreduce_grads(model, trainer=None):
+    """One all-reduce of the model's flat gradient buffer; the mean is taken by the optimizer's grad_scale."""
+    w = world_size()
+    if w <= 1:
+        return
+    allreduce_flat(model.params.G)
+    if trainer is not None and hasattr(trainer, "grad_scale"):
+        trainer.grad_scale = 1.0 / w
+    else:
+        model.params.G.mul_(1.0 / w)
+
+
+def allreduce_scalars(*vals):
+    """Mean of a few logging scalars across ranks (one tiny collective)."""
+    if world_size() <= 1:
+        return vals
+    t = torch.stack([v.detach().float().reshape(()) for v in vals])
+    dist.all_reduce(t)
+    t /= world_size()
+    return tuple(t[i] for i in range(len(vals)))
+
+
+def configure_model_for_rank(model):
+    model.rank_rows_forced = rank() == 0
+    return model

@@ -1,0 +1,145 @@
+"""Flat parameter store of the denoiser.
+
+All trainable tensors of `DistilBertModel` (ref CLIP-DDPM.py:227-269; 108 tensors / 44.3 M elements at 6 layers)
+live in ONE contiguous fp32 buffer `P`, with gradients `G` and the AdamW moments `M`, `V` in three more buffers of
+the same layout, plus (bf16 mode) a bf16 shadow `Pb` that the GEMMs read.  Consequences:
+  * AdamW is ONE kernel launch over the flat range (dic_adamw) and writes the shadow in the same pass;
+  * the data-parallel gradient exchange is ONE RCCL all-reduce of `G`;
+  * q/k/v projection weights are stored stacked ([2304][768]) so the three Linears run as one GEMM, and
+    [LayerNorm.weight | LayerNorm.bias | bias of the Linear feeding that LayerNorm] are adjacent so one column-sum
+    launch finalises all three gradients.
+`parameters()` still returns per-tensor views in the reference's order (CLIP-DDPM.py:258-269), each with `.grad`
+set to the matching view of `G`, so `torch.optim.AdamW(model.parameters())` -- the reference's trainer -- also works.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import synth
+
+ALIGN = 64  # floats (256 B)
+
+
+class ParamStore:
+    def __init__(self, n_layers: int, device, concat: bool = True, dim: int = 768, hidden: int = 3072,
+                 max_pos: int = 512, clip_dim: int = 512, bf16_shadow: bool = True):
+        self.n_layers, self.dim, self.hidden, self.concat = n_layers, dim, hidden, concat
+        self.device = torch.device(device)
+        self._slots = {}     # internal slot name -> (offset, shape)
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            self._slots[name] = (off, tuple(shape))
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+
+        for i in range(n_layers):
+            add(f"L{i}.Wqkv", (3 * dim, dim)); add(f"L{i}.bqkv", (3 * dim,))
+            add(f"L{i}.Wo", (dim, dim))
+            add(f"L{i}.ln1g", (dim,)); add(f"L{i}.ln1b", (dim,)); add(f"L{i}.bo", (dim,))
+            add(f"L{i}.W1", (hidden, dim)); add(f"L{i}.b1", (hidden,))
+            add(f"L{i}.W2", (dim, hidden))
+            add(f"L{i}.ln2g", (dim,)); add(f"L{i}.ln2b", (dim,)); add(f"L{i}.b2", (dim,))
+        add("pos", (max_pos, dim)); add("eln_g", (dim,)); add("eln_b", (dim,))
+        add("Wvt", (dim, dim)); add("vln_g", (dim,)); add("vln_b", (dim,)); add("bvt", (dim,))
+        add("Wimg", (dim, clip_dim)); add("bimg", (dim,))
+        add("Wtxt", (dim, clip_dim)); add("btxt", (dim,))
+        if concat:
+            add("seg", (2, dim))
+        self.numel = off
+        self.P = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.G = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if bf16_shadow else None
+
+        # reference-named views, in the order of CLIP-DDPM.py:258-269
+        self.names = [n for n, _, _, _ in synth.denoiser_param_specs(n_layers)]
+        if not concat:
+            self.names = [n for n in self.names if n != "segment_embedding.weight"]
+        self._views = {n: self._view(self.P, n) for n in self.names}
+        self._gviews = {n: self._view(self.G, n) for n in self.names}
+        for n in self.names:
+            self._views[n]._dic_store = self
+        self.relink_grads()
+
+    # ---- slot helpers
+    def off(self, slot):
+        return self._slots[slot][0]
+
+    def ptr(self, slot, which="P"):
+        buf = {"P": self.P, "G": self.G, "Pb": self.Pb}[which]
+        return buf.data_ptr() + self._slots[slot][0] * buf.element_size()
+
+    def slot_view(self, buf, slot):
+        o, shp = self._slots[slot]
+        return buf[o:o + int(np.prod(shp))].view(shp)
+
+    def _view(self, buf, ref_name):
+        d = self.dim
+        pre = "model.distilbert."
+        simple = {
+            pre + "embeddings.position_embeddings.weight": "pos", pre + "embeddings.LayerNorm.weight": "eln_g",
+            pre + "embeddings.LayerNorm.bias": "eln_b", "model.vocab_transform.weight": "Wvt",
+            "model.vocab_transform.bias": "bvt", "model.vocab_layer_norm.weight": "vln_g",
+            "model.vocab_layer_norm.bias": "vln_b", "image_linear.weight": "Wimg", "image_linear.bias": "bimg",
+            "text_linear.weight": "Wtxt", "text_linear.bias": "btxt", "segment_embedding.weight": "seg",
+        }
+        if ref_name in simple:
+            return self.slot_view(buf, simple[ref_name])
+        assert ref_name.startswith(pre + "transformer.layer."), ref_name
+        rest = ref_name[len(pre + "transformer.layer."):]
+        i, rest = rest.split(".", 1)
+        L = f"L{i}."
+        qkv = {"q_lin": 0, "k_lin": 1, "v_lin": 2}
+        for lin, j in qkv.items():
+            if rest == f"attention.{lin}.weight":
+                return self.slot_view(buf, L + "Wqkv")[j * d:(j + 1) * d]
+            if rest == f"attention.{lin}.bias":
+                return self.slot_view(buf, L + "bqkv")[j * d:(j + 1) * d]
+        m = {"attention.out_lin.weight": "Wo", "attention.out_lin.bias": "bo", "sa_layer_norm.weight": "ln1g",
+             "sa_layer_norm.bias": "ln1b", "ffn.lin1.weight": "W1", "ffn.lin1.bias": "b1", "ffn.lin2.weight": "W2",
+             "ffn.lin2.bias": "b2", "output_layer_norm.weight": "ln2g", "output_layer_norm.bias": "ln2b"}
+        return self.slot_view(buf, L + m[rest])
+
+    # ---- public
+    def relink_grads(self):
+        """(Re)attach `.grad` views of the flat gradient buffer (torch optimizers' zero_grad() sets them to None)."""
+        for n in self.names:
+            self._views[n].grad = self._gviews[n]
+
+    def parameters(self):
+        return [self._views[n] for n in self.names]
+
+    def named_parameters(self):
+        return [(n, self._views[n]) for n in self.names]
+
+    @torch.no_grad()
+    def load_state(self, state: dict):
+        """`state`: reference-named tensors/arrays (e.g. synth.denoiser_state or a checkpoint)."""
+        for n in self.names:
+            v = state[n]
+            v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+            self._views[n].copy_(v.to(self.device, torch.float32))
+
+    def state_dict(self):
+        return {n: self._views[n].detach().clone() for n in self.names}
+
+    @torch.no_grad()
+    def init_like_reference(self, seed: int = 0):
+        """HF DistilBERT init (N(0, 0.02), zero biases, LayerNorm 1/0; hf `_init_weights`) and torch-default
+        Linear/Embedding init for the wrapper's image/text/segment layers (ref :252-256), seeded."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n in self.names:
+            v = self._views[n]
+            if "LayerNorm.weight" in n or "layer_norm.weight" in n:
+                v.fill_(1.0)
+            elif n.endswith(".bias") and not n.startswith(("image_linear", "text_linear")):
+                v.zero_()
+            elif n.startswith(("image_linear", "text_linear")):
+                bound = 1.0 / np.sqrt(512)
+                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * bound).to(self.device))
+            elif n == "segment_embedding.weight":
+                v.copy_(torch.randn(v.shape, generator=g).to(self.device))
+            else:
+                v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(self.device))

@@ -1,0 +1,162 @@
+/* dic_hip.h -- C-ABI of the MI355X (gfx950) hot path of CLIP-Diffusion-LM captioning.
+ *
+ * The reference (xu-shitong/diffusion-image-captioning) has no FFI: its hot path is Python calling
+ * ATen/HuggingFace ops.  This header is therefore the boundary a maintainer would bind INSTEAD of those op
+ * groups; each entry point cites the reference lines whose arithmetic it replaces ("ref" =
+ * /root/reference/CLIP-DDPM.py, "hf" = transformers/models/distilbert/modeling_distilbert.py 5.15.0).
+ * INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller
+ *   - kernels never allocate, never synchronise, launch on `stream` (a hipStream_t passed as void*)
+ *   - return value: 0 = ok, otherwise a hipError_t (or >= 1000 for argument errors); dic_last_error()
+ *     gives the message
+ *   - dtype: DIC_F32 (0) or DIC_BF16 (1) selects the activation/operand type `T`; statistics, losses,
+ *     gradients of parameters, optimizer state and biases are always float32
+ *   - row-major tensors; "T" below = number of tokens = sequences x tokens-per-sequence
+ */
+#ifndef DIC_HIP_H
+#define DIC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIC_F32 0
+#define DIC_BF16 1
+
+int dic_version(void);
+const char* dic_last_error(void);
+
+/* ---------------------------------------------------------------- GEMM (hf:183-185,201,221-223,510; ref:299,323)
+ * C[m][n] = sum_k A(m,k) B(n,k), A stored [M][lda] (a_km=0) or [K][lda] (a_km=1); B likewise.
+ * Epilogues:
+ *   AFFINE      C = dropout(acc + bias[n]) + R[m][n]   (bias, R optional; p_drop 0 = none); out T or f32,
+ *               accumulate=1 adds the previous C (f32 output only)         -- nn.Linear fwd/bwd, residual adds
+ *   BIAS_GELU   aux = acc + bias ; C = gelu(aux)                            -- hf:221-222 (ffn.lin1 + GELU)
+ *   GELU_BWD    C = acc * gelu'(aux)                                        -- backward of the above
+ *   CE_PARTIAL  per (row, 64-col half tile): {max, sum exp(x-max), first argmax}; tgt_logit[m] = acc[m][tgt[m]]
+ *               -- streaming form of softmax/gather/argmax over the 30522-wide logits (ref:323,436-437,620)
+ *   CE_DLOGITS  C = (exp(acc - lse[m]) - [n == tgt[m]]) * (m < ce_rows_a ? ce_scale_a : ce_scale_b),
+ *               zero for N <= n < ldc                                        -- backward of the rounding loss
+ */
+#define DIC_EPI_AFFINE 0
+#define DIC_EPI_BIAS_GELU 1
+#define DIC_EPI_GELU_BWD 2
+#define DIC_EPI_CE_PARTIAL 3
+#define DIC_EPI_CE_DLOGITS 4
+
+typedef struct DicGemmParams {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    const float* bias;          /* [N] or NULL */
+    const void* R; int ldr;     /* residual, dtype T, or NULL */
+    void* aux; int ldaux;       /* BIAS_GELU: out pre-activation; GELU_BWD: in pre-activation */
+    float p_drop; uint64_t seed;/* dropout on (acc+bias), mask keyed by (seed, m*N+n) */
+    int out_f32; int accumulate;
+    const int64_t* tgt;         /* [M] target ids (CE) */
+    const float* lse;           /* [M] logsumexp (CE_DLOGITS) */
+    float* partial;             /* [M][2*ceil(N/128)][4] (CE_PARTIAL) */
+    float* tgt_logit;           /* [M] (CE_PARTIAL) */
+    int ce_rows_a; float ce_scale_a, ce_scale_b;
+} DicGemmParams;
+
+int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
+
+/* Measurement hooks for bench.py: between begin/end every dic_gemm launch is bracketed by hipEvents recorded on its own
+ * stream; end() (after the caller synchronised) returns the summed kernel time, algorithmic flops (2*M*N*K) and count. */
+int dic_prof_begin(int max_launches);
+int dic_prof_end(double* total_ms, double* total_flops, int* n_launches);
+
+/* Reduce CE_PARTIAL output: lse[m], argmax[m] (first index of the max, as torch.argmax), nll[m] = lse - tgt_logit.
+ * ref:436-437 (-log softmax gathered at the true id) and ref:620 (softmax.argmax).                               */
+int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_partials,
+                   float* lse, int64_t* argmax, float* nll, void* stream);
+
+/* ---------------------------------------------------------------- embedding + q_sample (ref:459, 347-362) */
+int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, void* stream);
+/* out[(s*B+b)*LD + i] = sqrt(ac[t[s]])*x0[b*LD+i] + sqrt(1-ac[t[s]])*eps[b*LD+i]; eps = `noise` when non-NULL,
+ * else N(0,1) from Philox4x32-10 keyed by (seed, b*LD+i) -- ONE draw per element shared by all S, as ref:359. */
+int dic_qsample(const float* x0, const float* noise, const int64_t* t, const float* alpha_cumprod, float* out,
+                float* noise_out, int S, int B, int LD, int step_tot, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------- fusion + embeddings LayerNorm (ref:299-307, hf:113-117)
+ * mode 0 "concat": row t<L = x[n][t]; row L = img[n]; row L+1 = txt[n]; + seg[t>=L] + pos[t]; LayerNorm(eps);
+ * mode 1 "add":    row t = x[n][t] + img[n] (+ txt[n] when add_txt[n]) + pos[t]; LayerNorm.   Tk = L+2 / L.
+ * Writes h [N][Tk][D] (dtype T, dropout p applied) and mean/rstd [N*Tk].                                          */
+int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                    const float* seg, const float* pos, const float* gamma, const float* beta,
+                    void* h, float* mean, float* rstd, int N, int L, int D, float eps,
+                    float p_drop, uint64_t seed, void* stream);
+/* Backward: dh (T) -> dy [N][Tk][D] f32 (gradient wrt the pre-LN fused rows) and per-block partial sums of
+ * dgamma/dbeta in `partial` [nblocks][2*D] (reduce with dic_colsum).                                              */
+int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                    const float* seg, const float* pos, const float* gamma,
+                    const void* dh, const float* mean, const float* rstd, float* dy, float* partial, int n_partial_blocks,
+                    int N, int L, int D, float p_drop, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm (hf:236,239,253,257; eps 1e-12) */
+int dic_ln_fwd(int dtype, const void* y, const float* gamma, const float* beta, void* h, float* mean, float* rstd,
+               int T, int D, float eps, void* stream);
+/* dx (T) = LN backward; dx_drop (T, optional) = dx with the dropout mask of the producing GEMM epilogue applied
+ * (mask keyed by (seed, row*D+col)); partial [nblocks][3*D] = {dgamma, dbeta, colsum(dx_drop if given else dx)}.       */
+int dic_ln_bwd(int dtype, const void* dh, const void* y, const float* gamma, const float* mean, const float* rstd,
+               void* dx, void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks,
+               int T, int D, void* stream);
+
+/* ---------------------------------------------------------------- MLM-head GELU + LayerNorm (hf:511-512) */
+int dic_gelu_ln_fwd(int dtype, const void* u, const float* gamma, const float* beta, float* x_out,
+                    float* mean, float* rstd, int T, int D, float eps, void* stream);
+/* du (T) from dx_out (f32); partial [nblocks][3*D] = {dgamma, dbeta, colsum(du)}                                   */
+int dic_gelu_ln_bwd(int dtype, const float* dx_out, const void* u, const float* gamma, const float* mean,
+                    const float* rstd, void* du, float* partial, int n_partial_blocks, int T, int D, void* stream);
+
+/* ---------------------------------------------------------------- attention (hf:136-147, 183-185; ref:296-297)
+ * qkv [N][Tk][3*D] (q | k | v), key_mask [N][Tk] (1 = attend), ctx [N][Tk][D].  softmax(QK^T/sqrt(dh)+mask) V,
+ * attention-prob dropout p keyed by (seed, ((n*H+h)*Tk+i)*Tk+j).  bf16: MFMA 32x32x16; f32: exact VALU path.     */
+int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask, void* ctx, int N, int Tk, int H, int dh,
+                 float p_drop, uint64_t seed, void* stream);
+int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask, const void* dctx, void* dqkv,
+                 int N, int Tk, int H, int dh, float p_drop, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------- losses (ref:77-87, 418, 428)
+ * kind 0 series_sum_sample_mean, 1 series_sum, 2 mse_series_mean, 3 mse_series_sum.  x_out [N][Tk][D] f32 (rows
+ * t<L used), target [N or B][L][D] f32 (index n % tgt_rows).  per_seq[n] = sum|d| (kinds 0,1) or sqrt(sum d^2);
+ * grad_scale[n]-weighted gradient written to dx_out rows t<L (rows t>=L zeroed) when dx_out != NULL;
+ * xr [N*L][D] (dtype T) = compact copy of the rows that feed the rounding head.                                    */
+int dic_emb_loss(int dtype, int kind, const float* x_out, const float* target, int tgt_rows, float* per_seq,
+                 float* dx_out, const float* grad_scale, void* xr, int N, int L, int Tk, int D, void* stream);
+/* dx_out[n][t<L][:] += dxr[n*L+t][:]   (adds the rounding-loss gradient)                                           */
+int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int Tk, int D, void* stream);
+/* out3[0] = scale_a*sum in[0:n_a), out3[1] = scale_b*sum in[n_a:n), out3[2] = out3[0]+out3[1] (fp64 accumulate)      */
+int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out3, void* stream);
+
+/* ---------------------------------------------------------------- classifier-free-guidance mix (ref:313-317)
+ * x_out[idx[i]] = (1+w)*g_out[i] - w*x_out[idx[i]]  (rows of Tk*D floats); backward splits the gradient.          */
+int dic_cfg_mix_fwd(float* x_out, const float* g_out, const int64_t* idx, int n_g, int row_elems, float w, void* stream);
+int dic_cfg_mix_bwd(float* dx_out, float* dg_out, const int64_t* idx, int n_g, int row_elems, float w, void* stream);
+
+/* "add" fusion backward (ref:306-307): out_all[n] = sum_t in[n][t]; out_flag[n] = flags[n] ? out_all[n] : 0        */
+int dic_seq_sum(const float* in, const uint8_t* flags, float* out_all, float* out_flag, int N, int L, int D, void* stream);
+
+/* ---------------------------------------------------------------- reductions for bias / LN / embedding grads
+ * out[c] (+)= sum_r in[r][c]; in dtype f32 (in_dtype 0) or bf16 (1); two-stage, deterministic; ws >= 64*cols f32 */
+int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream);
+
+/* ---------------------------------------------------------------- AdamW (ref:335 -- torch defaults, decoupled wd on every tensor)
+ * p,g,m,v flat f32 [n]; g is multiplied by grad_scale first (1/world_size after the RCCL sum);
+ * shadow (bf16, optional) receives the updated parameters for the bf16 GEMM operands.                              */
+int dic_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, int64_t n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+              void* stream);
+int dic_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- probe (layout self-test used by the GPU tests) */
+int dic_probe_tr16(const uint16_t* in, uint16_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,462 @@
+"""Per-kernel parity: every C-ABI entry point against the CPU oracle (oracle/ref_model.py, oracle/rounding.c) or a
+float64 restatement, on seeded inputs, through ctypes -- the same calls the product makes.  GPU only."""
+import ctypes as C
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+dic = importlib.import_module("diffusion-image-captioning_amd")
+from oracle import ref_model as R                      # noqa: E402
+from oracle.rounding import rounding_ref               # noqa: E402
+
+F32, BF16 = 0, 1
+DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def L():
+    dic._lib.require_gpu()
+    return dic.lib()
+
+
+def dev(t, dt=None):
+    t = torch.as_tensor(t)
+    return t.to("cuda", dt if dt is not None else t.dtype).contiguous()
+
+
+def p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ok(rc, L):
+    assert rc == 0, L.dic_last_error().decode()
+
+
+def relerr(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def gemm(L, dtype, a_km, b_km, epi, **kw):
+    g = dic._lib.GemmParams()
+    for k, v in kw.items():
+        setattr(g, k, v)
+    ok(L.dic_gemm(dtype, a_km, b_km, epi, C.byref(g), stream()), L)
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ layout probe
+def test_tr16_layout_assumption(L):
+    src = torch.arange(256, dtype=torch.int16, device="cuda")
+    out = torch.zeros(256, dtype=torch.int16, device="cuda")
+    ok(L.dic_probe_tr16(p(src), p(out), stream()), L)
+    got = out.cpu().numpy().reshape(64, 4)
+    exp = np.array([[(l & 15) + 16 * j + 64 * (l >> 4) for j in range(4)] for l in range(64)])
+    assert (got == exp).all(), f"ds_read_b64_tr_b16 mapping differs:\n{got[:20]}"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("layout", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("shape", [(200, 256, 256), (128, 128, 64), (392, 384, 192)])
+def test_gemm_layouts(L, dtype, layout, shape):
+    a_km, b_km = layout
+    M, N, K = shape
+    if a_km:
+        M = (M + 7) // 8 * 8
+        K = K + 37                       # ragged contraction (tokens) is legal when both operands are k-major
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + dtype + 10 * a_km + 20 * b_km)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    Aq, Bq = A.to(DT[dtype]).float(), B.to(DT[dtype]).float()
+    ref = Aq.double() @ Bq.double().t()
+    Ad = dev(A.t() if a_km else A, DT[dtype])
+    Bd = dev(B.t() if b_km else B, DT[dtype])
+    Cd = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    gemm(L, dtype, a_km, b_km, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, out_f32=1)
+    e = relerr(Cd, ref)
+    assert e < (2e-6 if dtype == F32 else 2e-6), f"relerr {e}"   # inputs pre-rounded: both accumulate in fp32
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_f32_is_k_ordered_fmaf_chain_and_affine_epilogue(L, dtype):
+    M, N, K = 136, 260, 128
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias, Rr = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd, Rd = dev(A, DT[dtype]), dev(B, DT[dtype]), dev(Rr, DT[dtype])
+    Cd = torch.zeros(M, N, dtype=DT[dtype], device="cuda")
+    gemm(L, dtype, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), R=p(Rd), ldr=N)
+    ref = Ad.float().cpu().double() @ Bd.float().cpu().double().t() + bias.double() + Rd.float().cpu().double()
+    assert relerr(Cd.float(), ref) < (1e-6 if dtype == F32 else 6e-3)
+    if dtype == F32:   # bit-exact vs the fmaf-chain oracle (no bias / residual)
+        Cd2 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        gemm(L, F32, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cd2), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=1)
+        o = rounding_ref(A.numpy(), B.numpy(), None, want_logits=True)
+        assert np.array_equal(Cd2.cpu().numpy(), o["logits"]), "fp32 MFMA GEMM is not the k-ascending fmaf chain"
+        # accumulate=1
+        gemm(L, F32, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cd2), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=1, accumulate=1)
+        assert relerr(Cd2, 2 * torch.from_numpy(o["logits"])) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_gelu_epilogues_and_dropout(L, dtype):
+    M, N, K = 144, 256, 192
+    g = torch.Generator().manual_seed(9)
+    A, B, bias = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)
+    Ad, Bd = dev(A, DT[dtype]), dev(B, DT[dtype])
+    U = torch.zeros(M, N, dtype=DT[dtype], device="cuda")
+    G = torch.zeros(M, N, dtype=DT[dtype], device="cuda")
+    gemm(L, dtype, 0, 0, 1, A=p(Ad), B=p(Bd), C=p(G), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), aux=p(U), ldaux=N)
+    u_ref = Ad.float().cpu().double() @ Bd.float().cpu().double().t() + bias.double()
+    tol = 1e-5 if dtype == F32 else 1e-2
+    assert relerr(U.float(), u_ref) < tol
+    assert relerr(G.float(), R.gelu(U.float().cpu().double())) < tol
+    # GELU backward epilogue: C = acc * gelu'(U)
+    Dd = torch.zeros(M, N, dtype=DT[dtype], device="cuda")
+    gemm(L, dtype, 0, 0, 2, A=p(Ad), B=p(Bd), C=p(Dd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, aux=p(U), ldaux=N)
+    uu = U.float().cpu().double().requires_grad_(True)
+    R.gelu(uu).sum().backward()
+    acc = Ad.float().cpu().double() @ Bd.float().cpu().double().t()
+    assert relerr(Dd.float(), acc * uu.grad) < tol
+    # dropout epilogue: kept elements scaled by 1/(1-p), drop rate ~ p, deterministic in (seed, index)
+    C1 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    C2 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    for Cx in (C1, C2):
+        gemm(L, dtype, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cx), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=1, p_drop=0.25, seed=1234)
+    assert torch.equal(C1, C2)
+    full = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    gemm(L, dtype, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(full), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=1)
+    kept = C1 != 0
+    assert abs(float((~kept).float().mean()) - 0.25) < 0.02
+    assert relerr(C1[kept], full[kept] / 0.75) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ rounding head
+@pytest.mark.parametrize("dtype,V", [(F32, 30522), (BF16, 30522), (F32, 1000)])
+def test_rounding_ce_partial_combine_and_backward(L, dtype, V):
+    M, K = 40, 768
+    g = torch.Generator().manual_seed(V + dtype)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(V, K, generator=g) * 0.05
+    tgt = torch.randint(0, V, (M,), generator=g)
+    # plant exact ties: duplicate rows of W -> equal logits; first index must win
+    W[7] = W[3]
+    W[V - 1] = W[V - 2]
+    vpad = (V + 127) // 128 * 128
+    Wp = torch.zeros(vpad, K)
+    Wp[:V] = W
+    xd, Wd, td = dev(x, DT[dtype]), dev(Wp, DT[dtype]), dev(tgt)
+    npart = 2 * ((V + 127) // 128)
+    part = torch.zeros(M, npart, 4, device="cuda")
+    tl = torch.zeros(M, device="cuda")
+    lse = torch.zeros(M, device="cuda")
+    am = torch.zeros(M, dtype=torch.int64, device="cuda")
+    nll = torch.zeros(M, device="cuda")
+    gemm(L, dtype, 0, 0, 3, A=p(xd), B=p(Wd), M=M, N=V, K=K, lda=K, ldb=K, tgt=p(td), partial=p(part), tgt_logit=p(tl))
+    ok(L.dic_ce_combine(p(part), p(tl), M, npart, p(lse), p(am), p(nll), stream()), L)
+    torch.cuda.synchronize()
+    o = rounding_ref(xd.float().cpu().numpy(), Wd.float().cpu().numpy()[:V], tgt.numpy())
+    if dtype == F32:
+        assert np.array_equal(am.cpu().numpy(), o["argmax"]), "token ids must be bit-exact (first index on ties)"
+        assert np.array_equal(tl.cpu().numpy(), o["tgt_logit"])
+    else:
+        logits = xd.float().cpu().double() @ Wd.float().cpu().double()[:V].t()
+        top = logits.max(-1).values
+        chosen = logits.gather(1, am.cpu().unsqueeze(1)).squeeze(1)
+        assert float((top - chosen).max()) < 1e-3
+    np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=2e-6 if dtype == F32 else 2e-4)
+    np.testing.assert_allclose(nll.cpu().numpy(), o["lse"] - o["tgt_logit"], rtol=1e-5 if dtype == F32 else 1e-3, atol=1e-5)
+    # backward: dlogits epilogue + (KC,KM) GEMM against autograd of the oracle's rounding loss
+    rows_a, sa, sb = 24, 0.5 / 3, 0.5 / 2
+    dlog = torch.full((M, vpad), float("nan"), dtype=DT[dtype], device="cuda")
+    dxr = torch.zeros(M, K, dtype=torch.float32, device="cuda")
+    gemm(L, dtype, 0, 0, 4, A=p(xd), B=p(Wd), C=p(dlog), M=M, N=V, K=K, lda=K, ldb=K, ldc=vpad, tgt=p(td), lse=p(lse),
+         ce_rows_a=rows_a, ce_scale_a=sa, ce_scale_b=sb)
+    assert float(dlog[:, V:].float().abs().max()) == 0.0, "padding columns of dlogits must be zero"
+    gemm(L, dtype, 0, 1, 0, A=p(dlog), B=p(Wd), C=p(dxr), M=M, N=K, K=vpad, lda=vpad, ldb=K, ldc=K, out_f32=1)
+    xx = xd.float().cpu().double().requires_grad_(True)
+    lg = xx @ Wd.float().cpu().double()[:V].t()
+    nl = -torch.log_softmax(lg, -1).gather(1, tgt.unsqueeze(1)).squeeze(1)
+    (nl[:rows_a].sum() * sa + nl[rows_a:].sum() * sb).backward()
+    assert relerr(dxr, xx.grad) < (1e-5 if dtype == F32 else 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ embedding + q_sample
+def test_embed_gather_and_qsample_bit_exact(L):
+    V, B, Lq, S = 500, 3, 16, 5
+    g = torch.Generator().manual_seed(3)
+    E = torch.randn(V, 768, generator=g)
+    ids = torch.randint(0, V, (B, Lq), generator=g)
+    out = torch.zeros(B, Lq, 768, device="cuda")
+    ok(L.dic_embed_gather(p(dev(ids)), p(dev(E)), p(out), B * Lq, 768, V, stream()), L)
+    assert torch.equal(out.cpu(), E[ids])
+    for cosine, T in ((True, 1000), (False, 100)):
+        cfg = R.Config(COSIN_SCHEDULE=cosine, STEP_TOT=T)
+        ac = R.alpha_cumprod(cfg)
+        t = torch.randint(0, T, (S, 1, 1), generator=g)
+        noise = torch.randn(B, Lq, 768, generator=g)
+        x0 = E[ids]
+        ref = R.diffuse_t(x0, t, noise, ac)
+        xt = torch.zeros(S * B, Lq, 768, device="cuda")
+        ok(L.dic_qsample(p(dev(x0)), p(dev(noise)), p(dev(t.reshape(-1))), p(dev(ac)), p(xt), 0, S, B, Lq * 768, T, 0, stream()), L)
+        assert torch.equal(xt.cpu(), ref), "q_sample must be bit-exact with the reference arithmetic"
+    # device RNG: N(0,1) moments, one draw shared by all S, reproducible per seed
+    nz = torch.zeros(B, Lq, 768, device="cuda")
+    x0z = torch.zeros(64, 16, 768, device="cuda")
+    big = torch.zeros(2 * 64, 16, 768, device="cuda")
+    nzb = torch.zeros(64, 16, 768, device="cuda")
+    tt = dev(torch.tensor([50, 50]))
+    acd = dev(R.alpha_cumprod(R.Config(COSIN_SCHEDULE=False, STEP_TOT=100)))
+    ok(L.dic_qsample(p(x0z), 0, p(tt), p(acd), p(big), p(nzb), 2, 64, 16 * 768, 100, 42, stream()), L)
+    torch.cuda.synchronize()
+    e = nzb.cpu()
+    assert abs(float(e.mean())) < 5e-3 and abs(float(e.var()) - 1.0) < 1e-2 and abs(float((e ** 4).mean()) - 3.0) < 0.1
+    assert torch.equal(big[:64], big[64:])
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm family
+def _ln_inputs(T, seed):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn(T, 768, generator=g) * 1.7 + 0.3
+    gamma = 1 + 0.1 * torch.randn(768, generator=g)
+    beta = 0.1 * torch.randn(768, generator=g)
+    dh = torch.randn(T, 768, generator=g)
+    return y, gamma, beta, dh
+
+
+def _colsum(L, part, cols):
+    out = torch.zeros(cols, device="cuda")
+    ws = torch.zeros(64 * cols, device="cuda")
+    ok(L.dic_colsum(F32, p(part), part.shape[0], cols, cols, p(out), 0, p(ws), stream()), L)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_ln_fwd_bwd(L, dtype):
+    T = 333
+    y, gamma, beta, dh = _ln_inputs(T, 1)
+    yd, dhd = dev(y, DT[dtype]), dev(dh, DT[dtype])
+    h = torch.zeros(T, 768, dtype=DT[dtype], device="cuda")
+    mean, rstd = torch.zeros(T, device="cuda"), torch.zeros(T, device="cuda")
+    ok(L.dic_ln_fwd(dtype, p(yd), p(dev(gamma)), p(dev(beta)), p(h), p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+    yy = yd.float().cpu().double().requires_grad_(True)
+    gg, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = R.layer_norm(yy, gg, bb)
+    tol = 2e-6 if dtype == F32 else 8e-3
+    assert relerr(h.float(), ref) < tol
+    ref.backward(dhd.float().cpu().double())
+    dx = torch.zeros(T, 768, dtype=DT[dtype], device="cuda")
+    part = torch.zeros(64, 3 * 768, device="cuda")
+    ok(L.dic_ln_bwd(dtype, p(dhd), p(yd), p(dev(gamma)), p(mean), p(rstd), p(dx), 0, 0.0, 0, p(part), 64, T, 768, stream()), L)
+    s = _colsum(L, part, 3 * 768)
+    assert relerr(dx.float(), yy.grad) < (1e-5 if dtype == F32 else 1e-2)
+    assert relerr(s[:768], gg.grad) < 1e-5 and relerr(s[768:1536], bb.grad) < 1e-5
+    assert relerr(s[1536:], dx.float().cpu().double().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gelu_ln_fwd_bwd(L, dtype):
+    T = 150
+    u, gamma, beta, dxo = _ln_inputs(T, 2)
+    ud = dev(u, DT[dtype])
+    xo = torch.zeros(T, 768, device="cuda")
+    mean, rstd = torch.zeros(T, device="cuda"), torch.zeros(T, device="cuda")
+    ok(L.dic_gelu_ln_fwd(dtype, p(ud), p(dev(gamma)), p(dev(beta)), p(xo), p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+    uu = ud.float().cpu().double().requires_grad_(True)
+    gg, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = R.layer_norm(R.gelu(uu), gg, bb)
+    assert relerr(xo, ref) < 3e-6
+    ref.backward(dxo.double())
+    du = torch.zeros(T, 768, dtype=DT[dtype], device="cuda")
+    part = torch.zeros(32, 3 * 768, device="cuda")
+    ok(L.dic_gelu_ln_bwd(dtype, p(dev(dxo)), p(ud), p(dev(gamma)), p(mean), p(rstd), p(du), p(part), 32, T, 768, stream()), L)
+    s = _colsum(L, part, 3 * 768)
+    assert relerr(du.float(), uu.grad) < (1e-5 if dtype == F32 else 1e-2)
+    assert relerr(s[:768], gg.grad) < 1e-5 and relerr(s[768:1536], bb.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fuse_ln_fwd_bwd(L, dtype, mode):
+    N, Lq = 5, 16
+    Tk = Lq + 2 if mode == 0 else Lq
+    g = torch.Generator().manual_seed(11 + mode)
+    x = torch.randn(N, Lq, 768, generator=g)
+    img, txt = torch.randn(N, 768, generator=g), torch.randn(N, 768, generator=g)
+    seg, pos = torch.randn(2, 768, generator=g), 0.02 * torch.randn(512, 768, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    add_txt = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8)
+    dh = torch.randn(N, Tk, 768, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (img, txt, seg, pos, gamma, beta)]
+    im, tx, sg, ps, gm, bt = leaves
+    if mode == 0:
+        rows = torch.cat([x.double(), im[:, None], tx[:, None]], 1) + sg[torch.tensor([0] * Lq + [1] * 2)]
+    else:
+        rows = x.double() + im[:, None] + tx[:, None] * add_txt.double()[:, None, None]
+    rows = rows + ps[:Tk]
+    rows.retain_grad()
+    ref = R.layer_norm(rows, gm, bt)
+    h = torch.zeros(N, Tk, 768, dtype=DT[dtype], device="cuda")
+    mean, rstd = torch.zeros(N * Tk, device="cuda"), torch.zeros(N * Tk, device="cuda")
+    args = (p(dev(x)), p(dev(img)), p(dev(txt)), p(dev(add_txt)), p(dev(seg)), p(dev(pos)), p(dev(gamma)))
+    ok(L.dic_fuse_ln_fwd(dtype, mode, *args, p(dev(beta)), p(h), p(mean), p(rstd), N, Lq, 768, 1e-12, 0.0, 0, stream()), L)
+    assert relerr(h.float(), ref) < (3e-6 if dtype == F32 else 8e-3)
+    dhd = dev(dh, DT[dtype])
+    ref.backward(dhd.float().cpu().double())
+    dy = torch.zeros(N, Tk, 768, device="cuda")
+    part = torch.zeros(16, 2 * 768, device="cuda")
+    ok(L.dic_fuse_ln_bwd(dtype, mode, *args, p(dhd), p(mean), p(rstd), p(dy), p(part), 16, N, Lq, 768, 0.0, 0, stream()), L)
+    s = _colsum(L, part, 2 * 768)
+    assert relerr(dy, rows.grad) < 1e-5
+    assert relerr(s[:768], gm.grad) < 1e-5 and relerr(s[768:], bt.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype,Tk", [(F32, 18), (F32, 34), (F32, 16), (BF16, 18), (BF16, 16), (BF16, 32)])
+def test_attention_fwd_bwd(L, dtype, Tk):
+    N, H, D = 3, 12, 768
+    g = torch.Generator().manual_seed(Tk + dtype)
+    qkv = torch.randn(N, Tk, 3 * D, generator=g)
+    dctx = torch.randn(N, Tk, D, generator=g)
+    km = torch.ones(N, Tk, dtype=torch.uint8)
+    km[0, 5:Tk - 2] = 0
+    km[1, Tk - 1] = 0
+    km[2, 9:] = 0
+    km[2, 0] = 1
+    qd, dd = dev(qkv, DT[dtype]), dev(dctx, DT[dtype])
+    ctx = torch.full((N, Tk, D), float("nan"), dtype=DT[dtype], device="cuda")
+    ok(L.dic_attn_fwd(dtype, p(qd), p(dev(km)), p(ctx), N, Tk, H, 64, 0.0, 0, stream()), L)
+    qq = qd.float().cpu().double().requires_grad_(True)
+    ref = R.attention(qq[..., :D], qq[..., D:2 * D], qq[..., 2 * D:], km, H)
+    tol = 1e-5 if dtype == F32 else 1.5e-2
+    assert relerr(ctx.float(), ref) < tol
+    ref.backward(dd.float().cpu().double())
+    dq = torch.full((N, Tk, 3 * D), float("nan"), dtype=DT[dtype], device="cuda")
+    ok(L.dic_attn_bwd(dtype, p(qd), p(dev(km)), p(dd), p(dq), N, Tk, H, 64, 0.0, 0, stream()), L)
+    torch.cuda.synchronize()
+    for name, sl in (("dQ", slice(0, D)), ("dK", slice(D, 2 * D)), ("dV", slice(2 * D, 3 * D))):
+        e = relerr(dq.float()[..., sl], qq.grad[..., sl])
+        assert e < (2e-5 if dtype == F32 else 3e-2), f"{name} relerr {e}"
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attention_dropout_mask_is_shared_by_forward_and_backward(L, dtype):
+    N, H, D, Tk, pd, seed = 2, 12, 768, 18, 0.3, 777
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(N, Tk, 3 * D, generator=g)
+    # V = identity block per head -> ctx[i][d=j] = P_dropped[i][j]
+    v = torch.zeros(N, Tk, H, 64)
+    for j in range(Tk):
+        v[:, j, :, j] = 1.0
+    qkv[..., 2 * D:] = v.reshape(N, Tk, D)
+    km = torch.ones(N, Tk, dtype=torch.uint8)
+    qd = dev(qkv, DT[dtype])
+    ctx = torch.zeros(N, Tk, D, dtype=DT[dtype], device="cuda")
+    ok(L.dic_attn_fwd(dtype, p(qd), p(dev(km)), p(ctx), N, Tk, H, 64, pd, seed, stream()), L)
+    Pd = ctx.float().cpu().reshape(N, Tk, H, 64)[..., :Tk]          # [n, i, h, j]
+    drop_rate = float((Pd == 0).float().mean())
+    assert abs(drop_rate - pd) < 0.04
+    # backward with dO = 1: dV[j][d] = sum_i P_dropped[i][j]
+    dq = torch.zeros(N, Tk, 3 * D, dtype=DT[dtype], device="cuda")
+    ones = torch.ones(N, Tk, D, dtype=DT[dtype], device="cuda")
+    ok(L.dic_attn_bwd(dtype, p(qd), p(dev(km)), p(ones), p(dq), N, Tk, H, 64, pd, seed, stream()), L)
+    dV = dq.float().cpu()[..., 2 * D:].reshape(N, Tk, H, 64)[..., 0]  # [n, j, h]
+    colsum = Pd.sum(1).permute(0, 2, 1)                               # [n, j, h]
+    assert relerr(dV, colsum) < (1e-5 if dtype == F32 else 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ losses & small kernels
+@pytest.mark.parametrize("kind,name", list(enumerate(["series_sum_sample_mean", "series_sum", "mse_series_mean", "mse_series_sum"])))
+def test_emb_loss_kinds(L, kind, name):
+    N, B, Lq, Tk = 6, 3, 16, 18
+    g = torch.Generator().manual_seed(kind)
+    xo = torch.randn(N, Tk, 768, generator=g)
+    x0 = torch.randn(B, Lq, 768, generator=g)
+    cfg = R.Config(BATCH_SIZE=B)
+    xx = xo.double().requires_grad_(True)
+    ref = R.LOSS_FUNCS[name](xx[:, :Lq], x0.double().repeat(2, 1, 1), cfg)
+    ref.backward()
+    scale = {0: 1 / (N * 768), 1: 1 / B / 768 / 100, 2: 1 / N, 3: 1 / B}[kind]
+    per = torch.zeros(N, device="cuda")
+    dx = torch.full((N, Tk, 768), float("nan"), device="cuda")
+    gs = torch.full((N,), scale, device="cuda")
+    xr = torch.zeros(N * Lq, 768, device="cuda")
+    out = torch.zeros(3, device="cuda")
+    ok(L.dic_emb_loss(F32, kind, p(dev(xo)), p(dev(x0)), B, p(per), p(dx), p(gs), p(xr), N, Lq, Tk, 768, stream()), L)
+    ok(L.dic_seg_sum(p(per), N, N, scale, 0.0, p(out), stream()), L)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(ref)) < 2e-6 * abs(float(ref))
+    assert relerr(dx, xx.grad) < 1e-5
+    assert torch.equal(xr.cpu().reshape(N, Lq, 768), xo[:, :Lq])
+
+
+def test_small_kernels(L):
+    g = torch.Generator().manual_seed(8)
+    # add_rows
+    N, Lq, Tk = 4, 16, 18
+    dx = torch.randn(N, Tk, 768, generator=g)
+    dxr = torch.randn(N * Lq, 768, generator=g)
+    d = dev(dx)
+    ok(L.dic_add_rows(p(d), p(dev(dxr)), N, Lq, Tk, 768, stream()), L)
+    ref = dx.clone()
+    ref[:, :Lq] += dxr.reshape(N, Lq, 768)
+    assert torch.allclose(d.cpu(), ref)
+    # cfg mix fwd/bwd
+    x = torch.randn(7, Tk * 768, generator=g)
+    gi = torch.tensor([1, 4])
+    xd = dev(x)
+    ok(L.dic_cfg_mix_fwd(p(xd), p(xd[5:]), p(dev(gi)), 2, Tk * 768, 0.3, stream()), L)
+    ref = x.clone()
+    ref[gi] = 1.3 * x[5:7] - 0.3 * x[gi]
+    assert torch.allclose(xd.cpu(), ref, atol=1e-6)
+    dxx = torch.randn(7, Tk * 768, generator=g)
+    dd = dev(dxx)
+    ok(L.dic_cfg_mix_bwd(p(dd), p(dd[5:]), p(dev(gi)), 2, Tk * 768, 0.3, stream()), L)
+    ref = dxx.clone()
+    ref[5:7] = 1.3 * dxx[gi]
+    ref[gi] = -0.3 * dxx[gi]
+    assert torch.allclose(dd.cpu(), ref, atol=1e-6)
+    # colsum (bf16 and f32 inputs, ld > cols, accumulate)
+    a = torch.randn(1000, 3072, generator=g)
+    out = torch.ones(2304, device="cuda")
+    ws = torch.zeros(64 * 2304, device="cuda")
+    ok(L.dic_colsum(F32, p(dev(a)), 1000, 2304, 3072, p(out), 1, p(ws), stream()), L)
+    assert relerr(out, 1 + a[:, :2304].double().sum(0)) < 1e-5
+    ab = dev(a, torch.bfloat16)
+    ok(L.dic_colsum(BF16, p(ab), 1000, 3072, 3072, p(out := torch.zeros(3072, device="cuda")), 0, p(torch.zeros(64 * 3072, device="cuda")), stream()), L)
+    assert relerr(out, ab.float().cpu().double().sum(0)) < 1e-5
+    # seq_sum
+    y = torch.randn(5, 16, 768, generator=g)
+    fl = torch.tensor([1, 0, 0, 1, 1], dtype=torch.uint8)
+    oa, of = torch.zeros(5, 768, device="cuda"), torch.zeros(5, 768, device="cuda")
+    ok(L.dic_seq_sum(p(dev(y)), p(dev(fl)), p(oa), p(of), 5, 16, 768, stream()), L)
+    assert torch.allclose(oa.cpu(), y.sum(1), atol=1e-5) and torch.allclose(of.cpu(), y.sum(1) * fl[:, None].float(), atol=1e-5)
+
+
+def test_adamw_matches_oracle_and_writes_bf16_shadow(L):
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(21)
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = R.AdamW([ref_p], lr=1e-4)
+    P, M_, V_ = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step - 3))
+        ref_p.grad = grad.clone()
+        opt.step()
+        ok(L.dic_adamw(p(P), p(dev(grad * 4)), p(M_), p(V_), p(sh), n, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, 0.25, stream()), L)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(P.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=3e-7)
+    assert torch.equal(sh.cpu(), P.cpu().to(torch.bfloat16))

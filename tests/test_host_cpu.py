@@ -1,0 +1,184 @@
+"""CPU-only checks: host logic, the flat parameter store, the C-ABI library's exports (no compute calls without a GPU),
+the loud-failure rule, and the data-parallel path on 2 gloo ranks with the oracle as the compute stand-in."""
+import importlib
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dic = importlib.import_module("diffusion-image-captioning_amd")
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    dic.build()
+    L = dic.lib()
+    header = open(os.path.join(ROOT, "include", "dic_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(dic_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 25, declared
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(dic._lib.EXPORTS) == declared
+    assert L.dic_version() >= 10
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dic.DistilBertModel(None, None, config=dict(n_layers=1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dic.diffuse_t(torch.zeros(1, 16, 768), torch.zeros(1, dtype=torch.int64))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "diffusion-image-captioning_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_synth_is_deterministic_and_sane():
+    a = dic.synth.normal(dic.synth.stream_id("x", 3), (1000, 64))
+    b = dic.synth.normal(dic.synth.stream_id("x", 3), (1000, 64))
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1) < 0.02
+    assert float(a.flat[0]) == pytest.approx(float(dic.synth.normal(dic.synth.stream_id("x", 3), (5,))[0]))
+    bt = dic.synth.batch(8, 16, 30522, 1)
+    assert bt["input_ids"].min() >= 0 and bt["input_ids"].max() < 30522
+    assert np.allclose(np.linalg.norm(bt["image_clip"], axis=1), 1, atol=1e-6)
+    lens = bt["attention_mask"].sum(1)
+    assert lens.min() >= 6 and lens.max() <= 16 and (np.diff(bt["attention_mask"], axis=1) <= 0).all()
+
+
+def test_param_store_layout_matches_reference_parameter_list():
+    from importlib import import_module
+    ParamStore = import_module("diffusion-image-captioning_amd.params").ParamStore
+    st = ParamStore(6, "cpu", concat=True, bf16_shadow=False)
+    ps = st.parameters()
+    assert len(ps) == 108
+    assert sum(p.numel() for p in ps) == 44_303_616
+    specs = dic.synth.denoiser_param_specs(6)
+    assert [tuple(p.shape) for p in ps] == [s[1] for s in specs]
+    # views alias the flat buffers; grads alias G; q/k/v are slices of one stacked matrix
+    st.P.fill_(1.0)
+    assert all(float(p.min()) == 1.0 for p in ps)
+    st.G.fill_(2.0)
+    assert all(float(p.grad.min()) == 2.0 for p in ps)
+    names = [n for n, _ in st.named_parameters()]
+    q = ps[names.index("model.distilbert.transformer.layer.2.attention.q_lin.weight")]
+    k = ps[names.index("model.distilbert.transformer.layer.2.attention.k_lin.weight")]
+    assert k.data_ptr() - q.data_ptr() == 768 * 768 * 4
+    # [LayerNorm.weight | LayerNorm.bias | bias of the Linear feeding it] contiguous -> one column-sum launch
+    assert st.off("L0.ln1b") - st.off("L0.ln1g") == 768 and st.off("L0.bo") - st.off("L0.ln1b") == 768
+    assert st.off("L3.ln2b") - st.off("L3.ln2g") == 768 and st.off("L3.b2") - st.off("L3.ln2b") == 768
+    assert st.off("bvt") - st.off("vln_g") == 2 * 768
+    # load/state round trip
+    state = dic.synth.denoiser_state(6, 0)
+    st.load_state(state)
+    for n, p in st.named_parameters():
+        assert np.array_equal(p.numpy(), state[n]), n
+    st12 = ParamStore(12, "cpu", concat=False, bf16_shadow=False)
+    assert len(st12.parameters()) == 3 + 12 * 16 + 4 + 4
+
+
+def test_config_mirrors_reference_globals():
+    c = dic.Config()
+    assert (c.BATCH_SIZE, c.MAX_LENGTH, c.SAMPLE_SIZE, c.STEP_TOT, c.COSIN_SCHEDULE) == (8, 16, 100, 1000, True)
+    assert (c.ROUNDING_WEIGHT, c.CLASSIFIER_FREE_PROB, c.X_T_STEP_INTERVAL, c.LOSS_FUNC) == (0.5, 0.2, 100, "series_sum_sample_mean")
+    with pytest.raises(AttributeError):
+        c.update(NOT_A_KNOB=1)
+
+
+def test_bench_flop_model_matches_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert abs(bench.gflop_per_seq(16, 6) - 6.173) / 6.173 < 0.02
+    assert abs(bench.gflop_per_seq(16, 12) - 10.777) / 10.777 < 0.02
+
+
+# ------------------------------------------------------------------ data parallel on 2 CPU ranks (gloo)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    d = importlib.import_module("diffusion-image-captioning_amd")
+    from oracle import ref_model as R
+    ParamStore = importlib.import_module("diffusion-image-captioning_amd.params").ParamStore
+    r, w, _ = d.parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    B, S, L, V, nl = 4, 2, 16, 300, 1
+    E = d.synth.vocab_embedding(V, 768, 0)
+    full = {k: torch.from_numpy(v) for k, v in d.synth.batch(B, L, V, 1).items()}
+    mine = d.parallel.shard(full)
+    assert len(mine["input_ids"]) == B // world
+    # the reference shares ONE t-vector across the whole batch (ref :461): every rank must see rank 0's draw
+    torch.manual_seed(100 + rank)
+    t = d.parallel.shared_randint(0, 100, (S, 1, 1), "cpu")
+    noise_full = [torch.from_numpy(d.synth.noise((B, L, 768), 5, f"eps{i}")) for i in range(2)]
+    noise_mine = [n[rank * (B // world):(rank + 1) * (B // world)] for n in noise_full]
+    cfg = R.Config(BATCH_SIZE=B // world, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=nl, vocab=V)
+    model = R.build(cfg, d.synth.denoiser_state(nl, 0), E)
+    l, *_ = R.train_func(model, R.AdamW(model.parameters()), mine, train=False, t=t, noises=noise_mine)
+    l.backward()
+    store = ParamStore(nl, "cpu", bf16_shadow=False)
+    for (n, p), g in zip(store.named_parameters(), model.parameters()):
+        p.grad.copy_(g.grad)
+
+    class M:            # what parallel.allreduce_grads needs from a model
+        params = store
+
+    class T:
+        grad_scale = 1.0
+    tr = T()
+    d.parallel.allreduce_grads(M, tr)          # ONE collective over the flat buffer
+    assert tr.grad_scale == 1.0 / world
+    (lm,) = d.parallel.allreduce_scalars(l)
+    if rank == 0:
+        torch.save((t.clone(), store.G.clone() * tr.grad_scale, float(lm)), out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_full_batch_gloo_world2():
+    from oracle import ref_model as R
+    ParamStore = importlib.import_module("diffusion-image-captioning_amd.params").ParamStore
+    import tempfile
+    ctx = mp.get_context("spawn")
+    out = os.path.join(tempfile.mkdtemp(), "dp_rank0.pt")
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    t, g_dp, l_dp = torch.load(out)
+    B, S, L, V, nl = 4, 2, 16, 300, 1
+    E = dic.synth.vocab_embedding(V, 768, 0)
+    full = {k: torch.from_numpy(v) for k, v in dic.synth.batch(B, L, V, 1).items()}
+    noise_full = [torch.from_numpy(dic.synth.noise((B, L, 768), 5, f"eps{i}")) for i in range(2)]
+    cfg = R.Config(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=nl, vocab=V)
+    model = R.build(cfg, dic.synth.denoiser_state(nl, 0), E)
+    l, *_ = R.train_func(model, R.AdamW(model.parameters()), full, train=False, t=t, noises=noise_full)
+    l.backward()
+    store = ParamStore(nl, "cpu", bf16_shadow=False)
+    for (n, p), g in zip(store.named_parameters(), model.parameters()):
+        p.grad.copy_(g.grad)
+    assert abs(l_dp - float(l)) < 1e-4 * abs(float(l))
+    err = float((g_dp - store.G).abs().max() / store.G.abs().max())
+    assert err < 1e-5, err
