@@ -40,8 +40,9 @@ extern "C" int dic_embed_gather(const int64_t* ids, const float* E, float* out, 
 // ------------------------------------------------------------------------------------------------ K2 q_sample
 // ref CLIP-DDPM.py:356-362.  Each thread owns 4 consecutive elements of one [B][LD] slab position, draws (or
 // reads) its noise ONCE and writes the S noised copies (s-major output), so x0/eps are read once, not S times.
-__global__ void qsample_kernel(const float* x0, const float* noise, const int64_t* t, const float* ac, float* out,
+__global__ void qsample_kernel(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out,
                                float* noise_out, int S, long long BLD, int step_tot, unsigned long long seed) {
+#pragma clang fp contract(off)   // the reference rounds a*x, eps*b and their sum separately: no FMA contraction here
     const long long n4 = BLD >> 2;
     for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
         f32x4 x = *(const f32x4*)(x0 + i4 * 4);
@@ -62,8 +63,7 @@ __global__ void qsample_kernel(const float* x0, const float* noise, const int64_
         for (int s = 0; s < S; ++s) {
             long long ts = t[s];
             ts = ts < 0 ? 0 : (ts >= step_tot ? step_tot - 1 : ts);
-            const float a = ac[ts];
-            const float ca = sqrtf(a), cb = sqrtf(1.0f - a);
+            const float ca = sqrt_ac[ts], cb = sqrt_1mac[ts];    // tables built on the host exactly as ref :360-361 builds them
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(ca, x[k]), __fmul_rn(e[k], cb));   // un-fused, same op order as ref :360-362 => bit-exact
@@ -71,12 +71,12 @@ __global__ void qsample_kernel(const float* x0, const float* noise, const int64_
         }
     }
 }
-extern "C" int dic_qsample(const float* x0, const float* noise, const int64_t* t, const float* alpha_cumprod, float* out,
+extern "C" int dic_qsample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out,
                            float* noise_out, int S, int B, int LD, int step_tot, uint64_t seed, void* stream) {
     long long BLD = (long long)B * LD;
     DIC_REQUIRE(BLD % 4 == 0 && S > 0, "dic_qsample: B*L*D must be a multiple of 4");
     hipLaunchKernelGGL(qsample_kernel, dim3(grid_for(BLD / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
-                       alpha_cumprod, out, noise_out, S, BLD, step_tot, (unsigned long long)seed);
+                       sqrt_ac, sqrt_1mac, out, noise_out, S, BLD, step_tot, (unsigned long long)seed);
     DIC_CHECK_LAUNCH();
     return 0;
 }

@@ -26,9 +26,13 @@ _state = {"ac_key": None, "ac": None, "noise_seed": 0xD1FF0000, "val_loader": No
 # ------------------------------------------------------------------ schedule (ref :337-346)
 def alpha_cumprod_table(device=None) -> torch.Tensor:
     """alpha-bar[t], computed on the host exactly as the reference does (cosine: :338-342, linear: :344-346)."""
-    key = (cfg.COSIN_SCHEDULE, cfg.STEP_TOT, cfg.BETA_MIN, cfg.BETA_MAX, str(device))
+    ov = _state.get("ac_override")
+    key = (cfg.COSIN_SCHEDULE, cfg.STEP_TOT, cfg.BETA_MIN, cfg.BETA_MAX, str(device), id(ov))
     if _state["ac_key"] != key:
-        if cfg.COSIN_SCHEDULE:
+        if ov is not None:
+            assert ov.numel() == cfg.STEP_TOT, "alpha_cumprod override must have STEP_TOT entries"
+            ac = ov
+        elif cfg.COSIN_SCHEDULE:
             s = 0.008
 
             def sched(t):
@@ -37,9 +41,28 @@ def alpha_cumprod_table(device=None) -> torch.Tensor:
         else:
             betas = torch.hstack([torch.zeros(1), torch.linspace(cfg.BETA_MIN, cfg.BETA_MAX, cfg.STEP_TOT)])
             ac = torch.cumprod((1 - betas)[:-1], 0)
-        _state["ac"] = ac.to(torch.float32).to(device if device is not None else "cuda:0").contiguous()
+        dev = device if device is not None else "cuda:0"
+        ac = ac.to(torch.float32)
+        _state["ac"] = ac.to(dev).contiguous()
+        # the two coefficient tables of q_sample (ref :360-361): CORRECTLY ROUNDED fp32 square roots (sqrt in fp64, then
+        # round: exact for p' >= 2p+2).  torch's long-vector fp32 sqrt is not correctly rounded on every CPU, while the
+        # reference takes sqrt of the S gathered entries (scalar path, correctly rounded) -- this matches the latter.
+        _state["sqrt_ac"] = torch.sqrt(ac.double()).float().to(dev).contiguous()
+        _state["sqrt_1mac"] = torch.sqrt((1 - ac).double()).float().to(dev).contiguous()
         _state["ac_key"] = key
     return _state["ac"]
+
+
+def set_alpha_cumprod(table):
+    """Override the alpha-bar table (custom schedules; also how the golden tests inject the reference host's table --
+    `torch.cos` is not correctly rounded, so the cosine table differs by an ulp between CPU models).  None = rebuild
+    from cfg on next use."""
+    if table is None:
+        _state["ac_key"] = None
+        _state["ac_override"] = None
+        return
+    _state["ac_override"] = torch.as_tensor(table, dtype=torch.float32).cpu().contiguous()
+    _state["ac_key"] = None
 
 
 def seed_noise(seed: int):
@@ -61,12 +84,13 @@ def diffuse_t(x, t, *, noise=None, out=None):
     x = x.contiguous()
     t = t.to(dev, torch.int64).reshape(-1).contiguous()
     S = t.numel()
-    ac = alpha_cumprod_table(dev)
+    alpha_cumprod_table(dev)
     if out is None:
         out = torch.empty(S * b, seq_len, c, dtype=torch.float32, device=dev)
     nz = noise.to(dev, torch.float32).contiguous() if noise is not None else None
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(L.dic_qsample(_p(x), _p(nz), _p(t), _p(ac), _p(out), 0, S, b, seq_len * c, cfg.STEP_TOT, _next_seed(), st), "qsample")
+    _lib.check(L.dic_qsample(_p(x), _p(nz), _p(t), _p(_state["sqrt_ac"]), _p(_state["sqrt_1mac"]), _p(out), 0, S, b, seq_len * c,
+                             cfg.STEP_TOT, _next_seed(), st), "qsample")
     return out
 
 
@@ -113,6 +137,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         if gi.numel() == 0:
             gi = None
     Ng = 0 if gi is None else int(gi.numel())
+    model.params.text_unused = (not model.concat) and Ng == 0
     N = Nt + Ng + B
     ws = model._workspace(N, L)
     Tk = ws["Tk"]
@@ -238,8 +263,12 @@ class AdamW:
         self.t += 1
         s = self.store
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().dic_adamw(_p(s.P), _p(s.G), _p(self.m), _p(self.v), _p(s.Pb), s.numel, float(g["lr"]), b1, b2, g["eps"],
-                                        g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, self.grad_scale, st), "adamw")
+        # torch skips tensors whose .grad is None (unused this step: text_linear under "add" fusion without guidance)
+        for lo, hi in s.active_ranges():
+            sh = (_p(s.Pb) + 2 * lo) if s.Pb is not None else 0
+            _lib.check(_lib.lib().dic_adamw(_p(s.P) + 4 * lo, _p(s.G) + 4 * lo, _p(self.m) + 4 * lo, _p(self.v) + 4 * lo, sh, hi - lo,
+                                            float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                                            self.grad_scale, st), "adamw")
 
     def state_dict(self):
         return dict(t=self.t, m=self.m.clone(), v=self.v.clone(), param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])

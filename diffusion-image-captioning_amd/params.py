@@ -49,6 +49,7 @@ class ParamStore:
         if concat:
             add("seg", (2, dim))
         self.numel = off
+        self.text_unused = False      # set per step by diffusion.loss(): text_linear takes no part in the graph
         self.P = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.G = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if bf16_shadow else None
@@ -101,6 +102,15 @@ class ParamStore:
              "sa_layer_norm.bias": "ln1b", "ffn.lin1.weight": "W1", "ffn.lin1.bias": "b1", "ffn.lin2.weight": "W2",
              "ffn.lin2.bias": "b2", "output_layer_norm.weight": "ln2g", "output_layer_norm.bias": "ln2b"}
         return self.slot_view(buf, L + m[rest])
+
+    def active_ranges(self):
+        """Flat [lo, hi) ranges the optimizer must touch: everything, minus text_linear when it was unused this step."""
+        if not self.text_unused:
+            return [(0, self.numel)]
+        lo = self._slots["Wtxt"][0]
+        o, shp = self._slots["btxt"]
+        hi = o + (int(np.prod(shp)) + ALIGN - 1) // ALIGN * ALIGN
+        return [(0, lo), (hi, self.numel)] if hi < self.numel else [(0, lo)]
 
     # ---- public
     def relink_grads(self):

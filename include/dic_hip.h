@@ -77,10 +77,12 @@ int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_pa
 
 /* ---------------------------------------------------------------- embedding + q_sample (ref:459, 347-362) */
 int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, void* stream);
-/* out[(s*B+b)*LD + i] = sqrt(ac[t[s]])*x0[b*LD+i] + sqrt(1-ac[t[s]])*eps[b*LD+i]; eps = `noise` when non-NULL,
- * else N(0,1) from Philox4x32-10 keyed by (seed, b*LD+i) -- ONE draw per element shared by all S, as ref:359. */
-int dic_qsample(const float* x0, const float* noise, const int64_t* t, const float* alpha_cumprod, float* out,
-                float* noise_out, int S, int B, int LD, int step_tot, uint64_t seed, void* stream);
+/* out[(s*B+b)*LD + i] = sqrt_ac[t[s]]*x0[b*LD+i] + eps[b*LD+i]*sqrt_1mac[t[s]] (un-fused mul/mul/add: bit-exact with
+ * ref:360-362); sqrt_ac = sqrt(alpha_cumprod), sqrt_1mac = sqrt(1-alpha_cumprod), tables of length step_tot;
+ * eps = `noise` when non-NULL, else N(0,1) from Philox4x32-10 keyed by (seed, b*LD+i) -- ONE draw per element shared
+ * by all S, as ref:359.  noise_out (optional) receives eps.                                                          */
+int dic_qsample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                float* out, float* noise_out, int S, int B, int LD, int step_tot, uint64_t seed, void* stream);
 
 /* ---------------------------------------------------------------- fusion + embeddings LayerNorm (ref:299-307, hf:113-117)
  * mode 0 "concat": row t<L = x[n][t]; row L = img[n]; row L+1 = txt[n]; + seg[t>=L] + pos[t]; LayerNorm(eps);

