@@ -40,6 +40,8 @@ class Config:
     USE_X_1_LOSS: bool = True
     USE_PROB_LOSS: bool = True
     VOCAB_SIZE: int = 30522
+    # build-side switch (not a reference constant): skip the provably-unused text row when no sequence is guided
+    DROP_UNUSED_TEXT_ROW: bool = True
 
     def update(self, **kw):
         for k, v in kw.items():

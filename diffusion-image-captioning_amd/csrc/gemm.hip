@@ -22,6 +22,7 @@
 // CONSECUTIVE n for one m: epilogue loads/stores are 8-byte (bf16) or 16-byte (f32) vectors.
 #include "common.h"
 #include "../../include/dic_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -99,94 +100,37 @@ __device__ __forceinline__ float frag_f32(const char* lds, int base, int k4, int
 
 __device__ __forceinline__ float row_scale(const DicGemmParams& p, int m) { return m < p.ce_rows_a ? p.ce_scale_a : p.ce_scale_b; }
 
-template <typename T, bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int S = sizeof(T);
-    constexpr int BK = KCfg<T>::BK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware block order: consecutive logical tiles (same A row-panel) share one XCD's L2.
-    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM, nwg = nbm * nbn;
+// ---- block -> (tile, K-slice) ----------------------------------------------------------------------
+// XCD-aware order: consecutive logical ids (same A row-panel, then the K-slices of one tile) share one XCD's L2.
+struct TileId { int bm, bn, nbn, kz, kt0, kt1; };
+__device__ __forceinline__ TileId tile_of_block(const DicGemmParams& p, int BK) {
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int split = p.split_k > 1 ? p.split_k : 1;
+    const int nwg = nbm * nbn * split;
     int pid = blockIdx.x;
     {
         int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, slot = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int bm = pid / nbn, bn = pid % nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
+    TileId t;
+    t.kz = pid % split;
+    const int tile = pid / split;
+    t.bm = tile / nbn; t.bn = tile % nbn; t.nbn = nbn;
+    const int nk = (p.K + BK - 1) / BK, per = (nk + split - 1) / split;
+    t.kt0 = t.kz * per;
+    t.kt1 = min(nk, t.kt0 + per);
+    return t;
+}
+// split-K: slice kz writes its plain fp32 partial tile into slab kz of the workspace; dic_gemm folds the slabs after.
+__device__ __forceinline__ void redirect_to_slab(DicGemmParams& p, int kz) {
+    p.C = (float*)p.split_ws + (size_t)kz * p.M * p.ldc;
+    p.bias = nullptr; p.R = nullptr; p.p_drop = 0.f; p.out_f32 = 1; p.accumulate = 0;
+}
 
-    // buffer descriptors anchored at the tile origin; num_records ends at the matrix end => OOB rows read 0
-    const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
-    const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
-    long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
-    long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
-    if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
-    if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    i32x4 ra[4], rb[4];
-    stage_load<T, AKM>(ra, rsA, p.lda, 0, tid);
-    stage_load<T, BKM>(rb, rsB, p.ldb, 0, tid);
-    stage_store<T, AKM>(ra, smem, tid);
-    stage_store<T, BKM>(rb, smem + TILE_BYTES, tid);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* la = smem + (kt & 1) * (2 * TILE_BYTES);
-        const char* lb = la + TILE_BYTES;
-        if (kt + 1 < nk) {
-            stage_load<T, AKM>(ra, rsA, p.lda, (kt + 1) * BK, tid);
-            stage_load<T, BKM>(rb, rsB, p.ldb, (kt + 1) * BK, tid);
-        }
-        if constexpr (sizeof(T) == 2) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<AKM>(la, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = frag_bf16<BKM>(lb, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                float fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag_f32<AKM>(la, wm * 64 + i * 16, k4, lane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = frag_f32<BKM>(lb, wn * 64 + j * 16, k4, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) {
-            char* na = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
-            stage_store<T, AKM>(ra, na, tid);
-            stage_store<T, BKM>(rb, na + TILE_BYTES, tid);
-        }
-        __syncthreads();
-    }
-
-    // ------------------------------------------------------------------ epilogue
-    // acc[i][j][r]  <->  m = m0 + wm*64 + i*16 + (lane&15),  n = n0 + wn*64 + j*16 + (lane>>4)*4 + r
+// ---- epilogues, shared by both kernels -----------------------------------------------------------
+// acc[i][j][r]  <->  m = m0 + wm*64 + i*16 + (lane&15),  n = n0 + wn*64 + j*16 + (lane>>4)*4 + r
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const DicGemmParams& p, int m0, int n0, int wm, int wn, int lane, int bn, int nbn) {
     const int g = lane >> 4, t = lane & 15;
     if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_GELU_BWD) {
         const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
@@ -215,12 +159,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {
                     Elem<T>::st4((T*)p.aux + (size_t)m * p.ldaux + n, v);   // pre-activation u (for GELU')
                     f32x4 gl;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gl[r] = gelu_f(v[r]);
+                    for (int r = 0; r < 4; ++r) gl[r] = sizeof(T) == 2 ? gelu_fast(v[r]) : gelu_f(v[r]);
                     Elem<T>::st4((T*)p.C + (size_t)m * p.ldc + n, gl);
                 } else {   // GELU_BWD: dU = acc * gelu'(U)
                     f32x4 u = Elem<T>::ld4((const T*)p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(u[r]);
+                    for (int r = 0; r < 4; ++r) v[r] *= sizeof(T) == 2 ? gelu_grad_fast(u[r]) : gelu_grad_f(u[r]);
                     Elem<T>::st4((T*)p.C + (size_t)m * p.ldc + n, v);
                 }
             }
@@ -294,8 +238,247 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {
     }
 }
 
+template <typename T, bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {   // v1: register-staged; fp32 parity path (and bf16 A/B reference)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int S = sizeof(T);
+    constexpr int BK = KCfg<T>::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    TileId tl = tile_of_block(p, BK);
+    const int bm = tl.bm, bn = tl.bn, nbn = tl.nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    if (p.split_k > 1) redirect_to_slab(p, tl.kz);
+
+    // buffer descriptors anchored at the tile origin; num_records ends at the matrix end => OOB rows read 0
+    const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
+    const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
+    long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
+    long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
+    if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
+    if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int kt0 = tl.kt0, nk = tl.kt1;
+    i32x4 ra[4], rb[4];
+    stage_load<T, AKM>(ra, rsA, p.lda, kt0 * BK, tid);
+    stage_load<T, BKM>(rb, rsB, p.ldb, kt0 * BK, tid);
+    stage_store<T, AKM>(ra, smem + (kt0 & 1) * (2 * TILE_BYTES), tid);
+    stage_store<T, BKM>(rb, smem + (kt0 & 1) * (2 * TILE_BYTES) + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = kt0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* lb = la + TILE_BYTES;
+        if (kt + 1 < nk) {
+            stage_load<T, AKM>(ra, rsA, p.lda, (kt + 1) * BK, tid);
+            stage_load<T, BKM>(rb, rsB, p.ldb, (kt + 1) * BK, tid);
+        }
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag_bf16<AKM>(la, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag_bf16<BKM>(lb, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag_f32<AKM>(la, wm * 64 + i * 16, k4, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag_f32<BKM>(lb, wn * 64 + j * 16, k4, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            char* na = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
+            stage_store<T, AKM>(ra, na, tid);
+            stage_store<T, BKM>(rb, na + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+    epilogue<T, EPI>(acc, p, m0, n0, wm, wn, lane, bn, nbn);
+}
+
+// =====================================================================================================
+// bf16 kernel: operand tiles go HBM/L2 -> LDS directly with `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging VGPRs and
+// no ds_write pass (the register-staged v1 spent ~830 of every ~1340 LDS cycles per K-step on ds_write_b128); the next
+// tile's DMA is in flight while the MFMAs of the current tile run.  The DMA destination is lane-linear (wave base +
+// lane*16), so the bank-conflict-free LDS image is produced by permuting the per-lane SOURCE address and applying the
+// same XOR on the fragment reads (both verified against the bank model of MI355X_MICROARCH.md):
+//   KC tile [128 rows][128 B]: 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7); fragment = ONE ds_read_b128
+//                              (8 consecutive k), conflict-free and not mergeable into the half-rate ds_read2 forms
+//   KM tile [ 64 k   ][256 B]: chunk c of row k lives at c ^ km_key(k); fragment = two ds_read_b64_tr_b16 on rows
+//                              8g+{0..3} and 8g+4+{0..3}  => lane group g = lane>>4 holds k = 8g..8g+7 in BOTH layouts.
+// Everything lane-dependent (DMA source offsets, fragment addresses) is computed once; the K loop is 8 DMA issues,
+// 8+8 LDS reads, 32 MFMAs, 8 integer adds and one barrier per 64-deep step, unrolled over the two LDS stages so that
+// stage offsets are instruction immediates.
+constexpr int DMA_TILE = 16384, DMA_STAGE = 32768;
+__device__ __forceinline__ int kc_key(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int km_key(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
+
+template <bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = bf16_t;
+    constexpr int S = 2, BK = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, t = lane & 15;
+    TileId tl = tile_of_block(p, BK);
+    const int bm = tl.bm, bn = tl.bn, nbn = tl.nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    if (p.split_k > 1) redirect_to_slab(p, tl.kz);
+
+    const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
+    const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
+    long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
+    long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
+    if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
+    if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
+
+    const int kt0 = tl.kt0, nk = tl.kt1;
+    // ---- per-lane DMA source offsets of the 4 x 1 KiB pieces this wave stages per operand; they advance by a uniform step.
+    // (kept in VGPRs rather than the scalar offset operand: the descriptor's bounds check covers only the vector offset, and
+    //  it is that check which zero-fills ragged M/N/K)
+    unsigned voA[4], voB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = wave * 4 + j;
+        if (!AKM) { const int row = 8 * q + (lane >> 3); voA[j] = ((unsigned)row * (unsigned)p.lda + (unsigned)(kt0 * BK)) * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+        else      { const int row = 4 * q + (lane >> 4); voA[j] = ((unsigned)(kt0 * BK + row) * (unsigned)p.lda) * 2u + (((lane & 15) ^ km_key(row)) << 4); }
+        if (!BKM) { const int row = 8 * q + (lane >> 3); voB[j] = ((unsigned)row * (unsigned)p.ldb + (unsigned)(kt0 * BK)) * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+        else      { const int row = 4 * q + (lane >> 4); voB[j] = ((unsigned)(kt0 * BK + row) * (unsigned)p.ldb) * 2u + (((lane & 15) ^ km_key(row)) << 4); }
+    }
+    const unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;
+    const unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
+    // ---- per-lane fragment addresses inside an operand tile
+    int ofA[4][2], ofB[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (!AKM) { const int row = wm * 64 + i * 16 + t; ofA[i][kk] = row * 128 + (((kk * 4 + g) ^ kc_key(row)) << 4); }
+            else { const int rho = kk * 32 + 8 * g + (t >> 2), c = ((wm * 64 + i * 16) >> 3) + ((t & 3) >> 1); ofA[i][kk] = rho * 256 + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
+            if (!BKM) { const int row = wn * 64 + i * 16 + t; ofB[i][kk] = row * 128 + (((kk * 4 + g) ^ kc_key(row)) << 4); }
+            else { const int rho = kk * 32 + 8 * g + (t >> 2), c = ((wn * 64 + i * 16) >> 3) + ((t & 3) >> 1); ofB[i][kk] = rho * 256 + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
+        }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int stage) {
+        char* dst = smem + stage * DMA_STAGE + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(dst + j * 1024), 16, (int)voA[j], 0, 0, 0);
+            voA[j] += stepA;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(dst + DMA_TILE + j * 1024), 16, (int)voB[j], 0, 0, 0);
+            voB[j] += stepB;
+        }
+    };
+    auto frag = [&](const char* tile, int off, bool km) -> bf16x8 {
+        if (!km) { i32x4 v = *(const i32x4*)(tile + off); return __builtin_bit_cast(bf16x8, v); }
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off + 1024));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto compute = [&](int stage) {
+        const char* la = smem + stage * DMA_STAGE;
+        const char* lb = la + DMA_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag(la, ofA[i][kk], AKM);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag(lb, ofB[j][kk], BKM);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    int kt = kt0;
+    if (kt < nk) issue(0);
+    __syncthreads();                     // (the compiler drains the LDS-DMA with vmcnt(0) ahead of the barrier)
+    while (kt < nk) {
+        if (kt + 1 < nk) issue(1);       // next tile's DMA flies under this tile's MFMAs
+        compute(0);
+        __syncthreads();
+        if (++kt >= nk) break;
+        if (kt + 1 < nk) issue(0);
+        compute(1);
+        __syncthreads();
+        ++kt;
+    }
+    epilogue<T, EPI>(acc, p, m0, n0, wm, wn, lane, bn, nbn);
+}
+
+// fold split-K slabs: out[i] (+)= sum_s ws[s][i]   (fixed order => deterministic)
+__global__ void reduce_slabs_kernel(const float* ws, int nslab, long long n4, float* out, int accumulate) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 a = ((const f32x4*)ws)[i];
+        for (int s = 1; s < nslab; ++s) a += ((const f32x4*)ws)[(size_t)s * n4 + i];
+        if (accumulate) a += ((const f32x4*)out)[i];
+        ((f32x4*)out)[i] = a;
+    }
+}
+
+// DIC_GEMM=1 runs bf16 on the register-staged v1 kernel (kept for within-run A/B measurements); default = LDS-DMA kernel.
+bool bf16_on_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DIC_GEMM"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <typename T, bool AKM, bool BKM, int E>
 void launch_one(dim3 grid, hipStream_t st, const DicGemmParams& q) {
+    if constexpr (sizeof(T) == 2) {
+        if (!bf16_on_v1()) {
+            constexpr size_t lds = 2 * DMA_STAGE;           // 64 KB: two stages x (A tile + B tile) -> 2 workgroups per CU
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, E>), grid, dim3(NT), lds, st, q);
+            return;
+        }
+    }
     constexpr size_t lds = 4 * TILE_BYTES;   // 72 KB: two stages x (A tile + B tile) -> 2 workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
@@ -308,7 +491,8 @@ void launch_one(dim3 grid, hipStream_t st, const DicGemmParams& q) {
 template <typename T, bool AKM, bool BKM>
 int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-    dim3 grid(nbm * nbn);
+    const int split = p.split_k > 1 ? p.split_k : 1;
+    dim3 grid(nbm * nbn * split);
     switch (epi) {
         case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(grid, st, p); break;
         case DIC_EPI_BIAS_GELU: launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(grid, st, p); break;
@@ -316,6 +500,12 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
         case DIC_EPI_CE_PARTIAL: launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(grid, st, p); break;
         case DIC_EPI_CE_DLOGITS: launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(grid, st, p); break;
         default: dic_set_error("dic_gemm: unknown epilogue"); return 1002;
+    }
+    if (split > 1) {
+        const long long n4 = (long long)p.M * p.ldc / 4;
+        int g = (int)((n4 + 255) / 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(g), dim3(256), 0, st, (const float*)p.split_ws, split, n4, (float*)p.C, p.accumulate);
     }
     DIC_CHECK_LAUNCH();
     return 0;
@@ -381,6 +571,9 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (b_km) DIC_REQUIRE((long long)p.K * p.ldb * es < 0x7FFFFFFFll, "dic_gemm: k-major B too large for 32-bit buffer offsets");
     if (!a_km) DIC_REQUIRE((long long)BM * p.lda * es < 0x7FFFFFFFll, "dic_gemm: lda too large");
     if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
+    if (p.split_k > 1)
+        DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
+                    "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*M*N floats");
     if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % 4 == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DIC_BF16) return launch_layout<bf16_t>(p, a_km, b_km, epi, st);

@@ -280,8 +280,30 @@ __global__ void colsum_stage2(const float* ws, int nslab, int cols, float* out, 
     if (accumulate) acc += *(const f32x4*)(out + c);
     *(f32x4*)(out + c) = acc;
 }
+// few rows (the per-block partial rows of the LayerNorm backward kernels, split-K style folds): one launch, 4 waves per
+// 256 columns split the rows, LDS fold, fixed order.
+__global__ __launch_bounds__(256) void colsum_small(const float* in, int rows, int cols, int ld, float* out, int accumulate) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    if (c < cols)
+        for (int r = w; r < rows; r += 4) acc += *(const f32x4*)(in + (size_t)r * ld + c);
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < cols) {
+        f32x4 v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (accumulate) v += *(const f32x4*)(out + c);
+        *(f32x4*)(out + c) = v;
+    }
+}
 extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream) {
     DIC_REQUIRE(cols % 4 == 0 && rows > 0, "dic_colsum: cols must be a multiple of 4");
+    if (in_dtype == DIC_F32 && rows <= 512) {
+        hipLaunchKernelGGL(colsum_small, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)in, rows, cols, ld, out, accumulate);
+        DIC_CHECK_LAUNCH();
+        return 0;
+    }
     int nslab = (rows + 3) / 4;
     if (nslab > 64) nslab = 64;
     dim3 grid((cols + 255) / 256, nslab);

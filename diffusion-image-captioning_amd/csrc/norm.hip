@@ -50,11 +50,14 @@ __device__ __forceinline__ void fold_partials(f32x4 (&acc)[K][NCH], float* parti
 // ---------------------------------------------------------------------------------------------- fused input rows
 // mode 0 concat (ref :299-300): rows t<L: x + seg0 + pos[t]; row L: img + seg1 + pos[L]; row L+1: txt + seg1 + pos[L+1]
 // mode 1 add    (ref :306-307): rows t<L: x + img (+ txt if add_txt[n]) + pos[t]
+// mode 2 concat without the text row (Tk = L+1): when no row of the batch is classifier-free-guided the text row is masked
+//        as a key for every query and its own outputs are never read (ref :297, :323, :418), so it can be left out of the
+//        sequence without changing any loss or any gradient (text_linear's gradient is exactly zero either way).
 __device__ __forceinline__ void fused_row(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
                                           const float* seg, const float* pos, int n, int t, int L, int lane, f32x4 (&v)[NCH]) {
     f32x4 p[NCH];
     load_row<float>(pos + (size_t)t * D, lane, p);
-    if (mode == 0) {
+    if (mode != 1) {
         const float* src = t < L ? x + ((size_t)n * L + t) * D : (t == L ? img + (size_t)n * D : txt + (size_t)n * D);
         f32x4 s[NCH];
         load_row<float>(src, lane, v);
@@ -298,7 +301,7 @@ extern "C" int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float*
                                const float* seg, const float* pos, const float* gamma, const float* beta, void* h, float* mean,
                                float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
     DIC_REQUIRE(Dd == D, "dic_fuse_ln_fwd: D must be 768");
-    const int Tk = mode == 0 ? L + 2 : L;
+    const int Tk = mode == 0 ? L + 2 : (mode == 2 ? L + 1 : L);
     dim3 grid(rows_grid(N * Tk, 2048)), block(256);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
@@ -312,7 +315,7 @@ extern "C" int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float*
                                const float* rstd, float* dy, float* partial, int n_partial_blocks, int N, int L, int Dd, float p_drop,
                                uint64_t seed, void* stream) {
     DIC_REQUIRE(Dd == D && n_partial_blocks > 0, "dic_fuse_ln_bwd: D must be 768");
-    const int Tk = mode == 0 ? L + 2 : L;
+    const int Tk = mode == 0 ? L + 2 : (mode == 2 ? L + 1 : L);
     dim3 grid(n_partial_blocks), block(256);
     const size_t lds = 4 * 2 * D * sizeof(float);
     hipStream_t st = (hipStream_t)stream;

@@ -139,7 +139,9 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     Ng = 0 if gi is None else int(gi.numel())
     model.params.text_unused = (not model.concat) and Ng == 0
     N = Nt + Ng + B
-    ws = model._workspace(N, L)
+    # without a guided row the text row is masked as a key everywhere and its outputs are unused: leave it out (Tk = L+1)
+    drop_txt = model.concat and Ng == 0 and cfg.DROP_UNUSED_TEXT_ROW
+    ws = model._workspace(N, L, drop_txt)
     Tk = ws["Tk"]
 
     # ---- one stacked encoder batch: [x_t rows | guided copies | x_1 rows]
@@ -153,8 +155,8 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     m_rep = m.repeat(S, 1)
     if model.concat:
         one_t, one_b = torch.ones(Nt, 1, dtype=torch.uint8, device=dev), torch.ones(B, 1, dtype=torch.uint8, device=dev)
-        plain_t = torch.cat([m_rep, one_t, 0 * one_t], 1)
-        plain_b = torch.cat([m, one_b, 0 * one_b], 1)
+        plain_t = torch.cat([m_rep, one_t] if drop_txt else [m_rep, one_t, 0 * one_t], 1)
+        plain_b = torch.cat([m, one_b] if drop_txt else [m, one_b, 0 * one_b], 1)
     else:
         plain_t, plain_b = m_rep, m
     add_txt = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -167,7 +169,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         add_txt[Nt:Nt + Ng] = 1
     else:
         ic, tc, km = torch.cat([img_rep, img]), torch.cat([txt_rep, txt]), torch.cat([plain_t, plain_b])
-    x_out = model.encode(xin, ic, tc, km, add_txt)
+    x_out = model.encode(xin, ic, tc, km, add_txt, drop_txt=drop_txt)
     st = model.ops.stream
     row = Tk * 768
     if Ng:

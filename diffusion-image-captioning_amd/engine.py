@@ -43,7 +43,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -51,7 +51,17 @@ class Ops:
         g.p_drop, g.seed, g.out_f32, g.accumulate = p_drop, seed, out_f32, accumulate
         g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
         g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
+        g.split_k, g.split_ws = split_k, split_ws
         _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
+
+
+def pick_split_k(M, N, K, bk=64, target_blocks=512, max_split=32):
+    """dW GEMMs have few output tiles (768x768 -> 36) but a long contraction (all tokens): cut K so that about two
+    workgroups per CU exist (256 CUs x 2 resident), each slice keeping >= 8 K-steps."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = (K + bk - 1) // bk
+    s = max(1, min(max_split, target_blocks // max(tiles, 1), nk // 8))
+    return s
 
 
 class Denoiser:
@@ -154,9 +164,9 @@ class Denoiser:
         return out[:, :self.vocab].reshape(*shp, self.vocab)
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, N, L):
-        Tk = L + 2 if self.concat else L
-        key = (N, L)
+    def _workspace(self, N, L, drop_txt=False):
+        Tk = (L + 1 if drop_txt else L + 2) if self.concat else L
+        key = (N, L, Tk)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -165,7 +175,7 @@ class Denoiser:
         T, D, Hd, dev, td = N * Tk, self.dim, self.hidden, self.device, self.tdtype
         e = lambda *s, dtype=td: torch.empty(*s, dtype=dtype, device=dev)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        ws = dict(N=N, L=L, Tk=Tk, T=T)
+        ws = dict(N=N, L=L, Tk=Tk, T=T, mode=(2 if drop_txt else 0) if self.concat else 1)
         ws["img_in"], ws["txt_in"] = f(N, 512), f(N, 512)
         ws["img_p"], ws["txt_p"] = f(N, D), f(N, D)
         ws["xin"] = f(N, L, D)
@@ -186,6 +196,7 @@ class Denoiser:
         ws["partial"] = f(NPART, 3 * D)
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
+        ws["splitk"] = f(32 * 1024 * 1024)          # 128 MB: split_k * M * N fp32 partial tiles of one dW GEMM
         self._ws[key] = ws
         return ws
 
@@ -204,11 +215,12 @@ class Denoiser:
         return ws
 
     # ------------------------------------------------------------------ encoder forward (hf:92-118, 150-259, 501-513)
-    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None):
+    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False):
         """x [N,L,768] fp32; image_clip/text_clip [N,512]; key_mask [N,Tk] uint8 -> x_out [N,Tk,768] fp32.
-        Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training."""
+        Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training.
+        drop_txt (concat fusion, no guided row in the batch): run with Tk = L+1, leaving the never-read text row out."""
         N, L, _ = x.shape
-        ws = self._workspace(N, L)
+        ws = self._workspace(N, L, drop_txt)
         Tk, T, D, Hd = ws["Tk"], ws["T"], self.dim, self.hidden
         o, P, lib = self.ops, self.params, self.ops.L
         o.begin()
@@ -226,10 +238,11 @@ class Denoiser:
         ws["kmask"].copy_(key_mask)
         if add_txt is not None:
             ws["addtxt"].copy_(add_txt)
-        mode = 0 if self.concat else 1
+        mode = ws["mode"]
         # K3: CLIP projections, exact fp32 MFMA (tiny)
         o.gemm(_p(ws["img_in"]), P.ptr("Wimg"), _p(ws["img_p"]), N, D, 512, 512, 512, D, bias=P.ptr("bimg"), out_f32=1, dtype=DIC_F32)
-        o.gemm(_p(ws["txt_in"]), P.ptr("Wtxt"), _p(ws["txt_p"]), N, D, 512, 512, 512, D, bias=P.ptr("btxt"), out_f32=1, dtype=DIC_F32)
+        if mode != 2:
+            o.gemm(_p(ws["txt_in"]), P.ptr("Wtxt"), _p(ws["txt_p"]), N, D, 512, 512, 512, D, bias=P.ptr("btxt"), out_f32=1, dtype=DIC_F32)
         # K4: concat/add fusion + segment + position + LayerNorm (+ dropout)
         _lib.check(lib.dic_fuse_ln_fwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                        P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), P.ptr("eln_b"),
@@ -271,13 +284,23 @@ class Denoiser:
         csw = _p(ws["cs_ws"])
         part = _p(ws["partial"])
 
+        skw = _p(ws["splitk"])
+        skcap = ws["splitk"].numel()
+
+        def wgrad(dY, X, slot, M, N, lda, ldb):
+            """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip."""
+            sk = pick_split_k(M, N, T, 64 if self.bf16 else 32)
+            while sk > 1 and sk * M * N > skcap:
+                sk -= 1
+            o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0)
+
         def colsum(in_dtype, src, rows, cols, ld, dst, acc=0):
             _lib.check(lib.dic_colsum(in_dtype, src, rows, cols, ld, dst, acc, csw, st), "colsum")
 
         # head: GELU+LN backward, vocab_transform
         _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(ws["dy"]), part, NPART, T, D, st), "gelu_ln_bwd")
         colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr("vln_g", "G"))                      # [vln_g | vln_b | bvt]
-        o.gemm(_p(ws["dy"]), _p(ws["h"][-1]), P.ptr("Wvt", "G"), D, D, T, D, D, D, a_km=1, b_km=1, out_f32=1)
+        wgrad(_p(ws["dy"]), _p(ws["h"][-1]), "Wvt", D, D, D, D)
         dH, dHn = ws["dHa"], ws["dHb"]
         o.gemm(_p(ws["dy"]), P.ptr("Wvt", wsrc), _p(dH), T, D, D, D, D, D, b_km=1)
         for i in reversed(range(self.n_layers)):
@@ -289,25 +312,25 @@ class Denoiser:
                                       _p(ws["dyd"]) if use_drop else 0, ph, seed + 4 * i + 2, part, NPART, T, D, st), "ln_bwd")
             colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln2g", "G"))              # [ln2g | ln2b | b2]
             dyd = ws["dyd"] if use_drop else ws["dy"]
-            o.gemm(_p(dyd), _p(Lw["g"]), P.ptr(pre + "W2", "G"), D, Hd, T, D, Hd, Hd, a_km=1, b_km=1, out_f32=1)          # dW2
+            wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(ws["du"]), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
             colsum(self.dt, _p(ws["du"]), T, Hd, Hd, P.ptr(pre + "b1", "G"))                  # db1
-            o.gemm(_p(ws["du"]), _p(Lw["sa"]), P.ptr(pre + "W1", "G"), Hd, D, T, Hd, D, D, a_km=1, b_km=1, out_f32=1)      # dW1
+            wgrad(_p(ws["du"]), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D)
             o.gemm(_p(ws["du"]), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(ws["dy"]), ldr=D)  # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(ws["dy1"]),
                                       0, 0.0, 0, part, NPART, T, D, st), "ln_bwd")
             colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln1g", "G"))              # [ln1g | ln1b | bo]
-            o.gemm(_p(ws["dy1"]), _p(Lw["ctx"]), P.ptr(pre + "Wo", "G"), D, D, T, D, D, D, a_km=1, b_km=1, out_f32=1)       # dWo
+            wgrad(_p(ws["dy1"]), _p(Lw["ctx"]), pre + "Wo", D, D, D, D)
             o.gemm(_p(ws["dy1"]), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
             _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(ws["dqkv"]), N, Tk, self.n_heads, 64, pa,
                                         seed + 4 * i + 1, st), "attn_bwd")
             colsum(self.dt, _p(ws["dqkv"]), T, 3 * D, 3 * D, P.ptr(pre + "bqkv", "G"))        # dbqkv
-            o.gemm(_p(ws["dqkv"]), _p(h), P.ptr(pre + "Wqkv", "G"), 3 * D, D, T, 3 * D, D, D, a_km=1, b_km=1, out_f32=1)    # dWqkv
+            wgrad(_p(ws["dqkv"]), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D)
             o.gemm(_p(ws["dqkv"]), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(ws["dy1"]), ldr=D)
             dH, dHn = dHn, dH
         # embeddings LayerNorm + fusion backward
-        mode = 0 if self.concat else 1
+        mode = ws["mode"]
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                        P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
                                        _p(ws["dy0"]), part, NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
@@ -317,7 +340,7 @@ class Denoiser:
         if self.concat:
             gpos = P.ptr("pos", "G")
             colsum(DIC_F32, gpos, L, D, D, P.ptr("seg", "G"))                                  # dseg[0] = sum_{t<L}
-            colsum(DIC_F32, gpos + L * D * 4, 2, D, D, P.ptr("seg", "G") + D * 4)              # dseg[1] = rows L, L+1
+            colsum(DIC_F32, gpos + L * D * 4, Tk - L, D, D, P.ptr("seg", "G") + D * 4)         # dseg[1] = rows L (, L+1)
             dimg, dtxt, ldd = dy0 + L * D * 4, dy0 + (L + 1) * D * 4, Tk * D
         else:
             # "add" fusion: the projected CLIP rows were broadcast over the sequence -> sum the row gradients
@@ -325,8 +348,9 @@ class Denoiser:
             dimg, dtxt, ldd = _p(ws["dimg"]), _p(ws["dtxt"]), D
         o.gemm(dimg, _p(ws["img_in"]), P.ptr("Wimg", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
         colsum(DIC_F32, dimg, N, D, ldd, P.ptr("bimg", "G"))
-        o.gemm(dtxt, _p(ws["txt_in"]), P.ptr("Wtxt", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
-        colsum(DIC_F32, dtxt, N, D, ldd, P.ptr("btxt", "G"))
+        if mode != 2:      # text row dropped: text_linear's gradient is exactly zero (G was zeroed by zero_grad)
+            o.gemm(dtxt, _p(ws["txt_in"]), P.ptr("Wtxt", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+            colsum(DIC_F32, dtxt, N, D, ldd, P.ptr("btxt", "G"))
 
     # ------------------------------------------------------------------ rounding head: streaming CE / argmax (ref :323, 436-437, 620)
     def rounding(self, xr, M, tgt=None, ce_ws=None, dtype=None):

@@ -61,6 +61,8 @@ typedef struct DicGemmParams {
     float* partial;             /* [M][2*ceil(N/128)][4] (CE_PARTIAL) */
     float* tgt_logit;           /* [M] (CE_PARTIAL) */
     int ce_rows_a; float ce_scale_a, ce_scale_b;
+    int split_k; void* split_ws;/* >1: K is cut into split_k slices (fills the chip when M*N has few tiles -- the dW GEMMs);
+                                   slices write fp32 partial tiles to split_ws [split_k][M][N], then folded into C in fixed order */
 } DicGemmParams;
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
@@ -87,6 +89,8 @@ int dic_qsample(const float* x0, const float* noise, const int64_t* t, const flo
 /* ---------------------------------------------------------------- fusion + embeddings LayerNorm (ref:299-307, hf:113-117)
  * mode 0 "concat": row t<L = x[n][t]; row L = img[n]; row L+1 = txt[n]; + seg[t>=L] + pos[t]; LayerNorm(eps);
  * mode 1 "add":    row t = x[n][t] + img[n] (+ txt[n] when add_txt[n]) + pos[t]; LayerNorm.   Tk = L+2 / L.
+ * mode 2 "concat, text row dropped" (Tk = L+1): legal when no sequence is guided -- the text row is then masked as a key
+ *        and its outputs are unused, so losses and gradients are unchanged.
  * Writes h [N][Tk][D] (dtype T, dropout p applied) and mean/rstd [N*Tk].                                          */
 int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
                     const float* seg, const float* pos, const float* gamma, const float* beta,

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""GEMM microbenchmark on the step's shapes (run on the GPU box): TFLOP/s per (layout, epilogue, shape), v1 vs v2."""
+import ctypes as C
+import importlib
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dic = importlib.import_module("diffusion-image-captioning_amd")
+L = dic.lib()
+GP = dic._lib.GemmParams
+T, D, F, V = 18432, 768, 3072, 30592
+bf = torch.bfloat16
+
+
+def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, **extra):
+    A = torch.randn((K, M) if a_km else (M, K), device="cuda").to(bf)
+    B = torch.randn((K, N) if b_km else (N, K), device="cuda").to(bf)
+    Cc = torch.empty(M, N, device="cuda", dtype=torch.float32 if out_f32 else bf)
+    aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2) else None
+    bias = torch.randn(N, device="cuda") if epi in (0, 1) and not out_f32 else None
+    ws = torch.empty(split * M * N, device="cuda") if split > 1 else None
+    g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N,
+           bias=bias.data_ptr() if bias is not None else 0, aux=aux.data_ptr() if aux is not None else 0, ldaux=N, out_f32=out_f32,
+           split_k=split, split_ws=ws.data_ptr() if ws is not None else 0)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        assert L.dic_gemm(1, a_km, b_km, epi, C.byref(g), st) == 0, L.dic_last_error()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.dic_gemm(1, a_km, b_km, epi, C.byref(g), st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"{name:34s} M={M:6d} N={N:6d} K={K:6d} split={split:2d}  {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    print("DIC_GEMM =", os.environ.get("DIC_GEMM", "3"))
+    run("fwd qkv        (KC,KC) bias", T, 3 * D, D, 0, 0)
+    run("fwd out-proj   (KC,KC) bias", T, D, D, 0, 0)
+    run("fwd ffn1       (KC,KC) gelu", T, F, D, 0, 0, epi=1)
+    run("fwd ffn2       (KC,KC) bias", T, D, F, 0, 0)
+    run("dX  ffn2->du   (KC,KM) gelu'", T, F, D, 0, 1, epi=2)
+    run("dX  ffn1->dsa  (KC,KM)", T, D, F, 0, 1)
+    run("dX  qkv->dh    (KC,KM)", T, D, 3 * D, 0, 1)
+    for sp in (1, 4, 8, 14):
+        run("dW  out-proj   (KM,KM) f32", D, D, T, 1, 1, split=sp, out_f32=1)
+    for sp in (1, 3, 4):
+        run("dW  ffn1       (KM,KM) f32", F, D, T, 1, 1, split=sp, out_f32=1)
+    for sp in (1, 4):
+        run("dW  qkv        (KM,KM) f32", 3 * D, D, T, 1, 1, split=sp, out_f32=1)
+    run("rounding dX    (KC,KM) f32", 16384, D, V, 0, 1, out_f32=1)
+    run("square 4096    (KC,KC)", 4096, 4096, 4096, 0, 0)
+    run("square 8192    (KC,KC)", 8192, 8192, 8192, 0, 0, iters=5)

@@ -100,6 +100,23 @@ def test_gemm_layouts(L, dtype, layout, shape):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("split", [2, 5])
+def test_gemm_split_k_weight_gradient(L, dtype, split):
+    """dW = dY^T X with the contraction (tokens) cut into slices that are folded in a fixed order."""
+    M, N, K = 256, 384, 64 * 23 + 17
+    g = torch.Generator().manual_seed(split)
+    A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    Ad, Bd = dev(A, DT[dtype]), dev(B, DT[dtype])
+    ref = Ad.float().cpu().double().t() @ Bd.float().cpu().double()
+    Cd = torch.full((M, N), 1.0, dtype=torch.float32, device="cuda")
+    ws = torch.full((split * M * N,), float("nan"), device="cuda")
+    gemm(L, dtype, 1, 1, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=M, ldb=N, ldc=N, out_f32=1, split_k=split, split_ws=p(ws))
+    assert relerr(Cd, ref) < 2e-6
+    gemm(L, dtype, 1, 1, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=M, ldb=N, ldc=N, out_f32=1, split_k=split, split_ws=p(ws), accumulate=1)
+    assert relerr(Cd, 2 * ref) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 def test_gemm_f32_is_k_ordered_fmaf_chain_and_affine_epilogue(L, dtype):
     M, N, K = 136, 260, 128
     g = torch.Generator().manual_seed(5)
