@@ -123,8 +123,45 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const ui
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 backward
-__global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
-                                                      int H, float scale, float p_drop, unsigned long long seed) {
+// Every byte of Q, K, V, dO is read from HBM exactly once, straight into MFMA operand registers (16 x 16-byte loads per
+// lane, all issued before the first use): the four score-shaped products S^T = K.Q^T, S = Q.K^T, dP^T = V.dO^T and
+// dP = dO.V^T are the same register fragments with the A/B roles swapped.  K, Q and dO are additionally written from those
+// registers into padded LDS tiles ((Tk+1 rounded up to 4) rows, the last one zero) for the three products that consume
+// them k-major (dQ = dS.K, dK = dS^T.Q, dV = P^T.dO) through ds_read_b64_tr_b16; token rows beyond Tk are redirected to the
+// zero row, so a wave needs 3 x 3.8 KB of LDS at Tk = 18 and three workgroups fit a CU.
+__device__ __forceinline__ bf16x8 tr_frag_clamped(const char* lds, int s, int db, int lane, int zero_row) {
+    const int hi = lane >> 5, half = (lane >> 4) & 1, t = lane & 15;
+    const int r0 = min(16 * s + 4 * hi + (t >> 2), zero_row), r1 = min(16 * s + 8 + 4 * hi + (t >> 2), zero_row);
+    const int col = (db * 32 + half * 16 + 4 * (t & 3)) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + r0 * VSTRIDE + col));
+    s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + r1 * VSTRIDE + col));
+    s16x8 v = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+struct RowFrags { bf16x8 f[4]; };
+__device__ __forceinline__ RowFrags load_rows(const bf16_t* X, int ld, int Tk, int lane) {
+    const int r = lane & 31, hi = lane >> 5;
+    RowFrags o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o.f[s] = ld_frag_global(X + (size_t)r * ld + 16 * s + 8 * hi, r < Tk);
+    return o;
+}
+__device__ __forceinline__ void store_rows(char* tile, const RowFrags& x, int Tk, int lane) {
+    const int r = lane & 31, hi = lane >> 5;
+    if (r <= Tk && r < 32) {                 // row Tk holds zeros (its fragment was loaded as zero): the redirect target
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *(i32x4*)(tile + r * VSTRIDE + 32 * s + 16 * hi) = __builtin_bit_cast(i32x4, x.f[s]);
+    }
+}
+__device__ __forceinline__ f32x16 rowdot_reg(const RowFrags& a, const RowFrags& b) {   // D[i][j] = sum_d a_row_i . b_row_j
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.f[s], b.f[s], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
+                                                      int H, float scale, float p_drop, unsigned long long seed, int tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 4 + wave;
@@ -132,20 +169,22 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const ui
     const int n = pair / H, h = pair - n * H;
     const int ld = 3 * H * DH, Dm = H * DH;
     const bf16_t* Q = qkv + (size_t)n * Tk * ld + h * DH;
-    const bf16_t* K = Q + Dm;
-    const bf16_t* V = Q + 2 * Dm;
     const bf16_t* dO = dctx + (size_t)n * Tk * Dm + h * DH;
     bf16_t* dQ = dqkv + (size_t)n * Tk * ld + h * DH;
     bf16_t* dK = dQ + Dm;
     bf16_t* dV = dQ + 2 * Dm;
-    char* base = smem + wave * (3 * TILE + 512);
+    char* base = smem + wave * (3 * tile_bytes + 512);
     char* kt = base;
-    char* qt = base + TILE;
-    char* dot = base + 2 * TILE;
-    float* stats = (float*)(base + 3 * TILE);       // [0..31] row max, [32..63] 1/rowsum, [64..95] delta
-    stage_tile(kt, K, ld, Tk, lane);
-    stage_tile(qt, Q, ld, Tk, lane);
-    stage_tile(dot, dO, Dm, Tk, lane);
+    char* qt = base + tile_bytes;
+    char* dot = base + 2 * tile_bytes;
+    float* stats = (float*)(base + 3 * tile_bytes);       // [0..31] row max, [32..63] 1/rowsum, [64..95] delta
+    const int zero_row = Tk < 32 ? Tk : 31;
+
+    const RowFrags fq = load_rows(Q, ld, Tk, lane), fk = load_rows(Q + Dm, ld, Tk, lane), fv = load_rows(Q + 2 * Dm, ld, Tk, lane),
+                   fo = load_rows(dO, Dm, Tk, lane);
+    store_rows(kt, fk, Tk, lane);
+    store_rows(qt, fq, Tk, lane);
+    store_rows(dot, fo, Tk, lane);
 
     const int c = lane & 31, hi = lane >> 5;
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -153,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const ui
 
     // ---- pass 1 (query-major): lane = query c, registers = keys.  P, delta, dS -> dQ
     {
-        f32x16 st = rowdot(K, ld, Q, ld, Tk, lane);
+        f32x16 st = rowdot_reg(fk, fq);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -168,8 +207,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const ui
         for (int r = 0; r < 16; ++r) { st[r] = (mx == -INFINITY) ? 0.f : __expf(st[r] - mx); sum += st[r]; }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-        // dPd^T[key][query] = sum_d V[key][d] dO[query][d]
-        f32x16 dpt = rowdot(V, ld, dO, Dm, Tk, lane);
+        f32x16 dpt = rowdot_reg(fv, fo);                                           // dPd^T[key][query]
         float delta = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -183,12 +221,11 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const ui
         for (int r = 0; r < 16; ++r) st[r] = st[r] * (dpt[r] - delta) * scale;      // dS[query][key] (scaled for dQ/dK)
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // dQ[query][d] = sum_key dS[query][key] K[key][d]
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
+        for (int db = 0; db < 2; ++db) {                                            // dQ[query][d] = sum_key dS[query][key] K[key][d]
             f32x16 o = zero16();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(st, s), tr_frag(kt, s, db, lane), o, 0, 0, 0);
+            for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(st, s), tr_frag_clamped(kt, s, db, lane, zero_row), o, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = reg_tok(r, hi);
@@ -196,35 +233,33 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* qkv, const ui
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
     // ---- pass 2 (key-major): lane = key c, registers = queries.  Pd -> dV, dS -> dK
     {
-        f32x16 s2 = rowdot(Q, ld, K, ld, Tk, lane);                               // S[query(reg)][key(lane)]
-        f32x16 dp2 = rowdot(dO, Dm, V, ld, Tk, lane);                             // dPd[query][key] = sum_d dO[query][d] V[key][d]
+        f32x16 s2 = rowdot_reg(fq, fk);                                             // S[query(reg)][key(lane)]
+        f32x16 dp2 = rowdot_reg(fo, fv);                                            // dPd[query][key]
         const bool kok = c < Tk && km[c < Tk ? c : 0] != 0;
         f32x16 pd, ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = reg_tok(r, hi);
             const float m_ = stats[qi], inv = stats[32 + qi], delta = stats[64 + qi];
-            float p = (kok && m_ > -INFINITY) ? __expf(s2[r] * scale - m_) * inv : 0.f;
-            float dpr = dp2[r], pdr = p;
+            float pr = (kok && m_ > -INFINITY) ? __expf(s2[r] * scale - m_) * inv : 0.f;
+            float dpr = dp2[r], pdr = pr;
             if (p_drop > 0.f) {
                 const unsigned long long idx = ((unsigned long long)pair * Tk + qi) * Tk + c;
                 dpr = dropout1(dpr, seed, idx, p_drop, inv_keep);
-                pdr = dropout1(p, seed, idx, p_drop, inv_keep);
+                pdr = dropout1(pr, seed, idx, p_drop, inv_keep);
             }
             pd[r] = pdr;
-            ds[r] = p * (dpr - delta) * scale;
+            ds[r] = pr * (dpr - delta) * scale;
         }
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
             f32x16 ov = zero16(), ok_ = zero16();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                ov = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pd, s), tr_frag(dot, s, db, lane), ov, 0, 0, 0);
-                ok_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ds, s), tr_frag(qt, s, db, lane), ok_, 0, 0, 0);
+                ov = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pd, s), tr_frag_clamped(dot, s, db, lane, zero_row), ov, 0, 0, 0);
+                ok_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ds, s), tr_frag_clamped(qt, s, db, lane, zero_row), ok_, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -378,10 +413,12 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DIC_BF16) {
         DIC_REQUIRE(Tk <= 32, "dic_attn (bf16 MFMA path): at most 32 tokens per sequence");
-        size_t lds = 4 * (3 * TILE + 512);
+        const int rows = Tk < 32 ? ((Tk + 1 + 3) & ~3) : 32;          // valid rows + one zero row
+        const int tile_bytes = rows * VSTRIDE;
+        size_t lds = 4 * (size_t)(3 * tile_bytes + 512);
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL(attn_bwd_bf16, dim3((N * H + 3) / 4), dim3(256), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * TILE + 512)); attr = true; }
+        hipLaunchKernelGGL(attn_bwd_bf16, dim3((N * H + 3) / 4), dim3(256), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
     } else {
         DIC_REQUIRE(Tk <= TMAX, "dic_attn (f32 path): at most 64 tokens per sequence");
         size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);

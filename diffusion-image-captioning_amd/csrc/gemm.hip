@@ -103,11 +103,13 @@ __device__ __forceinline__ float row_scale(const DicGemmParams& p, int m) { retu
 // ---- block -> (tile, K-slice) ----------------------------------------------------------------------
 // XCD-aware order: consecutive logical ids (same A row-panel, then the K-slices of one tile) share one XCD's L2.
 struct TileId { int bm, bn, nbn, kz, kt0, kt1; };
-__device__ __forceinline__ TileId tile_of_block(const DicGemmParams& p, int BK) {
+__device__ __forceinline__ int total_units(const DicGemmParams& p) {
+    return ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * (p.split_k > 1 ? p.split_k : 1);
+}
+__device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, int pid) {
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     const int split = p.split_k > 1 ? p.split_k : 1;
     const int nwg = nbm * nbn * split;
-    int pid = blockIdx.x;
     {
         int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, slot = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
@@ -121,6 +123,7 @@ __device__ __forceinline__ TileId tile_of_block(const DicGemmParams& p, int BK) 
     t.kt1 = min(nk, t.kt0 + per);
     return t;
 }
+__device__ __forceinline__ TileId tile_of_block(const DicGemmParams& p, int BK) { return tile_of_unit(p, BK, blockIdx.x); }
 // split-K: slice kz writes its plain fp32 partial tile into slab kz of the workspace; dic_gemm folds the slabs after.
 __device__ __forceinline__ void redirect_to_slab(DicGemmParams& p, int kz) {
     p.C = (float*)p.split_ws + (size_t)kz * p.M * p.ldc;
@@ -321,6 +324,102 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {   // v1:
     epilogue<T, EPI>(acc, p, m0, n0, wm, wn, lane, bn, nbn);
 }
 
+// ---- LDS-staged epilogue of the bf16 kernel -------------------------------------------------------------------------
+// The MFMA accumulator layout gives a lane 4 consecutive n of ONE row, so direct stores are 16 rows x 32-byte fragments
+// per wave-instruction -- store-ISSUE-bound: a K=64 GEMM of 510 tiles took 13 us, almost all of it this tail.  Instead the
+// 128x128 fp32 tile is parked in the (now idle) 64 KB of LDS, XOR-swizzled so both the scattered 16-byte writes and the
+// row-wise 16-byte reads are bank-conflict-free, and written out row-contiguously: each thread handles 8 consecutive n,
+// 16 threads cover a 256-byte output row, a wave-instruction writes 4 full rows.  Residual / pre-activation side inputs are
+// read with the same fully coalesced pattern, and each thread's 8 columns are fixed, so its bias slice is loaded once.
+__device__ __forceinline__ int ctile_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
+
+__device__ __forceinline__ void unpack8(i32x4 r, f32x4& a, f32x4& b) {
+    a[0] = __uint_as_float((unsigned)r[0] << 16); a[1] = __uint_as_float((unsigned)r[0] & 0xffff0000u);
+    a[2] = __uint_as_float((unsigned)r[1] << 16); a[3] = __uint_as_float((unsigned)r[1] & 0xffff0000u);
+    b[0] = __uint_as_float((unsigned)r[2] << 16); b[1] = __uint_as_float((unsigned)r[2] & 0xffff0000u);
+    b[2] = __uint_as_float((unsigned)r[3] << 16); b[3] = __uint_as_float((unsigned)r[3] & 0xffff0000u);
+}
+__device__ __forceinline__ i32x4 pack8f(const f32x4& a, const f32x4& b) {
+    i32x4 r;
+    r[0] = (int)((unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16)); r[1] = (int)((unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16));
+    r[2] = (int)((unsigned)f2bf(b[0]) | ((unsigned)f2bf(b[1]) << 16)); r[3] = (int)((unsigned)f2bf(b[2]) | ((unsigned)f2bf(b[3]) << 16));
+    return r;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const DicGemmParams& p, int m0, int n0, int wm, int wn, int lane, int tid, char* smem) {
+    using T = bf16_t;
+    const int g = lane >> 4, t = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *(f32x4*)(smem + ctile_off(wm * 64 + i * 16 + t, wn * 16 + j * 4 + g)) = acc[i][j];
+    __syncthreads();
+    const int c8 = tid & 15;                       // this thread's 8 columns are the same for every row it handles
+    const int n = n0 + c8 * 8;
+    const bool v0ok = n < p.N, v1ok = n + 4 < p.N;
+    f32x4 b0{0.f, 0.f, 0.f, 0.f}, b1{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU) {
+        if (p.bias) { if (v0ok) b0 = *(const f32x4*)(p.bias + n); if (v1ok) b1 = *(const f32x4*)(p.bias + n + 4); }
+    }
+    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+#pragma unroll 2
+    for (int k = 0; k < 8; ++k) {
+        const int row = (tid >> 4) + 16 * k, m = m0 + row;
+        if (m >= p.M) continue;
+        f32x4 x0 = *(const f32x4*)(smem + ctile_off(row, 2 * c8)), x1 = *(const f32x4*)(smem + ctile_off(row, 2 * c8 + 1));
+        if constexpr (EPI == DIC_EPI_AFFINE) {
+            if (!v0ok) continue;
+            x0 += b0; x1 += b1;
+            if (p.p_drop > 0.f) {
+                x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
+                x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + n + 4, p.p_drop, inv_keep);
+            }
+            if (p.R) {
+                const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
+                if (v1ok) { f32x4 r0, r1; unpack8(*(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
+                else x0 += Elem<T>::ld4(rp);
+            }
+            if (p.out_f32) {
+                float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                if (p.accumulate) { x0 += *(const f32x4*)c; if (v1ok) x1 += *(const f32x4*)(c + 4); }
+                *(f32x4*)c = x0;
+                if (v1ok) *(f32x4*)(c + 4) = x1;
+            } else {
+                T* c = (T*)p.C + (size_t)m * p.ldc + n;
+                if (v1ok) *(i32x4*)c = pack8f(x0, x1); else Elem<T>::st4(c, x0);
+            }
+        } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {
+            if (!v1ok) continue;                                   // N % 8 == 0 is required for this epilogue
+            x0 += b0; x1 += b1;
+            *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + n) = pack8f(x0, x1);     // pre-activation u (for GELU')
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
+            *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+        } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
+            if (!v1ok) continue;
+            f32x4 u0, u1;
+            unpack8(*(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n), u0, u1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
+            *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+        } else {   // DIC_EPI_CE_DLOGITS: (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
+            if (n >= p.ldc) continue;
+            const float lse = p.lse[m], sc = row_scale(p, m);
+            const long long tg = p.tgt[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
+                if ((long long)(n + r) == tg) q0 -= 1.0f;
+                if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
+                x0[r] = q0 * sc; x1[r] = q1 * sc;
+            }
+            *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+        }
+    }
+}
+
 // =====================================================================================================
 // bf16 kernel: operand tiles go HBM/L2 -> LDS directly with `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging VGPRs and
 // no ds_write pass (the register-staged v1 spent ~830 of every ~1340 LDS cycles per K-step on ds_write_b128); the next
@@ -347,36 +446,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, t = lane & 15;
-    TileId tl = tile_of_block(p, BK);
-    const int bm = tl.bm, bn = tl.bn, nbn = tl.nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
-    if (p.split_k > 1) redirect_to_slab(p, tl.kz);
 
-    const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
-    const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
-    long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
-    long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
-    if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
-    if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
-
-    const int kt0 = tl.kt0, nk = tl.kt1;
-    // ---- per-lane DMA source offsets of the 4 x 1 KiB pieces this wave stages per operand; they advance by a uniform step.
-    // (kept in VGPRs rather than the scalar offset operand: the descriptor's bounds check covers only the vector offset, and
-    //  it is that check which zero-fills ragged M/N/K)
-    unsigned voA[4], voB[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = wave * 4 + j;
-        if (!AKM) { const int row = 8 * q + (lane >> 3); voA[j] = ((unsigned)row * (unsigned)p.lda + (unsigned)(kt0 * BK)) * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
-        else      { const int row = 4 * q + (lane >> 4); voA[j] = ((unsigned)(kt0 * BK + row) * (unsigned)p.lda) * 2u + (((lane & 15) ^ km_key(row)) << 4); }
-        if (!BKM) { const int row = 8 * q + (lane >> 3); voB[j] = ((unsigned)row * (unsigned)p.ldb + (unsigned)(kt0 * BK)) * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
-        else      { const int row = 4 * q + (lane >> 4); voB[j] = ((unsigned)(kt0 * BK + row) * (unsigned)p.ldb) * 2u + (((lane & 15) ^ km_key(row)) << 4); }
-    }
-    const unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;
-    const unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
-    // ---- per-lane fragment addresses inside an operand tile
+    // ---- per-lane fragment addresses inside an operand tile (same for every tile this workgroup processes)
     int ofA[4][2], ofB[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -387,13 +458,37 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
             if (!BKM) { const int row = wn * 64 + i * 16 + t; ofB[i][kk] = row * 128 + (((kk * 4 + g) ^ kc_key(row)) << 4); }
             else { const int rho = kk * 32 + 8 * g + (t >> 2), c = ((wn * 64 + i * 16) >> 3) + ((t & 3) >> 1); ofB[i][kk] = rho * 256 + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
         }
-
-    f32x4 acc[4][4];
+    // ---- per-lane DMA source offsets of the 4 x 1 KiB pieces this wave stages per operand, relative to the tile origin at
+    // k = 0; they advance by a uniform step.  (Kept in VGPRs rather than the scalar offset operand: the descriptor's bounds
+    // check covers only the vector offset, and it is that check which zero-fills ragged M/N/K.)
+    unsigned baseA[4], baseB[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+        const int q = wave * 4 + j;
+        if (!AKM) { const int row = 8 * q + (lane >> 3); baseA[j] = (unsigned)row * (unsigned)p.lda * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+        else      { const int row = 4 * q + (lane >> 4); baseA[j] = (unsigned)row * (unsigned)p.lda * 2u + (((lane & 15) ^ km_key(row)) << 4); }
+        if (!BKM) { const int row = 8 * q + (lane >> 3); baseB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+        else      { const int row = 4 * q + (lane >> 4); baseB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 15) ^ km_key(row)) << 4); }
+    }
+    const unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;
+    const unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
 
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned voA[4], voB[4];
+    auto setup = [&](const TileId& tl) {          // descriptors anchored at the tile origin: OOB rows/k read as zero
+        const int m0 = tl.bm * BM, n0 = tl.bn * BN;
+        const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
+        const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
+        long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
+        long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
+        if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
+        if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
+        const unsigned ka = (unsigned)tl.kt0 * stepA, kb = (unsigned)tl.kt0 * stepB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { voA[j] = baseA[j] + ka; voB[j] = baseB[j] + kb; }
+    };
     auto issue = [&](int stage) {
         char* dst = smem + stage * DMA_STAGE + wave * 4096;
 #pragma unroll
@@ -414,6 +509,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
         s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     };
+    f32x4 acc[4][4];
     auto compute = [&](int stage) {
         const char* la = smem + stage * DMA_STAGE;
         const char* lb = la + DMA_TILE;
@@ -432,20 +528,43 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
         }
     };
 
-    int kt = kt0;
-    if (kt < nk) issue(0);
+    // ---- persistent loop over (tile, K-slice) units: the grid is capped at two workgroups per CU, so addressing set-up is
+    // paid once per workgroup and the tail of the launch is balanced by unit order rather than by dispatch order.
+    const int total = total_units(p);
+    int unit = blockIdx.x;
+    TileId tl = tile_of_unit(p, BK, unit);
+    setup(tl);
+    if (tl.kt0 < tl.kt1) issue(0);
     __syncthreads();                     // (the compiler drains the LDS-DMA with vmcnt(0) ahead of the barrier)
-    while (kt < nk) {
-        if (kt + 1 < nk) issue(1);       // next tile's DMA flies under this tile's MFMAs
-        compute(0);
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int kt = tl.kt0;
+        const int nk = tl.kt1;
+        while (kt < nk) {
+            if (kt + 1 < nk) issue(1);   // next K-step's DMA flies under this step's MFMAs
+            compute(0);
+            __syncthreads();
+            if (++kt >= nk) break;
+            if (kt + 1 < nk) issue(0);
+            compute(1);
+            __syncthreads();
+            ++kt;
+        }
+        DicGemmParams pe = p;
+        if (p.split_k > 1) redirect_to_slab(pe, tl.kz);
+        if constexpr (EPI == DIC_EPI_CE_PARTIAL) epilogue<T, EPI>(acc, pe, tl.bm * BM, tl.bn * BN, wm, wn, lane, tl.bn, tl.nbn);
+        else epilogue_lds<EPI>(acc, pe, tl.bm * BM, tl.bn * BN, wm, wn, lane, tid, smem);
+        unit += gridDim.x;
+        if (unit >= total) break;
+        tl = tile_of_unit(p, BK, unit);
+        setup(tl);
+        __syncthreads();                 // every wave is done with the LDS-staged output tile
+        if (tl.kt0 < tl.kt1) issue(0);
         __syncthreads();
-        if (++kt >= nk) break;
-        if (kt + 1 < nk) issue(0);
-        compute(1);
-        __syncthreads();
-        ++kt;
     }
-    epilogue<T, EPI>(acc, p, m0, n0, wm, wn, lane, bn, nbn);
 }
 
 // fold split-K slabs: out[i] (+)= sum_s ws[s][i]   (fixed order => deterministic)
@@ -475,7 +594,17 @@ void launch_one(dim3 grid, hipStream_t st, const DicGemmParams& q) {
                 (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_set = true;
             }
-            hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, E>), grid, dim3(NT), lds, st, q);
+            static int cap = -1;                           // persistent grid: two workgroups per CU (DIC_GEMM_PERSIST=0: one unit per block)
+            if (cap < 0) {
+                const char* e = getenv("DIC_GEMM_PERSIST");
+                int cus = 256;
+                hipDeviceProp_t prop;
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+                cap = (e && e[0] == '0') ? 0x7fffffff : 2 * cus;
+            }
+            dim3 pgrid((int)grid.x < cap ? grid.x : cap);
+            hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, E>), pgrid, dim3(NT), lds, st, q);
             return;
         }
     }
@@ -571,6 +700,9 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (b_km) DIC_REQUIRE((long long)p.K * p.ldb * es < 0x7FFFFFFFll, "dic_gemm: k-major B too large for 32-bit buffer offsets");
     if (!a_km) DIC_REQUIRE((long long)BM * p.lda * es < 0x7FFFFFFFll, "dic_gemm: lda too large");
     if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
+    if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD))
+        DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && p.ldaux % 8 == 0, "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
+    if (dtype == DIC_BF16) DIC_REQUIRE(p.ldc % 4 == 0 && (p.R == nullptr || p.ldr % 4 == 0), "dic_gemm: ldc/ldr must be multiples of 4");
     if (p.split_k > 1)
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*M*N floats");

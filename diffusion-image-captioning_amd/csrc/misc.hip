@@ -287,8 +287,17 @@ __global__ __launch_bounds__(256) void colsum_small(const float* in, int rows, i
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
     f32x4 acc{0.f, 0.f, 0.f, 0.f};
-    if (c < cols)
-        for (int r = w; r < rows; r += 4) acc += *(const f32x4*)(in + (size_t)r * ld + c);
+    if (c < cols) {
+        int r = w;
+        for (; r + 28 < rows; r += 32) {               // 8 independent 16-byte loads in flight per lane (latency-bound otherwise)
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(in + (size_t)(r + 4 * u) * ld + c);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < rows; r += 4) acc += *(const f32x4*)(in + (size_t)r * ld + c);
+    }
     red[w][lane] = acc;
     __syncthreads();
     if (w == 0 && c < cols) {

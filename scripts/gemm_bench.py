@@ -38,7 +38,7 @@ def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, **extra)
     print(f"{name:34s} M={M:6d} N={N:6d} K={K:6d} split={split:2d}  {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     print("DIC_GEMM =", os.environ.get("DIC_GEMM", "3"))
     run("fwd qkv        (KC,KC) bias", T, 3 * D, D, 0, 0)
     run("fwd out-proj   (KC,KC) bias", T, D, D, 0, 0)
@@ -56,3 +56,17 @@ if __name__ == "__main__":
     run("rounding dX    (KC,KM) f32", 16384, D, V, 0, 1, out_f32=1)
     run("square 4096    (KC,KC)", 4096, 4096, 4096, 0, 0)
     run("square 8192    (KC,KC)", 8192, 8192, 8192, 0, 0, iters=5)
+
+
+def sweep():
+    print("--- K sweep (KC,KC) bias epilogue, N=768")
+    for M in (128 * 85, 18432):
+        for K in (64, 256, 768, 1536, 3072, 6144):
+            run(f"M={M} K sweep", M, 768, K, 0, 0)
+    print("--- N=3072")
+    for K in (64, 768, 3072):
+        run("N=3072 K sweep", 18432, 3072, K, 0, 0)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    sweep()
