@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const ui
     for (int r = 0; r < 16; ++r) { st[r] = (mx == -INFINITY) ? 0.f : __expf(st[r] - mx); sum += st[r]; }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         st[r] *= inv;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
     store_rows(dot, fo, Tk, lane);
 
     const int c = lane & 31, hi = lane >> 5;
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
     const uint8_t* km = key_mask + (size_t)n * Tk;
 
     // ---- pass 1 (query-major): lane = query c, registers = keys.  P, delta, dS -> dQ
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void attn_fwd_f32(const float* qkv, const uint8
         p[i * PW + j] = key_mask[(size_t)n * Tk + j] ? s * scale : -INFINITY;
     }
     __syncthreads();
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
     for (int i = lane; i < Tk; i += 64) {
         float mx = -INFINITY;
         for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, p[i * PW + j]);
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64) void attn_bwd_f32(const float* qkv, const uint8
         ds[i * PW + j] = g;
     }
     __syncthreads();
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
     for (int i = lane; i < Tk; i += 64) {
         float mx = -INFINITY;
         for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, p[i * PW + j]);

@@ -100,25 +100,43 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
     }
     return ctr;
 }
-// keep-mask for 4 consecutive elements starting at element index e4*4 (one Philox call per 4 elements)
 __device__ __forceinline__ uint4 rng4(unsigned long long seed, unsigned long long e4) {
     return philox4x32(make_uint4((unsigned)e4, (unsigned)(e4 >> 32), 0x0d1c5eedu, 0u),
                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// ---- dropout keep-masks ----------------------------------------------------------------------------------
+// Philox (above) is kept for the Gaussian noise of q_sample, drawn once per step.  Dropout decisions are drawn ~10^9 times
+// per step inside GEMM epilogues, LayerNorm and attention kernels, where ten Philox rounds (40 quarter-rate integer multiplies
+// per 4 elements) made HBM-bound kernels ALU-bound; they use a 2-multiply avalanche hash (lowbias32, bias 0.17) of
+// (seed, element pair): one 32-bit hash decides two consecutive elements with 16-bit thresholds, so the drop probability is
+// p rounded to 1/65536 (0.1 -> 0.100006) and the rescale uses that exact value.  Backward kernels regenerate the same mask
+// from the same (seed, index).
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned pair_hash(unsigned long long seed, unsigned long long pair) {
+    const unsigned hi = (unsigned)(pair >> 32) * 0x9E3779B9u + (unsigned)(seed >> 32);
+    return hash32((unsigned)pair ^ (unsigned)seed ^ hash32(hi));
+}
+__device__ __forceinline__ unsigned drop_thr(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ float drop_inv_keep(float p) { return p > 0.f ? 65536.0f / (65536.0f - (float)drop_thr(p)) : 1.0f; }
 // dropout on 4 consecutive values whose flat index starts at idx (idx % 4 == 0)
 __device__ __forceinline__ f32x4 dropout4(f32x4 v, unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-    uint4 r = rng4(seed, idx >> 2);
-    v[0] = (u01(r.x) >= p) ? v[0] * inv_keep : 0.f;
-    v[1] = (u01(r.y) >= p) ? v[1] * inv_keep : 0.f;
-    v[2] = (u01(r.z) >= p) ? v[2] * inv_keep : 0.f;
-    v[3] = (u01(r.w) >= p) ? v[3] * inv_keep : 0.f;
+    const unsigned thr = drop_thr(p);
+    const unsigned h0 = pair_hash(seed, idx >> 1), h1 = pair_hash(seed, (idx >> 1) + 1);
+    v[0] = ((h0 & 0xffffu) >= thr) ? v[0] * inv_keep : 0.f;
+    v[1] = ((h0 >> 16) >= thr) ? v[1] * inv_keep : 0.f;
+    v[2] = ((h1 & 0xffffu) >= thr) ? v[2] * inv_keep : 0.f;
+    v[3] = ((h1 >> 16) >= thr) ? v[3] * inv_keep : 0.f;
     return v;
 }
 __device__ __forceinline__ float dropout1(float v, unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-    uint4 r = rng4(seed, idx >> 2);
-    unsigned w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
-    return (u01(w) >= p) ? v * inv_keep : 0.f;
+    const unsigned h = pair_hash(seed, idx >> 1);
+    const unsigned w = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+    return (w >= drop_thr(p)) ? v * inv_keep : 0.f;
 }
 
 // ---- error plumbing for the C-ABI ----------------------------------------------------------------

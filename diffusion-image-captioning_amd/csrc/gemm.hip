@@ -125,8 +125,9 @@ __device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, i
 }
 __device__ __forceinline__ TileId tile_of_block(const DicGemmParams& p, int BK) { return tile_of_unit(p, BK, blockIdx.x); }
 // split-K: slice kz writes its plain fp32 partial tile into slab kz of the workspace; dic_gemm folds the slabs after.
+__device__ __forceinline__ size_t slab_stride(const DicGemmParams& p) { return (size_t)p.M * p.ldc + (p.colsum_out ? p.M : 0); }
 __device__ __forceinline__ void redirect_to_slab(DicGemmParams& p, int kz) {
-    p.C = (float*)p.split_ws + (size_t)kz * p.M * p.ldc;
+    p.C = (float*)p.split_ws + (size_t)kz * slab_stride(p);
     p.bias = nullptr; p.R = nullptr; p.p_drop = 0.f; p.out_f32 = 1; p.accumulate = 0;
 }
 
@@ -136,7 +137,7 @@ template <typename T, int EPI>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const DicGemmParams& p, int m0, int n0, int wm, int wn, int lane, int bn, int nbn) {
     const int g = lane >> 4, t = lane & 15;
     if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_GELU_BWD) {
-        const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+        const float inv_keep = drop_inv_keep(p.p_drop);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 64 + i * 16 + t;
@@ -363,7 +364,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const DicGemmPa
     if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU) {
         if (p.bias) { if (v0ok) b0 = *(const f32x4*)(p.bias + n); if (v1ok) b1 = *(const f32x4*)(p.bias + n + 4); }
     }
-    const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+    const float inv_keep = drop_inv_keep(p.p_drop);
 #pragma unroll 2
     for (int k = 0; k < 8; ++k) {
         const int row = (tid >> 4) + 16 * k, m = m0 + row;
@@ -510,9 +511,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
         return __builtin_bit_cast(bf16x8, v);
     };
     f32x4 acc[4][4];
+    // fused bias gradient (weight-gradient GEMMs only): db[m] = sum_k A[k][m] is a column sum of the A tile that is already
+    // in LDS; the workgroups of the first tile column (bn == 0) add it up on the side (4 x ds_read_b128 + 32 adds per thread
+    // per K-step) instead of a separate pass that re-reads dY from HBM.
+    bool do_cs = false;
+    f32x4 cs0{0.f, 0.f, 0.f, 0.f}, cs1{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int stage) {
         const char* la = smem + stage * DMA_STAGE;
         const char* lb = la + DMA_TILE;
+        if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
+            if (do_cs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = (tid >> 4) + 16 * r;
+                    f32x4 a, b;
+                    unpack8(*(const i32x4*)(la + rho * 256 + (((tid & 15) ^ km_key(rho)) << 4)), a, b);
+                    cs0 += a; cs1 += b;
+                }
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[4], fb[4];
@@ -541,6 +558,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
+            do_cs = p.colsum_out != nullptr && tl.bn == 0;
+            cs0 = f32x4{0.f, 0.f, 0.f, 0.f}; cs1 = cs0;
+        }
         int kt = tl.kt0;
         const int nk = tl.kt1;
         while (kt < nk) {
@@ -555,6 +576,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
         }
         DicGemmParams pe = p;
         if (p.split_k > 1) redirect_to_slab(pe, tl.kz);
+        if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
+            if (do_cs) {       // fold the 16 row-groups through LDS (free after the K loop's last barrier), fixed order
+                float* red = (float*)smem;
+                *(f32x4*)(red + (tid >> 4) * 128 + (tid & 15) * 8) = cs0;
+                *(f32x4*)(red + (tid >> 4) * 128 + (tid & 15) * 8 + 4) = cs1;
+                __syncthreads();
+                if (tid < 128) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int gq = 0; gq < 16; ++gq) v += red[gq * 128 + tid];
+                    const int m = tl.bm * BM + tid;
+                    if (m < p.M) {
+                        if (p.split_k > 1) ((float*)pe.C)[(size_t)p.M * p.ldc + m] = v;
+                        else p.colsum_out[m] = p.accumulate ? p.colsum_out[m] + v : v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) epilogue<T, EPI>(acc, pe, tl.bm * BM, tl.bn * BN, wm, wn, lane, tl.bn, tl.nbn);
         else epilogue_lds<EPI>(acc, pe, tl.bm * BM, tl.bn * BN, wm, wn, lane, tid, smem);
         unit += gridDim.x;
@@ -567,13 +607,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
     }
 }
 
-// fold split-K slabs: out[i] (+)= sum_s ws[s][i]   (fixed order => deterministic)
-__global__ void reduce_slabs_kernel(const float* ws, int nslab, long long n4, float* out, int accumulate) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+// fold split-K slabs: out[i] (+)= sum_s ws[s][i]   (fixed order => deterministic); the optional tail of each slab holds the
+// fused bias-gradient partial and goes to cs_out
+__global__ void reduce_slabs_kernel(const float* ws, int nslab, long long n4, long long stride4, float* out, int accumulate,
+                                    float* cs_out, long long n4_cs) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4 + n4_cs; i += (long long)gridDim.x * blockDim.x) {
         f32x4 a = ((const f32x4*)ws)[i];
-        for (int s = 1; s < nslab; ++s) a += ((const f32x4*)ws)[(size_t)s * n4 + i];
-        if (accumulate) a += ((const f32x4*)out)[i];
-        ((f32x4*)out)[i] = a;
+        for (int s = 1; s < nslab; ++s) a += ((const f32x4*)ws)[(size_t)s * stride4 + i];
+        f32x4* dst = i < n4 ? (f32x4*)out + i : (f32x4*)cs_out + (i - n4);
+        if (accumulate) a += *dst;
+        *dst = a;
     }
 }
 
@@ -631,10 +674,11 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
         default: dic_set_error("dic_gemm: unknown epilogue"); return 1002;
     }
     if (split > 1) {
-        const long long n4 = (long long)p.M * p.ldc / 4;
-        int g = (int)((n4 + 255) / 256);
+        const long long n4 = (long long)p.M * p.ldc / 4, n4cs = p.colsum_out ? p.M / 4 : 0;
+        int g = (int)((n4 + n4cs + 255) / 256);
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(g), dim3(256), 0, st, (const float*)p.split_ws, split, n4, (float*)p.C, p.accumulate);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(g), dim3(256), 0, st, (const float*)p.split_ws, split, n4, n4 + n4cs, (float*)p.C, p.accumulate,
+                           p.colsum_out, n4cs);
     }
     DIC_CHECK_LAUNCH();
     return 0;
@@ -703,9 +747,12 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD))
         DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && p.ldaux % 8 == 0, "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
     if (dtype == DIC_BF16) DIC_REQUIRE(p.ldc % 4 == 0 && (p.R == nullptr || p.ldr % 4 == 0), "dic_gemm: ldc/ldr must be multiples of 4");
+    if (p.colsum_out)
+        DIC_REQUIRE(dtype == DIC_BF16 && a_km && b_km && epi == DIC_EPI_AFFINE && p.out_f32 && p.M % 4 == 0,
+                    "dic_gemm: colsum_out (fused bias gradient) is available on bf16 weight-gradient GEMMs (k-major A and B, fp32 output)");
     if (p.split_k > 1)
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
-                    "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*M*N floats");
+                    "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
     if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % 4 == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DIC_BF16) return launch_layout<bf16_t>(p, a_km, b_km, epi, st);

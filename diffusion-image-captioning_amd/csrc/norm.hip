@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float*
     f32x4 g[NCH], b[NCH];
     load_row<float>(gamma, lane, g);
     load_row<float>(beta, lane, b);
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void fuse_ln_bwd_kernel(int mode, const float*
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH], d[NCH];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dh, const T* y, co
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const float inv_keep = drop_inv_keep(p_drop);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         f32x4 v[NCH], d[NCH];
         load_row<T>(y + (size_t)row * D, lane, v);

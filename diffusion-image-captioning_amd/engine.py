@@ -43,7 +43,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -51,7 +51,7 @@ class Ops:
         g.p_drop, g.seed, g.out_f32, g.accumulate = p_drop, seed, out_f32, accumulate
         g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
         g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
-        g.split_k, g.split_ws = split_k, split_ws
+        g.split_k, g.split_ws, g.colsum_out = split_k, split_ws, colsum_out
         _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
 
 
@@ -287,12 +287,16 @@ class Denoiser:
         skw = _p(ws["splitk"])
         skcap = ws["splitk"].numel()
 
-        def wgrad(dY, X, slot, M, N, lda, ldb):
-            """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip."""
+        def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
+            """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
+            bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum)."""
             sk = pick_split_k(M, N, T, 64 if self.bf16 else 32)
-            while sk > 1 and sk * M * N > skcap:
+            while sk > 1 and sk * (M * N + M) > skcap:
                 sk -= 1
-            o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0)
+            cs = P.ptr(bias_slot, "G") if (bias_slot is not None and self.bf16) else 0
+            o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0, colsum_out=cs)
+            if bias_slot is not None and not self.bf16:
+                colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
 
         def colsum(in_dtype, src, rows, cols, ld, dst, acc=0):
             _lib.check(lib.dic_colsum(in_dtype, src, rows, cols, ld, dst, acc, csw, st), "colsum")
@@ -314,8 +318,7 @@ class Denoiser:
             dyd = ws["dyd"] if use_drop else ws["dy"]
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(ws["du"]), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
-            colsum(self.dt, _p(ws["du"]), T, Hd, Hd, P.ptr(pre + "b1", "G"))                  # db1
-            wgrad(_p(ws["du"]), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D)
+            wgrad(_p(ws["du"]), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                           # dW1 (+ db1)
             o.gemm(_p(ws["du"]), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(ws["dy"]), ldr=D)  # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(ws["dy1"]),
@@ -325,8 +328,7 @@ class Denoiser:
             o.gemm(_p(ws["dy1"]), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
             _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(ws["dqkv"]), N, Tk, self.n_heads, 64, pa,
                                         seed + 4 * i + 1, st), "attn_bwd")
-            colsum(self.dt, _p(ws["dqkv"]), T, 3 * D, 3 * D, P.ptr(pre + "bqkv", "G"))        # dbqkv
-            wgrad(_p(ws["dqkv"]), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D)
+            wgrad(_p(ws["dqkv"]), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D, bias_slot=pre + "bqkv")                      # dWqkv (+ dbqkv)
             o.gemm(_p(ws["dqkv"]), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(ws["dy1"]), ldr=D)
             dH, dHn = dHn, dH
         # embeddings LayerNorm + fusion backward
@@ -371,9 +373,13 @@ class Denoiser:
         o.begin()
         if cw["dlogits"] is None:
             cw["dlogits"] = torch.empty(M, self.vpad, dtype=self.tdtype, device=self.device)
+        ws_split = self._saved["splitk"]
         o.gemm(_p(cw["xr"]), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_DLOGITS,
                tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b)
-        o.gemm(_p(cw["dlogits"]), _p(self.W_lm_c), _p(cw["dxr"]), M, 768, self.vpad, self.vpad, 768, 768, b_km=1, out_f32=1)
+        # 128 x 6 = 768 output tiles on 512 resident workgroups is 1.5 rounds: cut the 30592-deep contraction in two
+        sk = 2 if (M * 768 * 2 <= ws_split.numel() and M >= 2048) else 1
+        o.gemm(_p(cw["dlogits"]), _p(self.W_lm_c), _p(cw["dxr"]), M, 768, self.vpad, self.vpad, 768, 768, b_km=1, out_f32=1,
+               split_k=sk, split_ws=_p(ws_split) if sk > 1 else 0)
         return cw["dxr"]
 
     # ------------------------------------------------------------------ reference forward (ref :271-323)

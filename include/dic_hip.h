@@ -62,7 +62,9 @@ typedef struct DicGemmParams {
     float* tgt_logit;           /* [M] (CE_PARTIAL) */
     int ce_rows_a; float ce_scale_a, ce_scale_b;
     int split_k; void* split_ws;/* >1: K is cut into split_k slices (fills the chip when M*N has few tiles -- the dW GEMMs);
-                                   slices write fp32 partial tiles to split_ws [split_k][M][N], then folded into C in fixed order */
+                                   slices write fp32 partial tiles to split_ws [split_k][M*N (+M)], then folded into C in fixed order */
+    float* colsum_out;          /* bf16 (k-major,k-major) fp32-output GEMMs only: out[m] = sum_k A(m,k) -- the bias gradient that
+                                   goes with a weight gradient dW = dY^T X (hf nn.Linear backward), taken from the LDS-resident A tile */
 } DicGemmParams;
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);

@@ -116,6 +116,22 @@ def test_gemm_split_k_weight_gradient(L, dtype, split):
     assert relerr(Cd, 2 * ref) < 2e-6
 
 
+@pytest.mark.parametrize("split", [1, 3])
+def test_gemm_fused_bias_gradient(L, split):
+    """bf16 weight-gradient GEMM also returns colsum(dY) (the bias gradient) from the LDS-resident A tiles."""
+    M, N, K = 384, 256, 64 * 11 + 5
+    g = torch.Generator().manual_seed(40 + split)
+    A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    Ad, Bd = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    Cd = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    cs = torch.full((M,), float("nan"), device="cuda")
+    ws = torch.zeros(split * (M * N + M), device="cuda")
+    gemm(L, BF16, 1, 1, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=M, ldb=N, ldc=N, out_f32=1, split_k=split, split_ws=p(ws),
+         colsum_out=p(cs))
+    assert relerr(Cd, Ad.float().cpu().double().t() @ Bd.float().cpu().double()) < 2e-6
+    assert relerr(cs, Ad.float().cpu().double().sum(0)) < 2e-6
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_gemm_f32_is_k_ordered_fmaf_chain_and_affine_epilogue(L, dtype):
     M, N, K = 136, 260, 128
