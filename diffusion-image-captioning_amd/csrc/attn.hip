@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
 
 // ------------------------------------------------------------------------------------------------ f32 VALU path
 constexpr int TMAX = 64, PADW = 65;
-__global__ __launch_bounds__(64) void attn_fwd_f32(const float* qkv, const uint8_t* key_mask, float* ctx, int N, int Tk, int H, float scale,
+template <typename T>
+__global__ __launch_bounds__(64) void attn_fwd_f32(const T* qkv, const uint8_t* key_mask, T* ctx, int N, int Tk, int H, float scale,
                                                     float p_drop, unsigned long long seed) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q = (float*)smem;
@@ -284,12 +285,12 @@ __global__ __launch_bounds__(64) void attn_fwd_f32(const float* qkv, const uint8
     float* p = v + Tk * PADW;          // [Tk][Tk+1]
     const int lane = threadIdx.x, pair = blockIdx.x, n = pair / H, h = pair - n * H;
     const int ld = 3 * H * DH, Dm = H * DH, PW = Tk + 1;
-    const float* src = qkv + (size_t)n * Tk * ld + h * DH;
+    const T* src = qkv + (size_t)n * Tk * ld + h * DH;
     for (int i = lane; i < Tk * DH; i += 64) {
         int r = i >> 6, d = i & 63;
-        q[r * PADW + d] = src[(size_t)r * ld + d];
-        k[r * PADW + d] = src[(size_t)r * ld + Dm + d];
-        v[r * PADW + d] = src[(size_t)r * ld + 2 * Dm + d];
+        q[r * PADW + d] = Elem<T>::ld(src + (size_t)r * ld + d);
+        k[r * PADW + d] = Elem<T>::ld(src + (size_t)r * ld + Dm + d);
+        v[r * PADW + d] = Elem<T>::ld(src + (size_t)r * ld + 2 * Dm + d);
     }
     __syncthreads();
     for (int e = lane; e < Tk * Tk; e += 64) {
@@ -316,11 +317,12 @@ __global__ __launch_bounds__(64) void attn_fwd_f32(const float* qkv, const uint8
     for (int i = 0; i < Tk; ++i) {
         float o = 0.f;
         for (int j = 0; j < Tk; ++j) o = fmaf(p[i * PW + j], v[j * PADW + lane], o);
-        ctx[((size_t)n * Tk + i) * Dm + h * DH + lane] = o;
+        Elem<T>::st(ctx + ((size_t)n * Tk + i) * Dm + h * DH + lane, o);
     }
 }
 
-__global__ __launch_bounds__(64) void attn_bwd_f32(const float* qkv, const uint8_t* key_mask, const float* dctx, float* dqkv, int N, int Tk, int H,
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_f32(const T* qkv, const uint8_t* key_mask, const T* dctx, T* dqkv, int N, int Tk, int H,
                                                     float scale, float p_drop, unsigned long long seed) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q = (float*)smem;
@@ -331,14 +333,14 @@ __global__ __launch_bounds__(64) void attn_bwd_f32(const float* qkv, const uint8
     float* ds = p + Tk * (Tk + 1);     // dPd then dS         [Tk][Tk+1]
     const int lane = threadIdx.x, pair = blockIdx.x, n = pair / H, h = pair - n * H;
     const int ld = 3 * H * DH, Dm = H * DH, PW = Tk + 1;
-    const float* src = qkv + (size_t)n * Tk * ld + h * DH;
-    const float* gsrc = dctx + (size_t)n * Tk * Dm + h * DH;
+    const T* src = qkv + (size_t)n * Tk * ld + h * DH;
+    const T* gsrc = dctx + (size_t)n * Tk * Dm + h * DH;
     for (int i = lane; i < Tk * DH; i += 64) {
         int r = i >> 6, d = i & 63;
-        q[r * PADW + d] = src[(size_t)r * ld + d];
-        k[r * PADW + d] = src[(size_t)r * ld + Dm + d];
-        v[r * PADW + d] = src[(size_t)r * ld + 2 * Dm + d];
-        go[r * PADW + d] = gsrc[(size_t)r * Dm + d];
+        q[r * PADW + d] = Elem<T>::ld(src + (size_t)r * ld + d);
+        k[r * PADW + d] = Elem<T>::ld(src + (size_t)r * ld + Dm + d);
+        v[r * PADW + d] = Elem<T>::ld(src + (size_t)r * ld + 2 * Dm + d);
+        go[r * PADW + d] = Elem<T>::ld(gsrc + (size_t)r * Dm + d);
     }
     __syncthreads();
     for (int e = lane; e < Tk * Tk; e += 64) {
@@ -368,11 +370,11 @@ __global__ __launch_bounds__(64) void attn_bwd_f32(const float* qkv, const uint8
         for (int j = 0; j < Tk; ++j) ds[i * PW + j] = p[i * PW + j] * (ds[i * PW + j] - delta) * scale;
     }
     __syncthreads();
-    float* dst = dqkv + (size_t)n * Tk * ld + h * DH;
+    T* dst = dqkv + (size_t)n * Tk * ld + h * DH;
     for (int i = 0; i < Tk; ++i) {       // dQ[i][lane]
         float o = 0.f;
         for (int j = 0; j < Tk; ++j) o = fmaf(ds[i * PW + j], k[j * PADW + lane], o);
-        dst[(size_t)i * ld + lane] = o;
+        Elem<T>::st(dst + (size_t)i * ld + lane, o);
     }
     for (int j = 0; j < Tk; ++j) {       // dK[j][lane], dV[j][lane]
         float ok_ = 0.f, ov = 0.f;
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(64) void attn_bwd_f32(const float* qkv, const uint8
             if (p_drop > 0.f) pd = dropout1(pd, seed, ((unsigned long long)pair * Tk + i) * Tk + j, p_drop, inv_keep);
             ov = fmaf(pd, go[i * PADW + lane], ov);
         }
-        dst[(size_t)j * ld + Dm + lane] = ok_;
-        dst[(size_t)j * ld + 2 * Dm + lane] = ov;
+        Elem<T>::st(dst + (size_t)j * ld + Dm + lane, ok_);
+        Elem<T>::st(dst + (size_t)j * ld + 2 * Dm + lane, ov);
     }
 }
 
@@ -394,13 +396,15 @@ extern "C" int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask,
     DIC_REQUIRE(dh == DH && N > 0 && H > 0, "dic_attn: head dim must be 64");
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DIC_BF16) {
-        DIC_REQUIRE(Tk <= 32, "dic_attn (bf16 MFMA path): at most 32 tokens per sequence");
+    DIC_REQUIRE(Tk <= TMAX, "dic_attn: at most 64 tokens per sequence");
+    if (dtype == DIC_BF16 && Tk > 32) {      // beyond one 32x32 MFMA tile (seq_len 32 + CLIP rows): exact-fp32-math kernel on bf16 I/O
+        size_t lds = (size_t)(3 * Tk * PADW + Tk * (Tk + 1)) * sizeof(float);
+        hipLaunchKernelGGL(attn_fwd_f32<bf16_t>, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    } else if (dtype == DIC_BF16) {
         hipLaunchKernelGGL(attn_fwd_bf16, dim3((N * H + 3) / 4), dim3(256), 4 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
     } else {
-        DIC_REQUIRE(Tk <= TMAX, "dic_attn (f32 path): at most 64 tokens per sequence");
         size_t lds = (size_t)(3 * Tk * PADW + Tk * (Tk + 1)) * sizeof(float);
-        hipLaunchKernelGGL(attn_fwd_f32, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (float*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        hipLaunchKernelGGL(attn_fwd_f32<float>, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (float*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
     }
     DIC_CHECK_LAUNCH();
     return 0;
@@ -411,8 +415,13 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
     DIC_REQUIRE(dh == DH && N > 0 && H > 0, "dic_attn: head dim must be 64");
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DIC_BF16) {
-        DIC_REQUIRE(Tk <= 32, "dic_attn (bf16 MFMA path): at most 32 tokens per sequence");
+    DIC_REQUIRE(Tk <= TMAX, "dic_attn: at most 64 tokens per sequence");
+    if (dtype == DIC_BF16 && Tk > 32) {
+        size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute((const void*)attn_bwd_f32<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * TMAX * PADW + 2 * TMAX * (TMAX + 1))); attr2 = true; }
+        hipLaunchKernelGGL(attn_bwd_f32<bf16_t>, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    } else if (dtype == DIC_BF16) {
         const int rows = Tk < 32 ? ((Tk + 1 + 3) & ~3) : 32;          // valid rows + one zero row
         const int tile_bytes = rows * VSTRIDE;
         size_t lds = 4 * (size_t)(3 * tile_bytes + 512);
@@ -420,9 +429,10 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
         if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * TILE + 512)); attr = true; }
         hipLaunchKernelGGL(attn_bwd_bf16, dim3((N * H + 3) / 4), dim3(256), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
     } else {
-        DIC_REQUIRE(Tk <= TMAX, "dic_attn (f32 path): at most 64 tokens per sequence");
         size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);
-        hipLaunchKernelGGL(attn_bwd_f32, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (const float*)dctx, (float*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        static bool attr3 = false;
+        if (!attr3) { (void)hipFuncSetAttribute((const void*)attn_bwd_f32<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * TMAX * PADW + 2 * TMAX * (TMAX + 1))); attr3 = true; }
+        hipLaunchKernelGGL(attn_bwd_f32<float>, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (const float*)dctx, (float*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
     }
     DIC_CHECK_LAUNCH();
     return 0;

@@ -184,3 +184,112 @@ def test_validate_signature_and_oracle_agreement():
     assert model.training          # validate() restores train mode (ref :499)
     # same order of magnitude as the recorded eval losses (different noise draws)
     assert abs(f(vt) - z["eval_losses"][1]) / z["eval_losses"][1] < 0.2
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE full sizes: properties
+class _NoStep:
+    """Trainer stand-in: keeps train_func's backward but leaves the parameters alone."""
+    def __init__(self, model): self.model = model
+    def zero_grad(self): self.model.params.G.zero_()
+    def step(self): pass
+
+
+def _grads_for(model, x, B, t, noises):
+    dic.cfg.update(BATCH_SIZE=B)
+    l, *_ = dic.train_func(model, _NoStep(model), x, t=t, noises=noises)
+    return model.params.G.clone(), f(l)
+
+
+@pytest.mark.parametrize("dtype,n_layers,tol", [("bf16", 12, 3e-2), ("fp32", 2, 2e-4)])
+def test_full_size_gradient_is_mean_of_shard_gradients(dtype, n_layers, tol):
+    """Config 2/3 shape (512 captions x 16 tokens): the gradient of the global batch equals the mean of the gradients of its two
+    halves (same t, per-item noise) -- the property the single RCCL all-reduce of data parallelism relies on."""
+    B, L, V = 512, 16, 30522
+    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=1, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True, VOCAB_SIZE=V)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(V, 768, 0)
+    model = dic.DistilBertModel(E, E, config=dict(n_layers=n_layers, dropout=0.0, attention_dropout=0.0), dtype=dtype)
+    model.load_state(synth.denoiser_state(n_layers, 0))
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 3).items()}
+    t = torch.tensor([[[37]]])
+    nz = [torch.from_numpy(synth.noise((B, L, 768), 11, f"eps{i}")) for i in range(2)]
+    g_full, l_full = _grads_for(model, x, B, t, nz)
+    h = B // 2
+    halves = []
+    for s in (slice(0, h), slice(h, B)):
+        xs = {k: v[s] for k, v in x.items()}
+        halves.append(_grads_for(model, xs, h, t, [n[s] for n in nz]))
+    g_mean = 0.5 * (halves[0][0] + halves[1][0])
+    l_mean = 0.5 * (halves[0][1] + halves[1][1])
+    assert abs(l_full - l_mean) < 1e-3 * abs(l_full) if dtype == "bf16" else abs(l_full - l_mean) < 1e-5 * abs(l_full)
+    err = float((g_full - g_mean).norm() / g_full.norm())
+    print(dtype, "full-vs-shard-mean gradient rel err", err, "loss", l_full)
+    assert err < tol and np.isfinite(l_full)
+
+
+def test_full_size_training_is_deterministic_and_descends():
+    """Config 2: B=512, 12 layers, bf16, dropout 0.1: same seeds -> bit-identical losses; loss decreases over steps."""
+    B, L, V = 512, 16, 30522
+    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=1, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True, VOCAB_SIZE=V)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(V, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 1).items()}
+    runs = []
+    for rep in range(2):
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=12, dropout=0.1, attention_dropout=0.1), dtype="bf16", seed=1)
+        trainer = dic.AdamW(model.parameters(), lr=1e-4)
+        dic.seed_noise(7)
+        ls = []
+        for step in range(4):
+            t = torch.from_numpy(synth.timesteps(1, 100, step))
+            ls.append(f(dic.train_func(model, trainer, x, t=t)[0]))
+        runs.append(ls)
+    assert runs[0] == runs[1], runs
+    assert all(np.isfinite(runs[0])) and runs[0][-1] < runs[0][0]
+
+
+def test_config5_seq32_guidance_bf16_matches_fp32():
+    """Config 5 shape: seq_len 32 (+2 CLIP rows = 34 tokens, beyond one MFMA tile), classifier-free guidance p=0.2 w=0.3."""
+    B, S, L, V = 8, 2, 32, 5000
+    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5, CLASSIFIER_FREE_PROB=0.2,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.3, X_0_PREDICTION=True, VOCAB_SIZE=V)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(V, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 5).items()}
+    t = torch.from_numpy(synth.timesteps(S, 100, 2))
+    nz = [torch.from_numpy(synth.noise((B, L, 768), 4, f"eps{i}")) for i in range(2)]
+    u = torch.from_numpy(synth.uniform(synth.stream_id("cfg", 4), (S * B, 1)))
+    out = {}
+    for dtype in ("fp32", "bf16"):
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=2, dropout=0.0, attention_dropout=0.0), dtype=dtype)
+        model.load_state(synth.denoiser_state(2, 0))
+        trainer = dic.AdamW(model.parameters(), lr=1e-4)
+        out[dtype] = [np.array([f(v) for v in dic.train_func(model, trainer, x, t=t, noises=nz, cfg_uniform=u)]) for _ in range(2)]
+    # fp32 against the CPU oracle
+    rcfg = R.Config(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=2, vocab=V, CLASSIFIER_FREE_WEIGHT=0.3)
+    om = R.build(rcfg, synth.denoiser_state(2, 0), E)
+    otr = R.AdamW(om.parameters(), lr=1e-4)
+    xo = {k: v.cpu() for k, v in x.items()}
+    ref = [np.array([float(v) for v in R.train_func(om, otr, xo, t=t, noises=nz, cfg_uniform=u)]) for _ in range(2)]
+    np.testing.assert_allclose(out["fp32"], ref, rtol=1e-4)
+    np.testing.assert_allclose(out["bf16"], ref, rtol=5e-3)
+
+
+def test_sampling_is_batch_permutation_equivariant_at_config4_size():
+    """Config 4 shape (batch 2048 images): every image is refined independently, so permuting the batch permutes the ids
+    bit-for-bit (no kernel depends on a sequence's position in the batch)."""
+    Bn, L, V = 2048, 16, 30522
+    dic.cfg.update(MAX_LENGTH=L, CLASSIFIER_FREE_WEIGHT=0.0, CLIP_ADDING_METHOD="concat", VOCAB_SIZE=V)
+    E = synth.vocab_embedding(V, 768, 0)
+    model = dic.DistilBertModel(E, E, config=dict(n_layers=6), dtype="fp32")
+    model.load_state(synth.denoiser_state(6, 0))
+    model.eval()
+    img = torch.from_numpy(synth.batch(Bn, L, V, 9)["image_clip"]).cuda()
+    start = torch.from_numpy(synth.noise((Bn, L + 2, 768), 21, "restored")).cuda()
+    perm = torch.from_numpy(np.random.RandomState(0).permutation(Bn)).cuda()
+    ids = dic.sample(model, img, steps=4, start=start)
+    ids_p = dic.sample(model, img[perm], steps=4, start=start[perm])
+    assert torch.equal(ids[perm], ids_p)
+    assert ids.shape == (Bn, L) and int(ids.min()) >= 0 and int(ids.max()) < V
