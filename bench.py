@@ -128,8 +128,8 @@ def main():
             "metric": "training captions/sec (seq16, bert-base)", "value": round(value, 2), "unit": "captions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"train_func: B={B}/GPU x S={S} (+x_1 pass) = {(S + 1) * B} sequences x {L + 2} tokens, {args.layers}-layer "
-                                   f"DistilBERT-width denoiser, concat fusion, linear beta T=100, dropout 0.1, AdamW",
+            "config": {"workload": f"train_func: B={B}/GPU x S={S} (+x_1 pass) = {(S + 1) * B} sequences x {L}+2 tokens (the unguided text row is "
+                                   f"skipped), {args.layers}-layer DistilBERT-width denoiser, concat fusion, linear beta T=100, dropout 0.1, AdamW",
                        "global_batch": world * B, "seq_len": L, "sample_size": S, "n_layers": args.layers,
                        "parallelism": f"dp{world}", "loss": round(loss_val, 4),
                        "algorithmic_tflop_per_s": round(value * gf / 1e3, 2)},

@@ -307,8 +307,9 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
     if train:
         if not model._pending:
             raise RuntimeError("train_func(train=True) called under torch.no_grad()")
-        model.backward()
-        parallel.allreduce_grads(model, trainer)
+        reducer = parallel.GradReducer(model)
+        model.backward(layer_done=reducer.layer_done if reducer.active else None)
+        reducer.finish(trainer)
         if not isinstance(trainer, AdamW):
             model.params.relink_grads()
         trainer.step()
@@ -348,11 +349,14 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
     img = image_clip.to(dev, torch.float32)
     restored = start.to(dev, torch.float32) if start is not None else torch.randn(B, L + 2, cfg.IN_CHANNEL, device=dev)
     one = torch.ones(B, 1, dtype=torch.uint8, device=dev)
-    km = torch.cat([torch.ones(B, L, dtype=torch.uint8, device=dev), one, 0 * one], 1) if model.concat else torch.ones(B, L, dtype=torch.uint8, device=dev)
+    ones_l = torch.ones(B, L, dtype=torch.uint8, device=dev)
+    # the text row is masked as a key ([1, 0]) and only rows < L are fed back: skip it unless the caller wants the full hidden state
+    drop_txt = model.concat and cfg.DROP_UNUSED_TEXT_ROW and not return_hidden
+    km = (torch.cat([ones_l, one], 1) if drop_txt else torch.cat([ones_l, one, 0 * one], 1)) if model.concat else ones_l
     zeros = torch.zeros_like(img)
     x = restored[:, :L, :].contiguous()
     for _ in range(steps):
-        x_out = model.encode(x, img, zeros, km)
+        x_out = model.encode(x, img, zeros, km, drop_txt=drop_txt)
         x = x_out[:, :L, :].contiguous()
     xr = x.reshape(B * L, 768)
     _, ids, _ = model.rounding(xr, B * L, dtype=_lib.DIC_F32)

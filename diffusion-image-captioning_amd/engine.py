@@ -269,9 +269,10 @@ class Denoiser:
         return ws["x_out"]
 
     # ------------------------------------------------------------------ encoder backward
-    def backward(self, dx_out=None):
+    def backward(self, dx_out=None, layer_done=None):
         """dx_out [N,Tk,768] fp32 (defaults to the workspace buffer the loss kernels filled).  Accumulates nothing:
-        every parameter gradient in `params.G` is overwritten (pos rows >= Tk stay zero from zero_grad)."""
+        every parameter gradient in `params.G` is overwritten (pos rows >= Tk stay zero from zero_grad).
+        layer_done(i): optional callback fired once layer i's gradients are complete (data-parallel overlap)."""
         ws = self._saved
         assert ws is not None, "backward() without a saved forward"
         N, L, Tk, T, D, Hd = ws["N"], ws["L"], ws["Tk"], ws["T"], self.dim, self.hidden
@@ -331,6 +332,8 @@ class Denoiser:
             wgrad(_p(ws["dqkv"]), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D, bias_slot=pre + "bqkv")                      # dWqkv (+ dbqkv)
             o.gemm(_p(ws["dqkv"]), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(ws["dy1"]), ldr=D)
             dH, dHn = dHn, dH
+            if layer_done is not None:
+                layer_done(i)
         # embeddings LayerNorm + fusion backward
         mode = ws["mode"]
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),

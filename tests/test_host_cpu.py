@@ -139,13 +139,17 @@ def _dp_worker(rank, world, port, out):
     for (n, p), g in zip(store.named_parameters(), model.parameters()):
         p.grad.copy_(g.grad)
 
-    class M:            # what parallel.allreduce_grads needs from a model
+    class M:            # what the reducer needs from a model
         params = store
 
     class T:
         grad_scale = 1.0
     tr = T()
-    d.parallel.allreduce_grads(M, tr)          # ONE collective over the flat buffer
+    red = d.parallel.GradReducer(M)            # layer slices go out asynchronously as the backward produces them ...
+    assert red.active
+    for i in reversed(range(nl)):
+        red.layer_done(i)
+    red.finish(tr)                             # ... then the small tail; together exactly one pass over the flat buffer
     assert tr.grad_scale == 1.0 / world
     (lm,) = d.parallel.allreduce_scalars(l)
     if rank == 0:
