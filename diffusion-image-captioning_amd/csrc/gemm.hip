@@ -103,11 +103,11 @@ __device__ __forceinline__ float row_scale(const DicGemmParams& p, int m) { retu
 // ---- block -> (tile, K-slice) ----------------------------------------------------------------------
 // XCD-aware order: consecutive logical ids (same A row-panel, then the K-slices of one tile) share one XCD's L2.
 struct TileId { int bm, bn, nbn, kz, kt0, kt1; };
-__device__ __forceinline__ int total_units(const DicGemmParams& p) {
-    return ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * (p.split_k > 1 ? p.split_k : 1);
+__device__ __forceinline__ int total_units(const DicGemmParams& p, int bm_ = BM, int bn_ = BN) {
+    return ((p.N + bn_ - 1) / bn_) * ((p.M + bm_ - 1) / bm_) * (p.split_k > 1 ? p.split_k : 1);
 }
-__device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, int pid) {
-    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+__device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, int pid, int bm_ = BM, int bn_ = BN) {
+    const int nbn = (p.N + bn_ - 1) / bn_, nbm = (p.M + bm_ - 1) / bm_;
     const int split = p.split_k > 1 ? p.split_k : 1;
     const int nwg = nbm * nbn * split;
     {
@@ -328,12 +328,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {   // v1:
 // ---- LDS-staged epilogue of the bf16 kernel -------------------------------------------------------------------------
 // The MFMA accumulator layout gives a lane 4 consecutive n of ONE row, so direct stores are 16 rows x 32-byte fragments
 // per wave-instruction -- store-ISSUE-bound: a K=64 GEMM of 510 tiles took 13 us, almost all of it this tail.  Instead the
-// 128x128 fp32 tile is parked in the (now idle) 64 KB of LDS, XOR-swizzled so both the scattered 16-byte writes and the
-// row-wise 16-byte reads are bank-conflict-free, and written out row-contiguously: each thread handles 8 consecutive n,
-// 16 threads cover a 256-byte output row, a wave-instruction writes 4 full rows.  Residual / pre-activation side inputs are
-// read with the same fully coalesced pattern, and each thread's 8 columns are fixed, so its bias slice is loaded once.
-__device__ __forceinline__ int ctile_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
-
+// fp32 tile is parked in the (now idle) LDS stages -- 128 rows at a time --, XOR-swizzled so both the scattered 16-byte writes
+// and the row-wise 16-byte reads are bank-conflict-free, and written out row-contiguously: each thread handles 8 consecutive
+// n, BN/8 threads cover an output row, a wave-instruction writes whole 128-byte lines.  Residual / pre-activation side inputs
+// are read with the same fully coalesced pattern, and each thread's 8 columns are fixed, so its bias slice is loaded once.
 __device__ __forceinline__ void unpack8(i32x4 r, f32x4& a, f32x4& b) {
     a[0] = __uint_as_float((unsigned)r[0] << 16); a[1] = __uint_as_float((unsigned)r[0] & 0xffff0000u);
     a[2] = __uint_as_float((unsigned)r[1] << 16); a[3] = __uint_as_float((unsigned)r[1] & 0xffff0000u);
@@ -347,17 +345,31 @@ __device__ __forceinline__ i32x4 pack8f(const f32x4& a, const f32x4& b) {
     return r;
 }
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const DicGemmParams& p, int m0, int n0, int wm, int wn, int lane, int tid, char* smem) {
+// Tile geometries of the bf16 kernel.  T128: 128x128, 4 waves (2x2, 64x64 each), 64 KB LDS, two workgroups per CU.
+// T256: 256x256, 8 waves (2x4, 128x64 each), 128 KB LDS, one workgroup per CU -- twice the flop per byte pulled from L2
+// (128 vs 64 flop/B: the 128x128 kernel saturates near 0.9 PFLOP/s on L2->LDS bandwidth) and 25 % fewer LDS reads per MFMA.
+struct T128 { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
+struct T256 { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4; };
+template <class C> struct Geo {
+    static constexpr int BM = C::BM, BN = C::BN, WM = C::WM, WN = C::WN;
+    static constexpr int NW = WM * WN, NTH = 64 * NW;
+    static constexpr int FM = BM / WM / 16, FN = BN / WN / 16;           // MFMA fragments per wave
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
+    static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;             // 1 KiB DMA pieces per wave per operand
+    static constexpr int C_ROWS = LDS / (BN * 4) < BM ? LDS / (BN * 4) : BM;   // output rows parked in LDS per epilogue pass
+    static constexpr int C_PASSES = BM / C_ROWS;
+};
+
+template <class C, int EPI>
+__device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN], const DicGemmParams& p, int m0, int n0, int wm, int wn,
+                                             int lane, int tid, char* smem) {
+    using G = Geo<C>;
     using T = bf16_t;
+    constexpr int ROWB = G::BN * 4;                       // bytes per parked row
+    constexpr int CPR = G::BN / 8;                        // 8-column items per row
+    constexpr int RPI = G::NTH / CPR;                     // rows covered per iteration
     const int g = lane >> 4, t = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *(f32x4*)(smem + ctile_off(wm * 64 + i * 16 + t, wn * 16 + j * 4 + g)) = acc[i][j];
-    __syncthreads();
-    const int c8 = tid & 15;                       // this thread's 8 columns are the same for every row it handles
+    const int c8 = tid % CPR;                             // this thread's 8 columns are the same for every row it handles
     const int n = n0 + c8 * 8;
     const bool v0ok = n < p.N, v1ok = n + 4 < p.N;
     f32x4 b0{0.f, 0.f, 0.f, 0.f}, b1{0.f, 0.f, 0.f, 0.f};
@@ -365,58 +377,74 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const DicGemmPa
         if (p.bias) { if (v0ok) b0 = *(const f32x4*)(p.bias + n); if (v1ok) b1 = *(const f32x4*)(p.bias + n + 4); }
     }
     const float inv_keep = drop_inv_keep(p.p_drop);
-#pragma unroll 2
-    for (int k = 0; k < 8; ++k) {
-        const int row = (tid >> 4) + 16 * k, m = m0 + row;
-        if (m >= p.M) continue;
-        f32x4 x0 = *(const f32x4*)(smem + ctile_off(row, 2 * c8)), x1 = *(const f32x4*)(smem + ctile_off(row, 2 * c8 + 1));
-        if constexpr (EPI == DIC_EPI_AFFINE) {
-            if (!v0ok) continue;
-            x0 += b0; x1 += b1;
-            if (p.p_drop > 0.f) {
-                x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
-                x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + n + 4, p.p_drop, inv_keep);
-            }
-            if (p.R) {
-                const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
-                if (v1ok) { f32x4 r0, r1; unpack8(*(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
-                else x0 += Elem<T>::ld4(rp);
-            }
-            if (p.out_f32) {
-                float* c = (float*)p.C + (size_t)m * p.ldc + n;
-                if (p.accumulate) { x0 += *(const f32x4*)c; if (v1ok) x1 += *(const f32x4*)(c + 4); }
-                *(f32x4*)c = x0;
-                if (v1ok) *(f32x4*)(c + 4) = x1;
-            } else {
-                T* c = (T*)p.C + (size_t)m * p.ldc + n;
-                if (v1ok) *(i32x4*)c = pack8f(x0, x1); else Elem<T>::st4(c, x0);
-            }
-        } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {
-            if (!v1ok) continue;                                   // N % 8 == 0 is required for this epilogue
-            x0 += b0; x1 += b1;
-            *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + n) = pack8f(x0, x1);     // pre-activation u (for GELU')
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
-            *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-        } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
-            if (!v1ok) continue;
-            f32x4 u0, u1;
-            unpack8(*(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n), u0, u1);
+    for (int pass = 0; pass < G::C_PASSES; ++pass) {
+        if (pass > 0) __syncthreads();
+        const int wrow0 = wm * (G::BM / G::WM) - pass * G::C_ROWS;       // this wave's first row relative to the parked block
+        if (wrow0 >= 0 && wrow0 < G::C_ROWS) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
-            *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-        } else {   // DIC_EPI_CE_DLOGITS: (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
-            if (n >= p.ldc) continue;
-            const float lse = p.lse[m], sc = row_scale(p, m);
-            const long long tg = p.tgt[m];
+            for (int i = 0; i < G::FM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
-                if ((long long)(n + r) == tg) q0 -= 1.0f;
-                if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
-                x0[r] = q0 * sc; x1[r] = q1 * sc;
+                for (int j = 0; j < G::FN; ++j) {
+                    const int row = wrow0 + i * 16 + t, chunk = wn * (G::BN / G::WN / 4) + j * 4 + g;
+                    *(f32x4*)(smem + row * ROWB + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
+                }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < G::C_ROWS / RPI; ++k) {
+            const int row = tid / CPR + RPI * k, m = m0 + pass * G::C_ROWS + row;
+            if (m >= p.M) continue;
+            const char* rp_ = smem + row * ROWB;
+            f32x4 x0 = *(const f32x4*)(rp_ + (((2 * c8) ^ (row & 15)) << 4)), x1 = *(const f32x4*)(rp_ + (((2 * c8 + 1) ^ (row & 15)) << 4));
+            if constexpr (EPI == DIC_EPI_AFFINE) {
+                if (!v0ok) continue;
+                x0 += b0; x1 += b1;
+                if (p.p_drop > 0.f) {
+                    x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
+                    x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + n + 4, p.p_drop, inv_keep);
+                }
+                if (p.R) {
+                    const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
+                    if (v1ok) { f32x4 r0, r1; unpack8(*(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
+                    else x0 += Elem<T>::ld4(rp);
+                }
+                if (p.out_f32) {
+                    float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                    if (p.accumulate) { x0 += *(const f32x4*)c; if (v1ok) x1 += *(const f32x4*)(c + 4); }
+                    *(f32x4*)c = x0;
+                    if (v1ok) *(f32x4*)(c + 4) = x1;
+                } else {
+                    T* c = (T*)p.C + (size_t)m * p.ldc + n;
+                    if (v1ok) *(i32x4*)c = pack8f(x0, x1); else Elem<T>::st4(c, x0);
+                }
+            } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {
+                if (!v1ok) continue;                                   // N % 8 == 0 is required for this epilogue
+                x0 += b0; x1 += b1;
+                *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + n) = pack8f(x0, x1);     // pre-activation u (for GELU')
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
+                *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+            } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
+                if (!v1ok) continue;
+                f32x4 u0, u1;
+                unpack8(*(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n), u0, u1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
+                *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+            } else {   // DIC_EPI_CE_DLOGITS: (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
+                if (n >= p.ldc) continue;
+                const float lse = p.lse[m], sc = row_scale(p, m);
+                const long long tg = p.tgt[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
+                    if ((long long)(n + r) == tg) q0 -= 1.0f;
+                    if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
+                    x0[r] = q0 * sc; x1[r] = q1 * sc;
+                }
+                *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
             }
-            *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
         }
     }
 }
@@ -427,57 +455,53 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const DicGemmPa
 // tile's DMA is in flight while the MFMAs of the current tile run.  The DMA destination is lane-linear (wave base +
 // lane*16), so the bank-conflict-free LDS image is produced by permuting the per-lane SOURCE address and applying the
 // same XOR on the fragment reads (both verified against the bank model of MI355X_MICROARCH.md):
-//   KC tile [128 rows][128 B]: 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7); fragment = ONE ds_read_b128
-//                              (8 consecutive k), conflict-free and not mergeable into the half-rate ds_read2 forms
-//   KM tile [ 64 k   ][256 B]: chunk c of row k lives at c ^ km_key(k); fragment = two ds_read_b64_tr_b16 on rows
-//                              8g+{0..3} and 8g+4+{0..3}  => lane group g = lane>>4 holds k = 8g..8g+7 in BOTH layouts.
-// Everything lane-dependent (DMA source offsets, fragment addresses) is computed once; the K loop is 8 DMA issues,
-// 8+8 LDS reads, 32 MFMAs, 8 integer adds and one barrier per 64-deep step, unrolled over the two LDS stages so that
-// stage offsets are instruction immediates.
-constexpr int DMA_TILE = 16384, DMA_STAGE = 32768;
+//   KC tile [rows][128 B]:       16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7); fragment = ONE ds_read_b128
+//                                (8 consecutive k), conflict-free and not mergeable into the half-rate ds_read2 forms
+//   KM tile [64 k][rows x 2 B]:  chunk c of row k lives at c ^ km_key(k); fragment = two ds_read_b64_tr_b16 on rows
+//                                8g+{0..3} and 8g+4+{0..3}  => lane group g = lane>>4 holds k = 8g..8g+7 in BOTH layouts.
+// Everything lane-dependent (DMA source offsets, fragment addresses) is computed once per workgroup; the K loop is DMA
+// issues, LDS reads, MFMAs, a few integer adds and one barrier per 64-deep step, unrolled over the two LDS stages so
+// that stage offsets are instruction immediates.
 __device__ __forceinline__ int kc_key(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int km_key(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
-template <bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
+template <class C, bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Geo<C>;
     using T = bf16_t;
     constexpr int S = 2, BK = 64;
+    constexpr int ROWB_A = AKM ? G::BM * 2 : 128, ROWB_B = BKM ? G::BN * 2 : 128;     // LDS row pitch of each operand tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / G::WN, wn = wave % G::WN;
     const int g = lane >> 4, t = lane & 15;
 
-    // ---- per-lane fragment addresses inside an operand tile (same for every tile this workgroup processes)
-    int ofA[4][2], ofB[4][2];
+    // ---- per-lane fragment addresses inside an operand tile for the first 32-deep half-step (same for every tile this
+    // workgroup processes); the second half-step is `^ 64` (KC: chunk index bit 2) or `+ 32 rows` (KM: same swizzle key)
+    int ofA[G::FM], ofB[G::FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (!AKM) { const int row = wm * 64 + i * 16 + t; ofA[i][kk] = row * 128 + (((kk * 4 + g) ^ kc_key(row)) << 4); }
-            else { const int rho = kk * 32 + 8 * g + (t >> 2), c = ((wm * 64 + i * 16) >> 3) + ((t & 3) >> 1); ofA[i][kk] = rho * 256 + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
-            if (!BKM) { const int row = wn * 64 + i * 16 + t; ofB[i][kk] = row * 128 + (((kk * 4 + g) ^ kc_key(row)) << 4); }
-            else { const int rho = kk * 32 + 8 * g + (t >> 2), c = ((wn * 64 + i * 16) >> 3) + ((t & 3) >> 1); ofB[i][kk] = rho * 256 + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
-        }
-    // ---- per-lane DMA source offsets of the 4 x 1 KiB pieces this wave stages per operand, relative to the tile origin at
-    // k = 0; they advance by a uniform step.  (Kept in VGPRs rather than the scalar offset operand: the descriptor's bounds
-    // check covers only the vector offset, and it is that check which zero-fills ragged M/N/K.)
-    unsigned baseA[4], baseB[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = wave * 4 + j;
-        if (!AKM) { const int row = 8 * q + (lane >> 3); baseA[j] = (unsigned)row * (unsigned)p.lda * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
-        else      { const int row = 4 * q + (lane >> 4); baseA[j] = (unsigned)row * (unsigned)p.lda * 2u + (((lane & 15) ^ km_key(row)) << 4); }
-        if (!BKM) { const int row = 8 * q + (lane >> 3); baseB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
-        else      { const int row = 4 * q + (lane >> 4); baseB[j] = (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 15) ^ km_key(row)) << 4); }
+    for (int i = 0; i < G::FM; ++i) {
+        const int base = wm * (G::BM / G::WM) + i * 16;
+        if (!AKM) { const int row = base + t; ofA[i] = row * 128 + ((g ^ kc_key(row)) << 4); }
+        else { const int rho = 8 * g + (t >> 2), c = (base >> 3) + ((t & 3) >> 1); ofA[i] = rho * ROWB_A + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
     }
+#pragma unroll
+    for (int j = 0; j < G::FN; ++j) {
+        const int base = wn * (G::BN / G::WN) + j * 16;
+        if (!BKM) { const int row = base + t; ofB[j] = row * 128 + ((g ^ kc_key(row)) << 4); }
+        else { const int rho = 8 * g + (t >> 2), c = (base >> 3) + ((t & 3) >> 1); ofB[j] = rho * ROWB_B + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
+    }
+    // ---- per-lane DMA source offsets of the 1 KiB pieces this wave stages per operand advance by a uniform step.  (Kept in
+    // VGPRs rather than the scalar offset operand: the descriptor's bounds check covers only the vector offset, and it is
+    // that check which zero-fills ragged M/N/K.)
     const unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;
     const unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
 
     __amdgpu_buffer_rsrc_t rsA, rsB;
-    unsigned voA[4], voB[4];
+    unsigned voA[G::PA], voB[G::PB];
     auto setup = [&](const TileId& tl) {          // descriptors anchored at the tile origin: OOB rows/k read as zero
-        const int m0 = tl.bm * BM, n0 = tl.bn * BN;
+        const int m0 = tl.bm * G::BM, n0 = tl.bn * G::BN;
         const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
         const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
         long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
@@ -488,105 +512,118 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
         rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
         const unsigned ka = (unsigned)tl.kt0 * stepA, kb = (unsigned)tl.kt0 * stepB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { voA[j] = baseA[j] + ka; voB[j] = baseB[j] + kb; }
+        for (int j = 0; j < G::PA; ++j) {
+            const int q = wave * G::PA + j;
+            if (!AKM) { const int row = 8 * q + (lane >> 3); voA[j] = ka + (unsigned)row * (unsigned)p.lda * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+            else { constexpr int CPRW = G::BM / 8; const int row = q * (64 / CPRW) + lane / CPRW; voA[j] = ka + (unsigned)row * (unsigned)p.lda * 2u + (((lane % CPRW) ^ km_key(row)) << 4); }
+        }
+#pragma unroll
+        for (int j = 0; j < G::PB; ++j) {
+            const int q = wave * G::PB + j;
+            if (!BKM) { const int row = 8 * q + (lane >> 3); voB[j] = kb + (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+            else { constexpr int CPRW = G::BN / 8; const int row = q * (64 / CPRW) + lane / CPRW; voB[j] = kb + (unsigned)row * (unsigned)p.ldb * 2u + (((lane % CPRW) ^ km_key(row)) << 4); }
+        }
     };
     auto issue = [&](int stage) {
-        char* dst = smem + stage * DMA_STAGE + wave * 4096;
+        char* dstA = smem + stage * G::STAGE + wave * (G::PA * 1024);
+        char* dstB = smem + stage * G::STAGE + G::A_BYTES + wave * (G::PB * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(dst + j * 1024), 16, (int)voA[j], 0, 0, 0);
+        for (int j = 0; j < G::PA; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(dstA + j * 1024), 16, (int)voA[j], 0, 0, 0);
             voA[j] += stepA;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(dst + DMA_TILE + j * 1024), 16, (int)voB[j], 0, 0, 0);
+        for (int j = 0; j < G::PB; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(dstB + j * 1024), 16, (int)voB[j], 0, 0, 0);
             voB[j] += stepB;
         }
     };
-    auto frag = [&](const char* tile, int off, bool km) -> bf16x8 {
+    auto frag = [&](const char* tile, int off, bool km, int rowb) -> bf16x8 {
         if (!km) { i32x4 v = *(const i32x4*)(tile + off); return __builtin_bit_cast(bf16x8, v); }
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off + 1024));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + off + 4 * rowb));
         s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     };
-    f32x4 acc[4][4];
+    f32x4 acc[G::FM][G::FN];
     // fused bias gradient (weight-gradient GEMMs only): db[m] = sum_k A[k][m] is a column sum of the A tile that is already
     // in LDS; the workgroups of the first tile column (bn == 0) add it up on the side (4 x ds_read_b128 + 32 adds per thread
     // per K-step) instead of a separate pass that re-reads dY from HBM.
     bool do_cs = false;
     f32x4 cs0{0.f, 0.f, 0.f, 0.f}, cs1{0.f, 0.f, 0.f, 0.f};
+    constexpr int CS_CPR = G::BM / 8, CS_GROUPS = G::NTH / CS_CPR;        // 16-byte chunks per A row; thread groups over k
     auto compute = [&](int stage) {
-        const char* la = smem + stage * DMA_STAGE;
-        const char* lb = la + DMA_TILE;
+        const int sb = stage * G::STAGE;
+        const char* la = smem + sb;
+        const char* lb = la + G::A_BYTES;
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
             if (do_cs) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rho = (tid >> 4) + 16 * r;
+                for (int r = 0; r < 64 / CS_GROUPS; ++r) {
+                    const int rho = tid / CS_CPR + CS_GROUPS * r;
                     f32x4 a, b;
-                    unpack8(*(const i32x4*)(la + rho * 256 + (((tid & 15) ^ km_key(rho)) << 4)), a, b);
+                    unpack8(*(const i32x4*)(la + rho * ROWB_A + (((tid % CS_CPR) ^ km_key(rho)) << 4)), a, b);
                     cs0 += a; cs1 += b;
                 }
             }
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fb[G::FN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag(la, ofA[i][kk], AKM);
+            for (int j = 0; j < G::FN; ++j) fb[j] = frag(lb, BKM ? ofB[j] + kk * 32 * ROWB_B : ofB[j] ^ (kk * 64), BKM, ROWB_B);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag(lb, ofB[j][kk], BKM);
+            for (int ih = 0; ih < G::FM; ih += 4) {          // A fragments four at a time: bounded register footprint at FM = 8
+                bf16x8 fa[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) fa[i] = frag(la, AKM ? ofA[ih + i] + kk * 32 * ROWB_A : ofA[ih + i] ^ (kk * 64), AKM, ROWB_A);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < G::FN; ++j)
+                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih + i][j], 0, 0, 0);
+            }
         }
     };
 
-    // ---- persistent loop over (tile, K-slice) units: the grid is capped at two workgroups per CU, so addressing set-up is
-    // paid once per workgroup and the tail of the launch is balanced by unit order rather than by dispatch order.
-    const int total = total_units(p);
+    // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
+    // addressing set-up is paid once per workgroup and the tail of the launch is balanced by unit order, not dispatch order.
+    const int total = total_units(p, G::BM, G::BN);
     int unit = blockIdx.x;
-    TileId tl = tile_of_unit(p, BK, unit);
+    TileId tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
     __syncthreads();                     // (the compiler drains the LDS-DMA with vmcnt(0) ahead of the barrier)
     for (;;) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < G::FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < G::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
             do_cs = p.colsum_out != nullptr && tl.bn == 0;
             cs0 = f32x4{0.f, 0.f, 0.f, 0.f}; cs1 = cs0;
         }
-        int kt = tl.kt0;
         const int nk = tl.kt1;
-        while (kt < nk) {
-            if (kt + 1 < nk) issue(1);   // next K-step's DMA flies under this step's MFMAs
-            compute(0);
+        int cur = 0;
+        for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
+            if (kt + 1 < nk) issue(cur ^ 1);           //  register allocator keep two copies of the accumulator tile)
+            compute(cur);                              // next K-step's DMA flies under this step's MFMAs
             __syncthreads();
-            if (++kt >= nk) break;
-            if (kt + 1 < nk) issue(0);
-            compute(1);
-            __syncthreads();
-            ++kt;
+            cur ^= 1;
         }
         DicGemmParams pe = p;
         if (p.split_k > 1) redirect_to_slab(pe, tl.kz);
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
-            if (do_cs) {       // fold the 16 row-groups through LDS (free after the K loop's last barrier), fixed order
+            if (do_cs) {       // fold the thread groups through LDS (free after the K loop's last barrier), fixed order
                 float* red = (float*)smem;
-                *(f32x4*)(red + (tid >> 4) * 128 + (tid & 15) * 8) = cs0;
-                *(f32x4*)(red + (tid >> 4) * 128 + (tid & 15) * 8 + 4) = cs1;
+                *(f32x4*)(red + (tid / CS_CPR) * G::BM + (tid % CS_CPR) * 8) = cs0;
+                *(f32x4*)(red + (tid / CS_CPR) * G::BM + (tid % CS_CPR) * 8 + 4) = cs1;
                 __syncthreads();
-                if (tid < 128) {
+                if (tid < G::BM) {
                     float v = 0.f;
 #pragma unroll
-                    for (int gq = 0; gq < 16; ++gq) v += red[gq * 128 + tid];
-                    const int m = tl.bm * BM + tid;
+                    for (int gq = 0; gq < CS_GROUPS; ++gq) v += red[gq * G::BM + tid];
+                    const int m = tl.bm * G::BM + tid;
                     if (m < p.M) {
                         if (p.split_k > 1) ((float*)pe.C)[(size_t)p.M * p.ldc + m] = v;
                         else p.colsum_out[m] = p.accumulate ? p.colsum_out[m] + v : v;
@@ -595,11 +632,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(DicGemmParams p) {
                 __syncthreads();
             }
         }
-        if constexpr (EPI == DIC_EPI_CE_PARTIAL) epilogue<T, EPI>(acc, pe, tl.bm * BM, tl.bn * BN, wm, wn, lane, tl.bn, tl.nbn);
-        else epilogue_lds<EPI>(acc, pe, tl.bm * BM, tl.bn * BN, wm, wn, lane, tid, smem);
+        if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
+            if constexpr (G::BM == 128) epilogue<T, EPI>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tl.bn, tl.nbn);
+        } else {
+            epilogue_lds<C, EPI>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tid, smem);
+        }
         unit += gridDim.x;
         if (unit >= total) break;
-        tl = tile_of_unit(p, BK, unit);
+        tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
         setup(tl);
         __syncthreads();                 // every wave is done with the LDS-staged output tile
         if (tl.kt0 < tl.kt1) issue(0);
@@ -627,27 +667,43 @@ bool bf16_on_v1() {
     return v == 1;
 }
 
+int device_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+bool persist_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DIC_GEMM_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
+template <class C, bool AKM, bool BKM, int E>
+void launch_bf16(const DicGemmParams& q, hipStream_t st) {
+    using G = Geo<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        attr_set = true;
+    }
+    const int units = ((q.N + G::BN - 1) / G::BN) * ((q.M + G::BM - 1) / G::BM) * (q.split_k > 1 ? q.split_k : 1);
+    const int resident = device_cus() * (160 * 1024 / G::LDS);       // co-resident workgroups (LDS-limited): 2 per CU at 64 KB, 1 at 128 KB
+    const int grid = (persist_enabled() && units > resident) ? resident : units;
+    hipLaunchKernelGGL((gemm_bf16_kernel<C, AKM, BKM, E>), dim3(grid), dim3(G::NTH), G::LDS, st, q);
+}
+
 template <typename T, bool AKM, bool BKM, int E>
-void launch_one(dim3 grid, hipStream_t st, const DicGemmParams& q) {
+void launch_one(hipStream_t st, const DicGemmParams& q) {
     if constexpr (sizeof(T) == 2) {
         if (!bf16_on_v1()) {
-            constexpr size_t lds = 2 * DMA_STAGE;           // 64 KB: two stages x (A tile + B tile) -> 2 workgroups per CU
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set = true;
+            if constexpr (E != DIC_EPI_CE_PARTIAL) {
+                if (q.tile == 256) { launch_bf16<T256, AKM, BKM, E>(q, st); return; }
             }
-            static int cap = -1;                           // persistent grid: two workgroups per CU (DIC_GEMM_PERSIST=0: one unit per block)
-            if (cap < 0) {
-                const char* e = getenv("DIC_GEMM_PERSIST");
-                int cus = 256;
-                hipDeviceProp_t prop;
-                int dev = 0;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-                cap = (e && e[0] == '0') ? 0x7fffffff : 2 * cus;
-            }
-            dim3 pgrid((int)grid.x < cap ? grid.x : cap);
-            hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, E>), pgrid, dim3(NT), lds, st, q);
+            launch_bf16<T128, AKM, BKM, E>(q, st);
             return;
         }
     }
@@ -657,20 +713,19 @@ void launch_one(dim3 grid, hipStream_t st, const DicGemmParams& q) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<T, AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, AKM, BKM, E>), grid, dim3(NT), lds, st, q);
+    const int nbn = (q.N + BN - 1) / BN, nbm = (q.M + BM - 1) / BM;
+    hipLaunchKernelGGL((gemm_kernel<T, AKM, BKM, E>), dim3(nbm * nbn * (q.split_k > 1 ? q.split_k : 1)), dim3(NT), lds, st, q);
 }
 
 template <typename T, bool AKM, bool BKM>
 int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
-    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     const int split = p.split_k > 1 ? p.split_k : 1;
-    dim3 grid(nbm * nbn * split);
     switch (epi) {
-        case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(grid, st, p); break;
-        case DIC_EPI_BIAS_GELU: launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(grid, st, p); break;
-        case DIC_EPI_GELU_BWD: launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(grid, st, p); break;
-        case DIC_EPI_CE_PARTIAL: launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(grid, st, p); break;
-        case DIC_EPI_CE_DLOGITS: launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(grid, st, p); break;
+        case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(st, p); break;
+        case DIC_EPI_BIAS_GELU: launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(st, p); break;
+        case DIC_EPI_GELU_BWD: launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(st, p); break;
+        case DIC_EPI_CE_PARTIAL: launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(st, p); break;
+        case DIC_EPI_CE_DLOGITS: launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(st, p); break;
         default: dic_set_error("dic_gemm: unknown epilogue"); return 1002;
     }
     if (split > 1) {
@@ -747,6 +802,9 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD))
         DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && p.ldaux % 8 == 0, "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
     if (dtype == DIC_BF16) DIC_REQUIRE(p.ldc % 4 == 0 && (p.R == nullptr || p.ldr % 4 == 0), "dic_gemm: ldc/ldr must be multiples of 4");
+    if (p.tile == 256)
+        DIC_REQUIRE(dtype == DIC_BF16 && epi != DIC_EPI_CE_PARTIAL && (!a_km || p.M % 256 == 0) && (!b_km || p.N % 256 == 0 || p.N % 8 == 0),
+                    "dic_gemm: tile=256 is a bf16 option (not for CE_PARTIAL); k-major A needs M % 256 == 0");
     if (p.colsum_out)
         DIC_REQUIRE(dtype == DIC_BF16 && a_km && b_km && epi == DIC_EPI_AFFINE && p.out_f32 && p.M % 4 == 0,
                     "dic_gemm: colsum_out (fused bias gradient) is available on bf16 weight-gradient GEMMs (k-major A and B, fp32 output)");

@@ -43,7 +43,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -52,16 +52,44 @@ class Ops:
         g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
         g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
         g.split_k, g.split_ws, g.colsum_out = split_k, split_ws, colsum_out
+        dt = self.dt if dtype is None else dtype
+        if tile is None:
+            tile = choose_tile(M, N, split_k, epi) if (dt == DIC_BF16 and epi != EPI_CE_PARTIAL and (not a_km or M % 256 == 0)) else 128
+        g.tile = tile
         _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
 
 
-def pick_split_k(M, N, K, bk=64, target_blocks=512, max_split=32):
-    """dW GEMMs have few output tiles (768x768 -> 36) but a long contraction (all tokens): cut K so that about two
-    workgroups per CU exist (256 CUs x 2 resident), each slice keeping >= 8 K-steps."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+import os as _os
+
+_TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "auto" (A/B switch for measurements)
+N_CU = 256
+
+
+def choose_tile(M, N, split_k=1, epi=EPI_AFFINE):
+    """256x256 workgroup tiles (8 waves, one workgroup per CU) pull half the bytes per flop through L2 of the 128x128 ones
+    (measured: 1.16-1.26 vs 0.83-0.95 PFLOP/s on large squares), but there are 4x fewer of them and their epilogue is not hidden
+    behind a second resident workgroup: use them for the plain-epilogue GEMMs when they still give every CU work; the two
+    GELU epilogues (two 113 MB outputs / one extra input) measured faster on 128-tiles (158/164 vs 165/175 us)."""
+    if _TILE_MODE in ("128", "256"):
+        return int(_TILE_MODE) if (M >= 256 and N >= 256) else 128
+    if M < 256 or N < 256 or epi in (EPI_BIAS_GELU, EPI_GELU_BWD):
+        return 128
+    units = ((M + 255) // 256) * ((N + 255) // 256) * max(split_k, 1)
+    return 256 if units >= int(0.75 * N_CU) else 128
+
+
+def pick_split_k(M, N, K, bk=64, max_split=32):
+    """dW GEMMs have few output tiles (768x768 -> 36) but a long contraction (all tokens): cut K so that one round of resident
+    workgroups covers the launch (2 per CU for 128-tiles, 1 per CU for 256-tiles), each slice keeping >= 8 K-steps.
+    Measured at K = 18432: 768x768 -> 128-tiles x14 (468 TF) beats 256-tiles x28 (404); 3072x768 -> 256-tiles x7 (836 TF)
+    beats 128-tiles x3 (781); 2304x768 -> 256-tiles x9 (736) ~ 128-tiles x4 (731).  Returns (split_k, tile)."""
     nk = (K + bk - 1) // bk
-    s = max(1, min(max_split, target_blocks // max(tiles, 1), nk // 8))
-    return s
+    big = _TILE_MODE != "128" and M % 256 == 0 and N >= 256 and M * N >= 2304 * 768
+    if _TILE_MODE == "256" and M % 256 == 0 and N >= 256:
+        big = True
+    tile, resident = (256, N_CU) if big else (128, 2 * N_CU)
+    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
+    return max(1, min(max_split, resident // max(tiles, 1), nk // 8)), tile
 
 
 class Denoiser:
@@ -291,11 +319,14 @@ class Denoiser:
         def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
             bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum)."""
-            sk = pick_split_k(M, N, T, 64 if self.bf16 else 32)
+            sk, tile = pick_split_k(M, N, T, 64 if self.bf16 else 32)
+            if not self.bf16:
+                tile = 128
             while sk > 1 and sk * (M * N + M) > skcap:
                 sk -= 1
             cs = P.ptr(bias_slot, "G") if (bias_slot is not None and self.bf16) else 0
-            o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0, colsum_out=cs)
+            o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0, colsum_out=cs,
+                   tile=tile)
             if bias_slot is not None and not self.bf16:
                 colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
 

@@ -21,7 +21,7 @@ def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, **extra)
     aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2) else None
     bias = torch.randn(N, device="cuda") if epi in (0, 1) and not out_f32 else None
     ws = torch.empty(split * M * N, device="cuda") if split > 1 else None
-    g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N,
+    g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, tile=int(os.environ.get("TILE", "128")),
            bias=bias.data_ptr() if bias is not None else 0, aux=aux.data_ptr() if aux is not None else 0, ldaux=N, out_f32=out_f32,
            split_k=split, split_ws=ws.data_ptr() if ws is not None else 0)
     st = torch.cuda.current_stream().cuda_stream
@@ -39,7 +39,7 @@ def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, **extra)
 
 
 if __name__ == "__main__" and len(sys.argv) == 1:
-    print("DIC_GEMM =", os.environ.get("DIC_GEMM", "3"))
+    print("TILE =", os.environ.get("TILE", "128"))
     run("fwd qkv        (KC,KC) bias", T, 3 * D, D, 0, 0)
     run("fwd out-proj   (KC,KC) bias", T, D, D, 0, 0)
     run("fwd ffn1       (KC,KC) gelu", T, F, D, 0, 0, epi=1)
@@ -47,11 +47,11 @@ if __name__ == "__main__" and len(sys.argv) == 1:
     run("dX  ffn2->du   (KC,KM) gelu'", T, F, D, 0, 1, epi=2)
     run("dX  ffn1->dsa  (KC,KM)", T, D, F, 0, 1)
     run("dX  qkv->dh    (KC,KM)", T, D, 3 * D, 0, 1)
-    for sp in (1, 4, 8, 14):
+    for sp in (1, 4, 8, 14, 28):
         run("dW  out-proj   (KM,KM) f32", D, D, T, 1, 1, split=sp, out_f32=1)
-    for sp in (1, 3, 4):
+    for sp in (1, 3, 4, 7):
         run("dW  ffn1       (KM,KM) f32", F, D, T, 1, 1, split=sp, out_f32=1)
-    for sp in (1, 4):
+    for sp in (1, 4, 9):
         run("dW  qkv        (KM,KM) f32", 3 * D, D, T, 1, 1, split=sp, out_f32=1)
     run("rounding dX    (KC,KM) f32", 16384, D, V, 0, 1, out_f32=1)
     run("square 4096    (KC,KC)", 4096, 4096, 4096, 0, 0)

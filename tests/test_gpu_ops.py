@@ -116,6 +116,43 @@ def test_gemm_split_k_weight_gradient(L, dtype, split):
     assert relerr(Cd, 2 * ref) < 2e-6
 
 
+@pytest.mark.parametrize("layout", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_tile256_all_layouts_and_epilogues(L, layout):
+    """The 256x256 / 8-wave geometry of the bf16 kernel: ragged M, N = 3 tiles, bias + residual, GELU pair, split-K + fused bias grad."""
+    a_km, b_km = layout
+    M, N, K = (512 if a_km else 600), 768, 320 + (37 if (a_km and b_km) else 0)
+    g = torch.Generator().manual_seed(7 + a_km + 2 * b_km)
+    A, B = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3
+    bias, Rr = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd, Rd = dev(A.t() if a_km else A, torch.bfloat16), dev(B.t() if b_km else B, torch.bfloat16), dev(Rr, torch.bfloat16)
+    acc = (Ad.float().cpu().double().t() if a_km else Ad.float().cpu().double()) @ (Bd.float().cpu().double() if b_km else Bd.float().cpu().double().t())
+    lda, ldb = Ad.shape[1], Bd.shape[1]
+    Cd = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, a_km, b_km, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, bias=p(dev(bias)), R=p(Rd), ldr=N, tile=256)
+    assert relerr(Cd.float(), acc + bias.double() + Rd.float().cpu().double()) < 6e-3
+    Cf = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    gemm(L, BF16, a_km, b_km, 0, A=p(Ad), B=p(Bd), C=p(Cf), M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, out_f32=1, tile=256)
+    assert relerr(Cf, acc) < 2e-6
+    if not a_km:
+        U = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        G_ = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        gemm(L, BF16, 0, b_km, 1, A=p(Ad), B=p(Bd), C=p(G_), M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, bias=p(dev(bias)), aux=p(U), ldaux=N, tile=256)
+        assert relerr(U.float(), acc + bias.double()) < 1e-2 and relerr(G_.float(), R.gelu(U.float().cpu().double())) < 1e-2
+        Dd = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        gemm(L, BF16, 0, b_km, 2, A=p(Ad), B=p(Bd), C=p(Dd), M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, aux=p(U), ldaux=N, tile=256)
+        uu = U.float().cpu().double().requires_grad_(True)
+        R.gelu(uu).sum().backward()
+        assert relerr(Dd.float(), acc * uu.grad) < 1e-2
+    else:
+        for split in (1, 3):
+            cs = torch.full((M,), float("nan"), device="cuda")
+            ws = torch.zeros(split * (M * N + M), device="cuda")
+            Cs = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+            gemm(L, BF16, 1, 1, 0, A=p(Ad), B=p(Bd), C=p(Cs), M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, out_f32=1, split_k=split, split_ws=p(ws),
+                 colsum_out=p(cs), tile=256)
+            assert relerr(Cs, acc) < 2e-6 and relerr(cs, Ad.float().cpu().double().sum(0)) < 2e-6
+
+
 @pytest.mark.parametrize("split", [1, 3])
 def test_gemm_fused_bias_gradient(L, split):
     """bf16 weight-gradient GEMM also returns colsum(dY) (the bias gradient) from the LDS-resident A tiles."""
