@@ -114,10 +114,22 @@ __device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, i
         int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, slot = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
+    // Logical order (what one XCD's L2 sees over time), chosen from the rocprof FETCH_SIZE of the first version (the rounding
+    // GEMM pulled 6 GB through the fabric for 72 MB of operands: with n fastest, every workgroup of a row-panel streamed a
+    // different 196 KB slice of the 47 MB vocabulary matrix):
+    //   * K-slice slowest: the workgroups resident together share one K range, hence the same A and B slices;
+    //   * inside a K-slice, column groups of 8 tiles, m fastest across the group: the ~64 workgroups an XCD runs at once form
+    //     an 8x8 patch (8 A panels + 8 B panels ~ 3 MB, inside the 4 MB L2) instead of a 1x64 strip (65 panels).
     TileId t;
-    t.kz = pid % split;
-    const int tile = pid / split;
-    t.bm = tile / nbn; t.bn = tile % nbn; t.nbn = nbn;
+    const int ntiles = nbm * nbn;
+    t.kz = pid / ntiles;
+    const int lin = pid - t.kz * ntiles;
+    constexpr int GW = 8;
+    const int grp = lin / (GW * nbm), rem = lin - grp * (GW * nbm);
+    const int w = min(GW, nbn - grp * GW);
+    t.bm = rem / w;
+    t.bn = grp * GW + (rem - t.bm * w);
+    t.nbn = nbn;
     const int nk = (p.K + BK - 1) / BK, per = (nk + split - 1) / split;
     t.kt0 = t.kz * per;
     t.kt1 = min(nk, t.kt0 + per);
