@@ -283,8 +283,26 @@ def run_sampling_case(name, *, B, L, n_layers, steps, vocab=30522, wseed=0, dsee
     print(f"[{name}] ids[0]={indexes[0].tolist()} uniq shape {tuple(uniq.shape)} min margin {float((top2[...,0]-top2[...,1]).min()):.3e}")
 
 
+def run_lr_tables():
+    """Per-epoch learning-rate tables `lrs` (ref :63-70 cosine_annealing, :451-456) from the reference's own statements."""
+    tree = ast.parse(open(REF).read(), REF)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cosine_annealing"][0]
+    ifs = [n for n in tree.body if isinstance(n, ast.If) and 451 <= n.lineno <= 456]
+    out = {}
+    for name, sched, epochs in (("linspace5", torch.linspace, 5), ("linspace15", torch.linspace, 15), ("logspace15", torch.logspace, 15),
+                                ("cosine", None, 15)):
+        ns = {"torch": torch, "math": math, "LEARNING_RATE": 1e-4, "END_LEARNING_RATE": 5e-5, "EPOCH_NUM": epochs}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), REF, "exec"), ns)
+        ns["SCHEDULER"] = sched if sched is not None else ns["cosine_annealing"]
+        exec(compile(ast.Module(body=ifs, type_ignores=[]), REF, "exec"), ns)
+        out[name] = ns["lrs"].numpy()
+    np.savez(os.path.join(OUT, "lr_tables.npz"), **out)
+    print("[lr_tables]", {k: v[:2] for k, v in out.items()})
+
+
 def main():
     torch.manual_seed(0)
+    run_lr_tables()
     torch.set_num_threads(8)
     # A: reference defaults shrunk (cosine T=1000, concat, L1, no CFG)
     run_case("base_b4s3l16", B=4, S=3, L=16, n_layers=2)
