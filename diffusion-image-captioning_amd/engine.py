@@ -125,6 +125,8 @@ class Denoiser:
         self._seed = 0x5EED0000 + seed
         self._saved = None
         self._pending = False
+        self._side = None
+        self.wgrad_stream_enabled = True
         self.rank_rows_forced = True     # CFG forces rows 0/1 to unguided/guided (ref :408-409); DP: rank 0 only
 
     # ------------------------------------------------------------------ frozen embedding / rounding head
@@ -145,6 +147,11 @@ class Denoiser:
         self.W_lm = torch.zeros(self.vpad, 768, dtype=torch.float32, device=self.device)
         self.W_lm[:self.vocab].copy_(W)
         self.W_lm_c = self.W_lm.to(torch.bfloat16).contiguous() if self.bf16 else self.W_lm
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def refresh_shadows(self):
         """bf16 copies of the parameters for the MFMA operands (dic_adamw keeps them fresh itself)."""
@@ -218,8 +225,11 @@ class Denoiser:
         # backward scratch (shared by all layers)
         ws["dx_out"] = f(N, Tk, D)
         ws["dHa"], ws["dHb"] = e(T, D), e(T, D)
-        ws["dy"], ws["dyd"], ws["dsa"], ws["dy1"], ws["dctx"] = e(T, D), e(T, D), e(T, D), e(T, D), e(T, D)
-        ws["du"], ws["dqkv"] = e(T, Hd), e(T, 3 * D)
+        # gradients that a weight-gradient GEMM consumes exist twice (layer parity): those GEMMs run on a second stream and may
+        # still be reading layer i+1's copy while the main stream produces layer i's
+        ws["dy"], ws["dyd"], ws["dy1"] = [e(T, D), e(T, D)], [e(T, D), e(T, D)], [e(T, D), e(T, D)]
+        ws["du"], ws["dqkv"] = [e(T, Hd), e(T, Hd)], [e(T, 3 * D), e(T, 3 * D)]
+        ws["dsa"], ws["dctx"] = e(T, D), e(T, D)
         ws["dy0"] = f(N, Tk, D)
         ws["partial"] = f(NPART, 3 * D)
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
@@ -316,6 +326,27 @@ class Denoiser:
         skw = _p(ws["splitk"])
         skcap = ws["splitk"].numel()
 
+        # ---- weight gradients on a second stream.  dW = dY^T X depends only on dY and on activations saved by the forward, never
+        # feeds the dX chain, and is MFMA-bound, while the chain it leaves behind alternates MFMA-bound GEMMs with HBM-bound
+        # LayerNorm / attention kernels and store-heavy epilogues: letting the two streams share the CUs overlaps those phases.
+        main = torch.cuda.current_stream()
+        use_side = self.bf16 and _os.environ.get("DIC_WGRAD_STREAM", "1") == "1" and self.wgrad_stream_enabled
+        side = self._side_stream() if use_side else None
+        done = {}                                     # layer -> event on the side stream after that layer's dW launches
+
+        def on_side(fn):
+            if not use_side:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            o.stream = side.cuda_stream
+            try:
+                fn()
+            finally:
+                o.stream = st
+
         def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
             bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum)."""
@@ -325,46 +356,73 @@ class Denoiser:
             while sk > 1 and sk * (M * N + M) > skcap:
                 sk -= 1
             cs = P.ptr(bias_slot, "G") if (bias_slot is not None and self.bf16) else 0
-            o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0, colsum_out=cs,
-                   tile=tile)
+
+            def launch():
+                o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0,
+                       colsum_out=cs, tile=tile)
+            on_side(launch)
             if bias_slot is not None and not self.bf16:
                 colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
 
         def colsum(in_dtype, src, rows, cols, ld, dst, acc=0):
             _lib.check(lib.dic_colsum(in_dtype, src, rows, cols, ld, dst, acc, csw, st), "colsum")
 
+        def finish_layer(j):
+            """dW launches of layer j are queued: mark it, and hand the layer's gradient slice to the data-parallel reducer."""
+            if use_side:
+                done[j] = torch.cuda.Event()
+                done[j].record(side)
+            if layer_done is not None and j < self.n_layers:
+                if use_side:
+                    ev = torch.cuda.Event()
+                    ev.record(main)                   # the LayerNorm / bias gradients of this layer come from the main stream
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        layer_done(j)
+                else:
+                    layer_done(j)
+
         # head: GELU+LN backward, vocab_transform
-        _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(ws["dy"]), part, NPART, T, D, st), "gelu_ln_bwd")
+        nl = self.n_layers
+        sp = nl & 1
+        dyb = ws["dy"][sp]
+        _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), part, NPART, T, D, st), "gelu_ln_bwd")
         colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr("vln_g", "G"))                      # [vln_g | vln_b | bvt]
-        wgrad(_p(ws["dy"]), _p(ws["h"][-1]), "Wvt", D, D, D, D)
+        wgrad(_p(dyb), _p(ws["h"][-1]), "Wvt", D, D, D, D)
+        finish_layer(nl)
         dH, dHn = ws["dHa"], ws["dHb"]
-        o.gemm(_p(ws["dy"]), P.ptr("Wvt", wsrc), _p(dH), T, D, D, D, D, D, b_km=1)
-        for i in reversed(range(self.n_layers)):
+        o.gemm(_p(dyb), P.ptr("Wvt", wsrc), _p(dH), T, D, D, D, D, D, b_km=1)
+        for i in reversed(range(nl)):
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
             use_drop = ph > 0.0
+            sp = i & 1
+            if (i + 2) in done:
+                main.wait_event(done[i + 2])          # the dW GEMMs of layer i+2 have finished with this parity's buffers
+            dy_, dyd_, dy1_, du_, dqkv_ = ws["dy"][sp], ws["dyd"][sp], ws["dy1"][sp], ws["du"][sp], ws["dqkv"][sp]
             # output_layer_norm backward; bias grad of lin2 folded in
-            _lib.check(lib.dic_ln_bwd(self.dt, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(ws["dy"]),
-                                      _p(ws["dyd"]) if use_drop else 0, ph, seed + 4 * i + 2, part, NPART, T, D, st), "ln_bwd")
+            _lib.check(lib.dic_ln_bwd(self.dt, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
+                                      _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, part, NPART, T, D, st), "ln_bwd")
             colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln2g", "G"))              # [ln2g | ln2b | b2]
-            dyd = ws["dyd"] if use_drop else ws["dy"]
+            dyd = dyd_ if use_drop else dy_
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
-            o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(ws["du"]), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
-            wgrad(_p(ws["du"]), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                           # dW1 (+ db1)
-            o.gemm(_p(ws["du"]), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(ws["dy"]), ldr=D)  # + residual
+            o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
+            wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                                # dW1 (+ db1)
+            o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
-            _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(ws["dy1"]),
+            _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
                                       0, 0.0, 0, part, NPART, T, D, st), "ln_bwd")
             colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln1g", "G"))              # [ln1g | ln1b | bo]
-            wgrad(_p(ws["dy1"]), _p(Lw["ctx"]), pre + "Wo", D, D, D, D)
-            o.gemm(_p(ws["dy1"]), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
-            _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(ws["dqkv"]), N, Tk, self.n_heads, 64, pa,
+            wgrad(_p(dy1_), _p(Lw["ctx"]), pre + "Wo", D, D, D, D)
+            o.gemm(_p(dy1_), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
+            _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(dqkv_), N, Tk, self.n_heads, 64, pa,
                                         seed + 4 * i + 1, st), "attn_bwd")
-            wgrad(_p(ws["dqkv"]), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D, bias_slot=pre + "bqkv")                      # dWqkv (+ dbqkv)
-            o.gemm(_p(ws["dqkv"]), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(ws["dy1"]), ldr=D)
+            wgrad(_p(dqkv_), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D, bias_slot=pre + "bqkv")                           # dWqkv (+ dbqkv)
+            o.gemm(_p(dqkv_), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(dy1_), ldr=D)
             dH, dHn = dHn, dH
-            if layer_done is not None:
-                layer_done(i)
+            finish_layer(i)
+        if use_side:
+            main.wait_stream(side)                    # every weight gradient is in G before anything downstream (AdamW, all-reduce tail)
         # embeddings LayerNorm + fusion backward
         mode = ws["mode"]
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
