@@ -37,7 +37,7 @@ class GemmParams(C.Structure):
         ("out_f32", C.c_int), ("accumulate", C.c_int),
         ("tgt", C.c_void_p), ("lse", C.c_void_p), ("partial", C.c_void_p), ("tgt_logit", C.c_void_p),
         ("ce_rows_a", C.c_int), ("ce_scale_a", C.c_float), ("ce_scale_b", C.c_float),
-        ("split_k", C.c_int), ("split_ws", C.c_void_p), ("tile", C.c_int), ("colsum_out", C.c_void_p),
+        ("split_k", C.c_int), ("split_ws", C.c_void_p), ("tile", C.c_int), ("cu_cap", C.c_int), ("colsum_out", C.c_void_p),
     ]
 
 

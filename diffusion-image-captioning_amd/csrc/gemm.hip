@@ -703,8 +703,10 @@ void launch_bf16(const DicGemmParams& q, hipStream_t st) {
         attr_set = true;
     }
     const int units = ((q.N + G::BN - 1) / G::BN) * ((q.M + G::BM - 1) / G::BM) * (q.split_k > 1 ? q.split_k : 1);
-    const int resident = device_cus() * (160 * 1024 / G::LDS);       // co-resident workgroups (LDS-limited): 2 per CU at 64 KB, 1 at 128 KB
-    const int grid = (persist_enabled() && units > resident) ? resident : units;
+    int cus = device_cus();
+    if (q.cu_cap > 0 && q.cu_cap < cus) cus = q.cu_cap;             // spatial share of the chip (two streams interleaving two half-batches)
+    const int resident = cus * (160 * 1024 / G::LDS);                // co-resident workgroups (LDS-limited): 2 per CU at 64 KB, 1 at 128 KB
+    const int grid = ((persist_enabled() || q.cu_cap > 0) && units > resident) ? resident : units;
     hipLaunchKernelGGL((gemm_bf16_kernel<C, AKM, BKM, E>), dim3(grid), dim3(G::NTH), G::LDS, st, q);
 }
 

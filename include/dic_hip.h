@@ -65,6 +65,8 @@ typedef struct DicGemmParams {
                                    slices write fp32 partial tiles to split_ws [split_k][M*N (+M)], then folded into C in fixed order */
     int tile;                   /* 0/128: 128x128 workgroup tiles; 256: 256x256 tiles, 8 waves (bf16, not CE_PARTIAL) -- half the
                                    L2->LDS traffic per flop; worth it when M*N/65536 tiles still fill the 256 CUs */
+    int cu_cap;                 /* >0: cap the persistent grid at this many CUs' worth of workgroups (bf16 kernel), leaving the rest of the chip
+                                   to a kernel on another stream */
     float* colsum_out;          /* bf16 (k-major,k-major) fp32-output GEMMs only: out[m] = sum_k A(m,k) -- the bias gradient that
                                    goes with a weight gradient dW = dY^T X (hf nn.Linear backward), taken from the LDS-resident A tile */
 } DicGemmParams;

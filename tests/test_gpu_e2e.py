@@ -293,3 +293,95 @@ def test_sampling_is_batch_permutation_equivariant_at_config4_size():
     ids_p = dic.sample(model, img[perm], steps=4, start=start[perm])
     assert torch.equal(ids[perm], ids_p)
     assert ids.shape == (Bn, L) and int(ids.min()) >= 0 and int(ids.max()) < V
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def _tiny_cfg(B, S, L, V, **kw):
+    base = dict(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5, LOSS_FUNC="series_sum_sample_mean",
+                CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True, VOCAB_SIZE=V, USE_X_T_LOSS=True, USE_X_1_LOSS=True,
+                USE_PROB_LOSS=True)
+    base.update(kw)
+    dic.cfg.update(**base)
+    dic.set_alpha_cumprod(None)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_minimum_batch_all_padding_and_vocab_edges(dtype):
+    """B=1, S=1 (two sequences in the whole step: every GEMM is a single ragged tile), a caption that is ALL padding (only the CLIP image key
+    is attendable), ids at both ends of the vocabulary."""
+    B, S, L, V = 1, 1, 16, 1003
+    _tiny_cfg(B, S, L, V)
+    E = synth.vocab_embedding(V, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 4).items()}
+    x["attention_mask"][:] = 0
+    x["input_ids"][0, 0], x["input_ids"][0, 1] = 0, V - 1
+    t = torch.tensor([[[99]]])
+    nz = [torch.from_numpy(synth.noise((B, L, 768), 3, f"eps{i}")) for i in range(2)]
+    model = dic.DistilBertModel(E, E, config=dict(n_layers=2, dropout=0.0, attention_dropout=0.0), dtype=dtype)
+    model.load_state(synth.denoiser_state(2, 0))
+    got = np.array([f(v) for v in dic.train_func(model, dic.AdamW(model.parameters(), lr=1e-4), x, t=t, noises=nz)])
+    rcfg = R.Config(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=2, vocab=V)
+    om = R.build(rcfg, synth.denoiser_state(2, 0), E)
+    ref = np.array([float(v) for v in R.train_func(om, R.AdamW(om.parameters(), lr=1e-4), {k: v.cpu() for k, v in x.items()}, t=t, noises=nz)])
+    np.testing.assert_allclose(got, ref, rtol=1e-4 if dtype == "fp32" else 5e-3)
+
+
+def test_loss_switches_and_direct_loss_call_signature():
+    """`loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, loss_func)` called the way the reference's train_func calls it,
+    with the USE_* switches (ref :112-114, 416-443) and a loss function passed as a callable named like the reference's."""
+    B, S, L, V = 3, 2, 16, 800
+    _tiny_cfg(B, S, L, V)
+    E = synth.vocab_embedding(V, 768, 0)
+    model = dic.DistilBertModel(E, E, config=dict(n_layers=1, dropout=0.0, attention_dropout=0.0), dtype="fp32")
+    model.load_state(synth.denoiser_state(1, 0))
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 6).items()}
+    t = torch.from_numpy(synth.timesteps(S, 100, 1)).cuda()
+    x_0 = model.embedding(x["input_ids"])
+    nz = [torch.from_numpy(synth.noise((B, L, 768), 8, f"eps{i}")) for i in range(2)]
+    x_t, x_tgt = dic.generate_diffuse_pair(x_0, t, noises=(nz[0], None))
+    assert x_tgt is x_0 and x_t.shape == (S * B, L, 768)
+    x_1 = dic.diffuse_t(x_0, torch.ones(1, dtype=torch.int64), noise=nz[1])
+
+    def series_sum_sample_mean(a, b):          # same __name__ as the reference's LOSS_FUNC
+        raise AssertionError("never called: the name selects the HIP loss kernel")
+    with torch.no_grad():
+        full = [f(v) for v in dic.loss(model, x_t, x_1, None, x_0, x["image_clip"], x["text_clip"], x["attention_mask"], x["input_ids"], series_sum_sample_mean)]
+        dic.cfg.update(USE_X_T_LOSS=False, USE_PROB_LOSS=False)
+        try:
+            part = [f(v) for v in dic.loss(model, x_t, x_1, None, x_0, x["image_clip"], x["text_clip"], x["attention_mask"], x["input_ids"], "series_sum_sample_mean")]
+        finally:
+            dic.cfg.update(USE_X_T_LOSS=True, USE_PROB_LOSS=True)
+    assert part[0] == 0.0 and part[2] == 0.0 and part[1] == pytest.approx(full[1], rel=1e-6)
+    rcfg = R.Config(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=1, vocab=V)
+    om = R.build(rcfg, synth.denoiser_state(1, 0), E, requires_grad=False)
+    ref = R.loss(om, x_t.cpu(), x_1.cpu(), None, x_0.cpu(), x["image_clip"].cpu(), x["text_clip"].cpu(), x["attention_mask"].cpu(), x["input_ids"].cpu())
+    np.testing.assert_allclose(full, [float(v) for v in ref], rtol=1e-4)
+    # shape errors surface as AssertionError, as in the reference (ref :396-400)
+    with pytest.raises(AssertionError):
+        dic.loss(model, x_t[:-1], x_1, None, x_0, x["image_clip"], x["text_clip"], x["attention_mask"], x["input_ids"], "series_sum_sample_mean")
+    with pytest.raises(NotImplementedError):
+        dic.loss(model, x_t, x_1, None, x_0, x["image_clip"], x["text_clip"], x["attention_mask"], x["input_ids"], "huber")
+    # API parity of the small pieces
+    logits = model.lm_head(x_0)
+    assert logits.shape == (B, L, V) and torch.equal(logits.argmax(-1).cpu(), x["input_ids"].cpu())     # tied head: E[id] . E^T peaks at id
+
+
+def test_maximum_sequence_length_64_tokens():
+    """L = 62 (+2 CLIP rows = 64 tokens): the attention kernels' upper bound."""
+    B, S, L, V = 2, 1, 62, 600
+    _tiny_cfg(B, S, L, V)
+    E = synth.vocab_embedding(V, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 7).items()}
+    t = torch.tensor([[[10]]])
+    nz = [torch.from_numpy(synth.noise((B, L, 768), 2, f"eps{i}")) for i in range(2)]
+    rcfg = R.Config(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=1, vocab=V, CLASSIFIER_FREE_WEIGHT=0.5)
+    dic.cfg.update(CLASSIFIER_FREE_WEIGHT=0.5)
+    u = torch.tensor([[0.9], [0.9]])
+    om = R.build(rcfg, synth.denoiser_state(1, 0), E)
+    ref = np.array([float(v) for v in R.train_func(om, R.AdamW(om.parameters(), lr=1e-4), {k: v.cpu() for k, v in x.items()}, t=t, noises=nz, cfg_uniform=u)])
+    for dtype, tol in (("fp32", 1e-4), ("bf16", 5e-3)):
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=1, dropout=0.0, attention_dropout=0.0), dtype=dtype)
+        model.load_state(synth.denoiser_state(1, 0))
+        got = np.array([f(v) for v in dic.train_func(model, dic.AdamW(model.parameters(), lr=1e-4), x, t=t, noises=nz, cfg_uniform=u)])
+        np.testing.assert_allclose(got, ref, rtol=tol)
+    dic.cfg.update(CLASSIFIER_FREE_WEIGHT=0.0)
