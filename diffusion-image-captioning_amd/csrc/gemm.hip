@@ -461,6 +461,54 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
     }
 }
 
+// CE_PARTIAL for the bf16 geometries: every wave owns (BM/WM) rows x (BN/WN) = 64 columns of the tile and emits one
+// (max, sum exp, first argmax) record per row; record slot = bn * WN + wn, so a row has nbn * WN records for ce_combine.
+template <class C>
+__device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN], const DicGemmParams& p, int m0, int n0, int wm,
+                                                    int wn, int lane, int bn, int nbn) {
+    using G = Geo<C>;
+    static_assert(G::BN / G::WN == 64 && G::FN == 4, "one 64-column record per wave");
+    const int g = lane >> 4, t = lane & 15;
+    const int np = G::WN * nbn;
+#pragma unroll
+    for (int i = 0; i < G::FM; ++i) {
+        const int m = m0 + wm * (G::BM / G::WM) + i * 16 + t;
+        const long long tg = (m < p.M && p.tgt) ? p.tgt[m] : -1;
+        float mx = -INFINITY;
+        int ix = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + j * 16 + g * 4 + r;
+                const float x = acc[i][j][r];
+                if (n < p.N) {
+                    if (x > mx) { mx = x; ix = n; }
+                    if ((long long)n == tg) p.tgt_logit[m] = x;
+                }
+            }
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + j * 16 + g * 4 + r;
+                if (n < p.N) sm += __expf(acc[i][j][r] - mx);
+            }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {       // merge the 4 lanes (g = 0..3) that share row m
+            float mx2 = __shfl_xor(mx, o, 64), sm2 = __shfl_xor(sm, o, 64);
+            int ix2 = __shfl_xor(ix, o, 64);
+            float M = fmaxf(mx, mx2);
+            float s1 = (mx == -INFINITY) ? 0.f : sm * __expf(mx - M);
+            float s2 = (mx2 == -INFINITY) ? 0.f : sm2 * __expf(mx2 - M);
+            ix = (mx > mx2) ? ix : (mx2 > mx) ? ix2 : min(ix, ix2);
+            mx = M; sm = s1 + s2;
+        }
+        if (g == 0 && m < p.M) *(float4*)(p.partial + ((size_t)m * np + bn * G::WN + wn) * 4) = make_float4(mx, sm, __int_as_float(ix), 0.f);
+    }
+}
+
 // =====================================================================================================
 // bf16 kernel: operand tiles go HBM/L2 -> LDS directly with `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging VGPRs and
 // no ds_write pass (the register-staged v1 spent ~830 of every ~1340 LDS cycles per K-step on ds_write_b128); the next
@@ -645,7 +693,7 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
             }
         }
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
-            if constexpr (G::BM == 128) epilogue<T, EPI>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tl.bn, tl.nbn);
+            epilogue_ce_partial<C>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tl.bn, tl.nbn);
         } else {
             epilogue_lds<C, EPI>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tid, smem);
         }
@@ -714,9 +762,7 @@ template <typename T, bool AKM, bool BKM, int E>
 void launch_one(hipStream_t st, const DicGemmParams& q) {
     if constexpr (sizeof(T) == 2) {
         if (!bf16_on_v1()) {
-            if constexpr (E != DIC_EPI_CE_PARTIAL) {
-                if (q.tile == 256) { launch_bf16<T256, AKM, BKM, E>(q, st); return; }
-            }
+            if (q.tile == 256) { launch_bf16<T256, AKM, BKM, E>(q, st); return; }
             launch_bf16<T128, AKM, BKM, E>(q, st);
             return;
         }
@@ -817,8 +863,8 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
         DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && p.ldaux % 8 == 0, "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
     if (dtype == DIC_BF16) DIC_REQUIRE(p.ldc % 4 == 0 && (p.R == nullptr || p.ldr % 4 == 0), "dic_gemm: ldc/ldr must be multiples of 4");
     if (p.tile == 256)
-        DIC_REQUIRE(dtype == DIC_BF16 && epi != DIC_EPI_CE_PARTIAL && (!a_km || p.M % 256 == 0) && (!b_km || p.N % 256 == 0 || p.N % 8 == 0),
-                    "dic_gemm: tile=256 is a bf16 option (not for CE_PARTIAL); k-major A needs M % 256 == 0");
+        DIC_REQUIRE(dtype == DIC_BF16 && !(epi == DIC_EPI_CE_PARTIAL && bf16_on_v1()) && (!a_km || p.M % 256 == 0) && (!b_km || p.N % 256 == 0 || p.N % 8 == 0),
+                    "dic_gemm: tile=256 is a bf16 option of the LDS-DMA kernel; k-major A needs M % 256 == 0");
     if (p.colsum_out)
         DIC_REQUIRE(dtype == DIC_BF16 && a_km && b_km && epi == DIC_EPI_AFFINE && p.out_f32 && p.M % 4 == 0,
                     "dic_gemm: colsum_out (fused bias gradient) is available on bf16 weight-gradient GEMMs (k-major A and B, fp32 output)");

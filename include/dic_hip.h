@@ -58,7 +58,7 @@ typedef struct DicGemmParams {
     int out_f32; int accumulate;
     const int64_t* tgt;         /* [M] target ids (CE) */
     const float* lse;           /* [M] logsumexp (CE_DLOGITS) */
-    float* partial;             /* [M][2*ceil(N/128)][4] (CE_PARTIAL) */
+    float* partial;             /* [M][np][4] (CE_PARTIAL); np = 2*ceil(N/128) for 128-tiles, 4*ceil(N/256) for tile=256 */
     float* tgt_logit;           /* [M] (CE_PARTIAL) */
     int ce_rows_a; float ce_scale_a, ce_scale_b;
     int split_k; void* split_ws;/* >1: K is cut into split_k slices (fills the chip when M*N has few tiles -- the dW GEMMs);

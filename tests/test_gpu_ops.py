@@ -224,9 +224,9 @@ def test_gemm_gelu_epilogues_and_dropout(L, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ rounding head
-@pytest.mark.parametrize("dtype,V", [(F32, 30522), (BF16, 30522), (F32, 1000)])
-def test_rounding_ce_partial_combine_and_backward(L, dtype, V):
-    M, K = 40, 768
+@pytest.mark.parametrize("dtype,V,tile", [(F32, 30522, 128), (BF16, 30522, 128), (F32, 1000, 128), (BF16, 30522, 256), (BF16, 1000, 256)])
+def test_rounding_ce_partial_combine_and_backward(L, dtype, V, tile):
+    M, K = (40 if tile == 128 else 300), 768
     g = torch.Generator().manual_seed(V + dtype)
     x = torch.randn(M, K, generator=g)
     W = torch.randn(V, K, generator=g) * 0.05
@@ -238,13 +238,13 @@ def test_rounding_ce_partial_combine_and_backward(L, dtype, V):
     Wp = torch.zeros(vpad, K)
     Wp[:V] = W
     xd, Wd, td = dev(x, DT[dtype]), dev(Wp, DT[dtype]), dev(tgt)
-    npart = 2 * ((V + 127) // 128)
+    npart = 2 * ((V + 127) // 128) if tile == 128 else 4 * ((V + 255) // 256)      # one record per 64 columns of every tile
     part = torch.zeros(M, npart, 4, device="cuda")
     tl = torch.zeros(M, device="cuda")
     lse = torch.zeros(M, device="cuda")
     am = torch.zeros(M, dtype=torch.int64, device="cuda")
     nll = torch.zeros(M, device="cuda")
-    gemm(L, dtype, 0, 0, 3, A=p(xd), B=p(Wd), M=M, N=V, K=K, lda=K, ldb=K, tgt=p(td), partial=p(part), tgt_logit=p(tl))
+    gemm(L, dtype, 0, 0, 3, A=p(xd), B=p(Wd), M=M, N=V, K=K, lda=K, ldb=K, tgt=p(td), partial=p(part), tgt_logit=p(tl), tile=tile)
     ok(L.dic_ce_combine(p(part), p(tl), M, npart, p(lse), p(am), p(nll), stream()), L)
     torch.cuda.synchronize()
     o = rounding_ref(xd.float().cpu().numpy(), Wd.float().cpu().numpy()[:V], tgt.numpy())
@@ -259,7 +259,7 @@ def test_rounding_ce_partial_combine_and_backward(L, dtype, V):
     np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=2e-6 if dtype == F32 else 2e-4)
     np.testing.assert_allclose(nll.cpu().numpy(), o["lse"] - o["tgt_logit"], rtol=1e-5 if dtype == F32 else 1e-3, atol=1e-5)
     # backward: dlogits epilogue + (KC,KM) GEMM against autograd of the oracle's rounding loss
-    rows_a, sa, sb = 24, 0.5 / 3, 0.5 / 2
+    rows_a, sa, sb = M * 3 // 5, 0.5 / 3, 0.5 / 2
     dlog = torch.full((M, vpad), float("nan"), dtype=DT[dtype], device="cuda")
     dxr = torch.zeros(M, K, dtype=torch.float32, device="cuda")
     gemm(L, dtype, 0, 0, 4, A=p(xd), B=p(Wd), C=p(dlog), M=M, N=V, K=K, lda=K, ldb=K, ldc=vpad, tgt=p(td), lse=p(lse),
