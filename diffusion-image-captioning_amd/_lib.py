@@ -12,6 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libdic_hip.so")
+_AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another build of the same library for within-run A/B timing
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
@@ -82,7 +83,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension must be built (no CPU fallback exists); "
                                "run __graft_entry__.build()")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(_AB_LIB if _AB_LIB else LIB_PATH)
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise RuntimeError(f"{LIB_PATH} does not export {name}")

@@ -372,7 +372,7 @@ template <class C> struct Geo {
     static constexpr int C_PASSES = BM / C_ROWS;
 };
 
-template <class C, int EPI>
+template <class C, int EPI, bool PF>
 __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN], const DicGemmParams& p, int m0, int n0, int wm, int wn,
                                              int lane, int tid, char* smem) {
     using G = Geo<C>;
@@ -402,9 +402,30 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
                     *(f32x4*)(smem + row * ROWB + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
                 }
         }
-        __syncthreads();
+        // Rows are finished in groups of GRP iterations: a group's global READS (GELU' pre-activation / residual rows) are all
+        // issued before any of them is consumed -- the first group's ahead of the barrier, under the parking traffic -- instead
+        // of stalling every row iteration on its own load.  128-tiles take the whole pass as one group (fully unrolled: measured
+        // 113 -> 93 us on the qkv projection even without a residual); 256-tiles have 16 spare VGPRs, i.e. groups of 4.
+        constexpr int NIT = G::C_ROWS / RPI;
+        constexpr bool PREFETCH = PF && (EPI == DIC_EPI_GELU_BWD || EPI == DIC_EPI_AFFINE);
+        constexpr int GRP = G::BM == 128 ? NIT : (PREFETCH ? 4 : 1);
+        const T* pf_src = EPI == DIC_EPI_GELU_BWD ? (const T*)p.aux : (const T*)p.R;
+        const int pf_ld = EPI == DIC_EPI_GELU_BWD ? p.ldaux : p.ldr;
 #pragma unroll 1
-        for (int k = 0; k < G::C_ROWS / RPI; ++k) {
+        for (int g0 = 0; g0 < NIT; g0 += GRP) {
+        i32x4 pre[GRP];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int kk = 0; kk < GRP; ++kk) {
+                const int m = m0 + pass * G::C_ROWS + tid / CPR + RPI * (g0 + kk);
+                pre[kk] = i32x4{0, 0, 0, 0};
+                if (pf_src && m < p.M && v1ok) pre[kk] = *(const i32x4*)(pf_src + (size_t)m * pf_ld + n);
+            }
+        }
+        if (g0 == 0) __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GRP; ++kk) {
+            const int k = g0 + kk;
             const int row = tid / CPR + RPI * k, m = m0 + pass * G::C_ROWS + row;
             if (m >= p.M) continue;
             const char* rp_ = smem + row * ROWB;
@@ -418,7 +439,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
                 }
                 if (p.R) {
                     const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
-                    if (v1ok) { f32x4 r0, r1; unpack8(*(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
+                    if (v1ok) { f32x4 r0, r1; unpack8(PREFETCH ? pre[kk] : *(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
                     else x0 += Elem<T>::ld4(rp);
                 }
                 if (p.out_f32) {
@@ -440,7 +461,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
             } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
                 if (!v1ok) continue;
                 f32x4 u0, u1;
-                unpack8(*(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n), u0, u1);
+                unpack8(PREFETCH ? pre[kk] : *(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n), u0, u1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
                 *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
@@ -457,6 +478,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
                 }
                 *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
             }
+        }
         }
     }
 }
@@ -695,7 +717,7 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
             epilogue_ce_partial<C>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tl.bn, tl.nbn);
         } else {
-            epilogue_lds<C, EPI>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tid, smem);
+            epilogue_lds<C, EPI, !AKM>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tid, smem);
         }
         unit += gridDim.x;
         if (unit >= total) break;

@@ -14,16 +14,17 @@ T, D, F, V = 18432, 768, 3072, 30592
 bf = torch.bfloat16
 
 
-def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, **extra):
+def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, resid=False, p_drop=0.0, **extra):
     A = torch.randn((K, M) if a_km else (M, K), device="cuda").to(bf)
     B = torch.randn((K, N) if b_km else (N, K), device="cuda").to(bf)
     Cc = torch.empty(M, N, device="cuda", dtype=torch.float32 if out_f32 else bf)
     aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2) else None
     bias = torch.randn(N, device="cuda") if epi in (0, 1) and not out_f32 else None
     ws = torch.empty(split * M * N, device="cuda") if split > 1 else None
+    Rr = torch.randn(M, N, device="cuda").to(bf) if resid else None
     g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, tile=int(os.environ.get("TILE", "128")),
            bias=bias.data_ptr() if bias is not None else 0, aux=aux.data_ptr() if aux is not None else 0, ldaux=N, out_f32=out_f32,
-           split_k=split, split_ws=ws.data_ptr() if ws is not None else 0)
+           split_k=split, split_ws=ws.data_ptr() if ws is not None else 0, R=Rr.data_ptr() if resid else 0, ldr=N, p_drop=p_drop, seed=7)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         assert L.dic_gemm(1, a_km, b_km, epi, C.byref(g), st) == 0, L.dic_last_error()
@@ -42,8 +43,10 @@ if __name__ == "__main__" and len(sys.argv) == 1:
     print("TILE =", os.environ.get("TILE", "128"))
     run("fwd qkv        (KC,KC) bias", T, 3 * D, D, 0, 0)
     run("fwd out-proj   (KC,KC) bias", T, D, D, 0, 0)
+    run("fwd out-proj   +resid +dropout", T, D, D, 0, 0, resid=True, p_drop=0.1)
     run("fwd ffn1       (KC,KC) gelu", T, F, D, 0, 0, epi=1)
     run("fwd ffn2       (KC,KC) bias", T, D, F, 0, 0)
+    run("fwd ffn2       +resid +dropout", T, D, F, 0, 0, resid=True, p_drop=0.1)
     run("dX  ffn2->du   (KC,KM) gelu'", T, F, D, 0, 1, epi=2)
     run("dX  ffn1->dsa  (KC,KM)", T, D, F, 0, 1)
     run("dX  qkv->dh    (KC,KM)", T, D, 3 * D, 0, 1)
