@@ -23,6 +23,7 @@
 #include "common.h"
 #include "../../include/dic_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -352,8 +353,8 @@ __device__ __forceinline__ void unpack8(i32x4 r, f32x4& a, f32x4& b) {
 }
 __device__ __forceinline__ i32x4 pack8f(const f32x4& a, const f32x4& b) {
     i32x4 r;
-    r[0] = (int)((unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16)); r[1] = (int)((unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16));
-    r[2] = (int)((unsigned)f2bf(b[0]) | ((unsigned)f2bf(b[1]) << 16)); r[3] = (int)((unsigned)f2bf(b[2]) | ((unsigned)f2bf(b[3]) << 16));
+    r[0] = (int)pack2bf(a[0], a[1]); r[1] = (int)pack2bf(a[2], a[3]);
+    r[2] = (int)pack2bf(b[0], b[1]); r[3] = (int)pack2bf(b[2], b[3]);
     return r;
 }
 
@@ -380,6 +381,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
     constexpr int ROWB = G::BN * 4;                       // bytes per parked row
     constexpr int CPR = G::BN / 8;                        // 8-column items per row
     constexpr int RPI = G::NTH / CPR;                     // rows covered per iteration
+    constexpr int NIT = G::C_ROWS / RPI;
     const int g = lane >> 4, t = lane & 15;
     const int c8 = tid % CPR;                             // this thread's 8 columns are the same for every row it handles
     const int n = n0 + c8 * 8;
@@ -389,6 +391,121 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
         if (p.bias) { if (v0ok) b0 = *(const f32x4*)(p.bias + n); if (v1ok) b1 = *(const f32x4*)(p.bias + n + 4); }
     }
     const float inv_keep = drop_inv_keep(p.p_drop);
+    // gfx950 has ONE counter (vmcnt) for loads and stores, and they complete out of order with respect to each other: any wait for a
+    // load drains every store issued before it.  A row loop that reads a side input per row (residual, GELU' pre-activation, lse /
+    // target of the rounding head) therefore serialises on the round trip of each row's STORE (measured: 12 us to write a 28 MB
+    // output that a fill kernel writes in 4).  So the row loop below contains no global load at all: a group of GRP rows gets its side
+    // inputs into registers first (the first group's under the parking traffic, ahead of the barrier), one explicit vmcnt(0) covers
+    // them, and then the rows are LDS read -> math -> store with nothing to wait on.  128-tiles take the whole pass as one group;
+    // 256-tiles have 16 spare VGPRs, i.e. groups of 4.  The two combinations that need loads inside the loop (accumulating into an
+    // fp32 C, a residual with N % 8 != 0) are rare and take the `general` instantiation of the loop.
+    constexpr bool SIDE = PF && (EPI == DIC_EPI_GELU_BWD || EPI == DIC_EPI_AFFINE);     // a [M][N] side matrix in the compute dtype
+    constexpr bool ROWSIDE = EPI == DIC_EPI_CE_DLOGITS;                                  // per-row scalars
+    constexpr int GRP = G::BM == 128 ? NIT : ((SIDE || ROWSIDE) ? 4 : 2);
+    const T* side = EPI == DIC_EPI_GELU_BWD ? (const T*)p.aux : (const T*)p.R;
+    const int side_ld = EPI == DIC_EPI_GELU_BWD ? p.ldaux : p.ldr;
+    auto rows = [&](auto general_c, int pass) {
+        constexpr bool GENERAL = decltype(general_c)::value;
+#pragma unroll 1
+        for (int g0 = 0; g0 < NIT; g0 += GRP) {
+            i32x4 pre[SIDE ? GRP : 1];
+            float r_lse[ROWSIDE ? GRP : 1], r_sc[ROWSIDE ? GRP : 1];
+            long long r_tg[ROWSIDE ? GRP : 1];
+            bool issued = false;
+            if constexpr (SIDE && !GENERAL) {
+                if (side) {
+                    issued = true;
+#pragma unroll
+                    for (int kk = 0; kk < GRP; ++kk) {
+                        const int m = m0 + pass * G::C_ROWS + tid / CPR + RPI * (g0 + kk);
+                        pre[kk] = i32x4{0, 0, 0, 0};
+                        if (m < p.M && v1ok) pre[kk] = *(const i32x4*)(side + (size_t)m * side_ld + n);
+                    }
+                }
+            }
+            if constexpr (ROWSIDE) {
+                issued = true;
+#pragma unroll
+                for (int kk = 0; kk < GRP; ++kk) {
+                    const int m = m0 + pass * G::C_ROWS + tid / CPR + RPI * (g0 + kk);
+                    const bool ok = m < p.M;
+                    r_lse[kk] = ok ? p.lse[m] : 0.f;
+                    r_tg[kk] = ok ? p.tgt[m] : -1;
+                    r_sc[kk] = ok ? row_scale(p, m) : 0.f;
+                }
+            }
+            if (g0 == 0) __syncthreads();
+            if (issued) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the group's side inputs are in registers
+#pragma unroll(GENERAL ? 1 : GRP)
+            for (int kk = 0; kk < GRP; ++kk) {
+                const int row = tid / CPR + RPI * (g0 + kk), m = m0 + pass * G::C_ROWS + row;
+                const bool mok = m < p.M;
+                const char* rp_ = smem + row * ROWB;
+                f32x4 x0 = *(const f32x4*)(rp_ + (((2 * c8) ^ (row & 15)) << 4)), x1 = *(const f32x4*)(rp_ + (((2 * c8 + 1) ^ (row & 15)) << 4));
+                if constexpr (EPI == DIC_EPI_AFFINE) {
+                    x0 += b0; x1 += b1;
+                    if (p.p_drop > 0.f) {
+                        x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
+                        x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + n + 4, p.p_drop, inv_keep);
+                    }
+                    if constexpr (!GENERAL) {
+                        if constexpr (SIDE) {
+                            if (side) { f32x4 r0, r1; unpack8(pre[kk], r0, r1); x0 += r0; x1 += r1; }
+                        }
+                        if (p.out_f32) {
+                            float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                            if (mok && v0ok) *(f32x4*)c = x0;
+                            if (mok && v1ok) *(f32x4*)(c + 4) = x1;
+                        } else {
+                            T* c = (T*)p.C + (size_t)m * p.ldc + n;
+                            if (mok && v1ok) *(i32x4*)c = pack8f(x0, x1);
+                            else if (mok && v0ok) Elem<T>::st4(c, x0);
+                        }
+                    } else if (mok && v0ok) {
+                        if (p.R) {
+                            const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
+                            if (v1ok) { f32x4 r0, r1; unpack8(*(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
+                            else x0 += Elem<T>::ld4(rp);
+                        }
+                        if (p.out_f32) {
+                            float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                            if (p.accumulate) { x0 += *(const f32x4*)c; if (v1ok) x1 += *(const f32x4*)(c + 4); }
+                            *(f32x4*)c = x0;
+                            if (v1ok) *(f32x4*)(c + 4) = x1;
+                        } else {
+                            T* c = (T*)p.C + (size_t)m * p.ldc + n;
+                            if (v1ok) *(i32x4*)c = pack8f(x0, x1); else Elem<T>::st4(c, x0);
+                        }
+                    }
+                } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {            // N % 8 == 0 is required for this epilogue
+                    x0 += b0; x1 += b1;
+                    if (mok && v1ok) *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + n) = pack8f(x0, x1);     // pre-activation u (for GELU')
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
+                    if (mok && v1ok) *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+                } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
+                    f32x4 u0, u1;
+                    if constexpr (SIDE) unpack8(pre[kk], u0, u1);
+                    else unpack8((mok && v1ok) ? *(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n) : i32x4{0, 0, 0, 0}, u0, u1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
+                    if (mok && v1ok) *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+                } else {   // DIC_EPI_CE_DLOGITS: (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
+                    const float lse = r_lse[kk], sc = r_sc[kk];
+                    const long long tg = r_tg[kk];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
+                        if ((long long)(n + r) == tg) q0 -= 1.0f;
+                        if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
+                        x0[r] = q0 * sc; x1[r] = q1 * sc;
+                    }
+                    if (mok && n < p.ldc) *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+                }
+            }
+        }
+    };
+    const bool general = EPI == DIC_EPI_AFFINE && (p.accumulate || (p.R != nullptr && (!SIDE || (p.N & 7) != 0)));
 #pragma unroll
     for (int pass = 0; pass < G::C_PASSES; ++pass) {
         if (pass > 0) __syncthreads();
@@ -402,83 +519,10 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
                     *(f32x4*)(smem + row * ROWB + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
                 }
         }
-        // Rows are finished in groups of GRP iterations: a group's global READS (GELU' pre-activation / residual rows) are all
-        // issued before any of them is consumed -- the first group's ahead of the barrier, under the parking traffic -- instead
-        // of stalling every row iteration on its own load.  128-tiles take the whole pass as one group (fully unrolled: measured
-        // 113 -> 93 us on the qkv projection even without a residual); 256-tiles have 16 spare VGPRs, i.e. groups of 4.
-        constexpr int NIT = G::C_ROWS / RPI;
-        constexpr bool PREFETCH = PF && (EPI == DIC_EPI_GELU_BWD || EPI == DIC_EPI_AFFINE);
-        constexpr int GRP = G::BM == 128 ? NIT : (PREFETCH ? 4 : 1);
-        const T* pf_src = EPI == DIC_EPI_GELU_BWD ? (const T*)p.aux : (const T*)p.R;
-        const int pf_ld = EPI == DIC_EPI_GELU_BWD ? p.ldaux : p.ldr;
-#pragma unroll 1
-        for (int g0 = 0; g0 < NIT; g0 += GRP) {
-        i32x4 pre[GRP];
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int kk = 0; kk < GRP; ++kk) {
-                const int m = m0 + pass * G::C_ROWS + tid / CPR + RPI * (g0 + kk);
-                pre[kk] = i32x4{0, 0, 0, 0};
-                if (pf_src && m < p.M && v1ok) pre[kk] = *(const i32x4*)(pf_src + (size_t)m * pf_ld + n);
-            }
-        }
-        if (g0 == 0) __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GRP; ++kk) {
-            const int k = g0 + kk;
-            const int row = tid / CPR + RPI * k, m = m0 + pass * G::C_ROWS + row;
-            if (m >= p.M) continue;
-            const char* rp_ = smem + row * ROWB;
-            f32x4 x0 = *(const f32x4*)(rp_ + (((2 * c8) ^ (row & 15)) << 4)), x1 = *(const f32x4*)(rp_ + (((2 * c8 + 1) ^ (row & 15)) << 4));
-            if constexpr (EPI == DIC_EPI_AFFINE) {
-                if (!v0ok) continue;
-                x0 += b0; x1 += b1;
-                if (p.p_drop > 0.f) {
-                    x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
-                    x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + n + 4, p.p_drop, inv_keep);
-                }
-                if (p.R) {
-                    const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
-                    if (v1ok) { f32x4 r0, r1; unpack8(PREFETCH ? pre[kk] : *(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
-                    else x0 += Elem<T>::ld4(rp);
-                }
-                if (p.out_f32) {
-                    float* c = (float*)p.C + (size_t)m * p.ldc + n;
-                    if (p.accumulate) { x0 += *(const f32x4*)c; if (v1ok) x1 += *(const f32x4*)(c + 4); }
-                    *(f32x4*)c = x0;
-                    if (v1ok) *(f32x4*)(c + 4) = x1;
-                } else {
-                    T* c = (T*)p.C + (size_t)m * p.ldc + n;
-                    if (v1ok) *(i32x4*)c = pack8f(x0, x1); else Elem<T>::st4(c, x0);
-                }
-            } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {
-                if (!v1ok) continue;                                   // N % 8 == 0 is required for this epilogue
-                x0 += b0; x1 += b1;
-                *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + n) = pack8f(x0, x1);     // pre-activation u (for GELU')
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
-                *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-            } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
-                if (!v1ok) continue;
-                f32x4 u0, u1;
-                unpack8(PREFETCH ? pre[kk] : *(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n), u0, u1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
-                *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-            } else {   // DIC_EPI_CE_DLOGITS: (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
-                if (n >= p.ldc) continue;
-                const float lse = p.lse[m], sc = row_scale(p, m);
-                const long long tg = p.tgt[m];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
-                    if ((long long)(n + r) == tg) q0 -= 1.0f;
-                    if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
-                    x0[r] = q0 * sc; x1[r] = q1 * sc;
-                }
-                *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-            }
-        }
+        if constexpr (EPI == DIC_EPI_AFFINE) {
+            if (general) rows(std::true_type{}, pass); else rows(std::false_type{}, pass);
+        } else {
+            rows(std::false_type{}, pass);
         }
     }
 }

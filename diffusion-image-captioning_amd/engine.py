@@ -69,11 +69,11 @@ N_CU = 256
 def choose_tile(M, N, split_k=1, epi=EPI_AFFINE):
     """256x256 workgroup tiles (8 waves, one workgroup per CU) pull half the bytes per flop through L2 of the 128x128 ones
     (measured: 1.16-1.26 vs 0.83-0.95 PFLOP/s on large squares), but there are 4x fewer of them and their epilogue is not hidden
-    behind a second resident workgroup: use them for the plain-epilogue GEMMs when they still give every CU work; the two
-    GELU epilogues (two 113 MB outputs / one extra input) measured faster on 128-tiles (158/164 vs 165/175 us)."""
+    behind a second resident workgroup: use them when they still give every CU work.  The GELU' epilogue (one extra 113 MB
+    input) measured faster on 128-tiles (145 vs 154 us); bias+GELU (two 113 MB outputs) on 256-tiles (136 vs 162 us)."""
     if _TILE_MODE in ("128", "256"):
         return int(_TILE_MODE) if (M >= 256 and N >= 256) else 128
-    if M < 256 or N < 256 or epi in (EPI_BIAS_GELU, EPI_GELU_BWD):
+    if M < 256 or N < 256 or epi == EPI_GELU_BWD:
         return 128
     units = ((M + 255) // 256) * ((N + 255) // 256) * max(split_k, 1)
     return 256 if units >= int(0.75 * N_CU) else 128
