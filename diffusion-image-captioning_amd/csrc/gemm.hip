@@ -778,8 +778,18 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
 __global__ void reduce_slabs_kernel(const float* ws, int nslab, long long n4, long long stride4, float* out, int accumulate,
                                     float* cs_out, long long n4_cs) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4 + n4_cs; i += (long long)gridDim.x * blockDim.x) {
+        // slabs are read eight at a time (independent loads in flight: one memory round trip per eight slabs, not one each) and
+        // added in slab order, so the result does not depend on the batching
         f32x4 a = ((const f32x4*)ws)[i];
-        for (int s = 1; s < nslab; ++s) a += ((const f32x4*)ws)[(size_t)s * stride4 + i];
+        int s = 1;
+        for (; s + 8 <= nslab; s += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ((const f32x4*)ws)[(size_t)(s + u) * stride4 + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; s < nslab; ++s) a += ((const f32x4*)ws)[(size_t)s * stride4 + i];
         f32x4* dst = i < n4 ? (f32x4*)out + i : (f32x4*)cs_out + (i - n4);
         if (accumulate) a += *dst;
         *dst = a;

@@ -280,36 +280,40 @@ __global__ void colsum_stage2(const float* ws, int nslab, int cols, float* out, 
     if (accumulate) acc += *(const f32x4*)(out + c);
     *(f32x4*)(out + c) = acc;
 }
-// few rows (the per-block partial rows of the LayerNorm backward kernels, split-K style folds): one launch, 4 waves per
-// 256 columns split the rows, LDS fold, fixed order.
-__global__ __launch_bounds__(256) void colsum_small(const float* in, int rows, int cols, int ld, float* out, int accumulate) {
-    __shared__ f32x4 red[4][64];
+// few rows (the per-block partial rows of the LayerNorm backward kernels, split-K style folds): one launch, 16 waves per
+// 256 columns split the rows (the kernel is a chain of memory round trips: rows / (16 waves x 8 loads in flight) of them),
+// LDS fold in fixed order.
+constexpr int CS_WAVES = 16;
+__global__ __launch_bounds__(64 * CS_WAVES) void colsum_small(const float* in, int rows, int cols, int ld, float* out, int accumulate) {
+    __shared__ f32x4 red[CS_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
     f32x4 acc{0.f, 0.f, 0.f, 0.f};
     if (c < cols) {
         int r = w;
-        for (; r + 28 < rows; r += 32) {               // 8 independent 16-byte loads in flight per lane (latency-bound otherwise)
+        for (; r + 7 * CS_WAVES < rows; r += 8 * CS_WAVES) {
             f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(in + (size_t)(r + 4 * u) * ld + c);
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(in + (size_t)(r + CS_WAVES * u) * ld + c);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; r < rows; r += 4) acc += *(const f32x4*)(in + (size_t)r * ld + c);
+        for (; r < rows; r += CS_WAVES) acc += *(const f32x4*)(in + (size_t)r * ld + c);
     }
     red[w][lane] = acc;
     __syncthreads();
     if (w == 0 && c < cols) {
-        f32x4 v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        f32x4 v = red[0][lane];
+#pragma unroll
+        for (int q = 1; q < CS_WAVES; ++q) v += red[q][lane];
         if (accumulate) v += *(const f32x4*)(out + c);
         *(f32x4*)(out + c) = v;
     }
 }
 extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream) {
     DIC_REQUIRE(cols % 4 == 0 && rows > 0, "dic_colsum: cols must be a multiple of 4");
-    if (in_dtype == DIC_F32 && rows <= 512) {
-        hipLaunchKernelGGL(colsum_small, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)in, rows, cols, ld, out, accumulate);
+    if (in_dtype == DIC_F32 && rows <= 1024) {
+        hipLaunchKernelGGL(colsum_small, dim3((cols + 255) / 256), dim3(64 * CS_WAVES), 0, (hipStream_t)stream, (const float*)in, rows, cols, ld, out, accumulate);
         DIC_CHECK_LAUNCH();
         return 0;
     }

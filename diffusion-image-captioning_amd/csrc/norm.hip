@@ -33,7 +33,7 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[NCH], float eps, floa
 }
 
 // block-level fold of per-wave register partials: acc[K][NCH] f32x4 per lane -> partial[blockIdx][K*D]
-template <int K>
+template <int K, int NWV = 4>
 __device__ __forceinline__ void fold_partials(f32x4 (&acc)[K][NCH], float* partial, float* lds) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -41,8 +41,10 @@ __device__ __forceinline__ void fold_partials(f32x4 (&acc)[K][NCH], float* parti
 #pragma unroll
         for (int c = 0; c < NCH; ++c) *(f32x4*)(lds + ((w * K + k) * D) + c * 256 + lane * 4) = acc[k][c];
     __syncthreads();
-    for (int i = threadIdx.x; i < K * D; i += 256) {
-        float s = lds[i] + lds[K * D + i] + lds[2 * K * D + i] + lds[3 * K * D + i];
+    for (int i = threadIdx.x; i < K * D; i += 64 * NWV) {
+        float s = lds[i];
+#pragma unroll
+        for (int q = 1; q < NWV; ++q) s += lds[q * K * D + i];
         partial[(size_t)blockIdx.x * K * D + i] = s;
     }
 }
@@ -176,8 +178,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* y, const float* ga
     }
 }
 
+// (8 waves per block: with a few hundred persistent blocks the kernel is bound by memory LATENCY -- every row iteration is one
+// load round trip -- so waves in flight per CU are what buy bandwidth; 256 blocks x 4 waves ran at 35 us, 108 MB)
+constexpr int LNB_WAVES = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dh, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
                                                       float p_drop, unsigned long long seed, float* partial, int rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dh, const T* y, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float inv_keep = drop_inv_keep(p_drop);
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         f32x4 v[NCH], d[NCH];
         load_row<T>(y + (size_t)row * D, lane, v);
         load_row<T>(dh + (size_t)row * D, lane, d);
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dh, const T* y, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[2][c] += d[c];
     }
-    fold_partials<3>(acc, partial, lds);
+    fold_partials<3, LNB_WAVES>(acc, partial, lds);
 }
 
 // ---------------------------------------------------------------------------------------------- GELU + LayerNorm (hf:511-512)
@@ -339,8 +344,14 @@ extern "C" int dic_ln_fwd(int dtype, const void* y, const float* gamma, const fl
 extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx,
                           void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks, int T, int Dd, void* stream) {
     DIC_REQUIRE(Dd == D && T > 0 && n_partial_blocks > 0, "dic_ln_bwd: D must be 768");
-    dim3 grid(n_partial_blocks), block(256);
-    const size_t lds = 4 * 3 * D * sizeof(float);
+    dim3 grid(n_partial_blocks), block(64 * LNB_WAVES);
+    const size_t lds = LNB_WAVES * 3 * D * sizeof(float);              // 72 KB: above the 64 KB default cap of dynamic LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, (unsigned long long)seed, partial, T),

@@ -22,7 +22,7 @@ from .config import LOSS_KINDS, cfg
 from .params import ParamStore
 
 LN_EPS = 1e-12
-NPART = 256          # persistent blocks (= partial rows) of the LayerNorm backward kernels
+NPART = 512          # persistent blocks (= partial rows) of the LayerNorm backward kernels (2 per CU)
 
 
 def _p(t):
