@@ -51,6 +51,29 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
     return __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ int reg_tok(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }   // 32x32 C/D row of register r
+// Output tiles leave through LDS.  With the token-major product as the MFMA *B* operand the accumulator is out^T[d][token]: lane =
+// token, and registers 4a..4a+3 hold FOUR CONSECUTIVE d (8a + 4hi + 0..3), i.e. one 8-byte bf16 run.  The runs go into a wave-
+// private LDS tile ([token][64] bf16, VSTRIDE pitch) and come back as 16-byte row chunks, so the global store is 3 fully
+// coalesced instructions per [Tk][64] output instead of 32 two-byte-per-lane ones (the kernels were VMEM-issue bound).
+__device__ __forceinline__ void stage_out(char* tile, const f32x16& o0, const f32x16& o1, int lane, int Tk) {
+    const int q = lane & 31, hi = lane >> 5;
+    if (q < Tk) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            uint2 u0, u1;
+            u0.x = pack2bf(o0[4 * a], o0[4 * a + 1]); u0.y = pack2bf(o0[4 * a + 2], o0[4 * a + 3]);
+            u1.x = pack2bf(o1[4 * a], o1[4 * a + 1]); u1.y = pack2bf(o1[4 * a + 2], o1[4 * a + 3]);
+            *(uint2*)(tile + q * VSTRIDE + (8 * a + 4 * hi) * 2) = u0;
+            *(uint2*)(tile + q * VSTRIDE + (32 + 8 * a + 4 * hi) * 2) = u1;
+        }
+    }
+}
+__device__ __forceinline__ void store_out(const char* tile, bf16_t* dst, int ld, int Tk, int lane) {
+    for (int e = lane; e < Tk * 8; e += 64) {
+        const int row = e >> 3, ch = e & 7;
+        *(i32x4*)(dst + (size_t)row * ld + ch * 8) = *(const i32x4*)(tile + row * VSTRIDE + ch * 16);
+    }
+}
 __device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
 
 // D[i][j] = sum_d X[i][d] * Y[j][d] over dh=64 with X rows as MFMA "A" (row index in registers after the MFMA) and
@@ -108,18 +131,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const ui
     }
     __builtin_amdgcn_s_waitcnt(0);   // V tile stores by this wave are complete (wave-private LDS region, no barrier needed)
     __builtin_amdgcn_wave_barrier();
-    // O[query][d] = sum_key P[query][key] V[key][d]
+    // O^T[d][query] = sum_key V[key][d] P[query][key]
+    f32x16 o[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-        f32x16 o = zero16();
+        o[db] = zero16();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(st, s), tr_frag(vt, s, db, lane), o, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qi = reg_tok(r, hi);
-            if (qi < Tk) ctx[((size_t)n * Tk + qi) * Dm + h * DH + db * 32 + q] = f2bf(o[r]);
-        }
+        for (int s = 0; s < 2; ++s) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vt, s, db, lane), pack8(st, s), o[db], 0, 0, 0);
     }
+    stage_out(vt, o[0], o[1], lane, Tk);          // (the V tile is dead: every transpose read above has been consumed)
+    store_out(vt, ctx + (size_t)n * Tk * Dm + h * DH, Dm, Tk, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 backward
@@ -221,17 +242,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
         for (int r = 0; r < 16; ++r) st[r] = st[r] * (dpt[r] - delta) * scale;      // dS[query][key] (scaled for dQ/dK)
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        f32x16 o[2];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {                                            // dQ[query][d] = sum_key dS[query][key] K[key][d]
-            f32x16 o = zero16();
+        for (int db = 0; db < 2; ++db) {                                            // dQ^T[d][query] = sum_key K[key][d] dS[query][key]
+            o[db] = zero16();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(st, s), tr_frag_clamped(kt, s, db, lane, zero_row), o, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = reg_tok(r, hi);
-                if (qi < Tk) dQ[(size_t)qi * ld + db * 32 + c] = f2bf(o[r]);
-            }
+            for (int s = 0; s < 2; ++s) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped(kt, s, db, lane, zero_row), pack8(st, s), o[db], 0, 0, 0);
         }
+        stage_out(kt, o[0], o[1], lane, Tk);                                        // K's tile is not read again
+        store_out(kt, dQ, ld, Tk, lane);
     }
     // ---- pass 2 (key-major): lane = key c, registers = queries.  Pd -> dV, dS -> dK
     {
@@ -253,23 +272,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
             pd[r] = pdr;
             ds[r] = pr * (dpr - delta) * scale;
         }
+        f32x16 o[2];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            f32x16 ov = zero16(), ok_ = zero16();
+        for (int db = 0; db < 2; ++db) {                                            // dV^T[d][key] = sum_query dO[query][d] Pd[query][key]
+            o[db] = zero16();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                ov = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pd, s), tr_frag_clamped(dot, s, db, lane, zero_row), ov, 0, 0, 0);
-                ok_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ds, s), tr_frag_clamped(qt, s, db, lane, zero_row), ok_, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ki = reg_tok(r, hi);
-                if (ki < Tk) {
-                    dV[(size_t)ki * ld + db * 32 + c] = f2bf(ov[r]);
-                    dK[(size_t)ki * ld + db * 32 + c] = f2bf(ok_[r]);
-                }
-            }
+            for (int s = 0; s < 2; ++s) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped(dot, s, db, lane, zero_row), pack8(pd, s), o[db], 0, 0, 0);
         }
+        stage_out(dot, o[0], o[1], lane, Tk);
+        store_out(dot, dV, ld, Tk, lane);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {                                            // dK^T[d][key] = sum_query Q[query][d] dS[query][key]
+            o[db] = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped(qt, s, db, lane, zero_row), pack8(ds, s), o[db], 0, 0, 0);
+        }
+        stage_out(qt, o[0], o[1], lane, Tk);
+        store_out(qt, dK, ld, Tk, lane);
     }
 }
 

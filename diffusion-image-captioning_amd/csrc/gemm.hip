@@ -536,10 +536,17 @@ __device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[Geo<C>::FM][Geo
     static_assert(G::BN / G::WN == 64 && G::FN == 4, "one 64-column record per wave");
     const int g = lane >> 4, t = lane & 15;
     const int np = G::WN * nbn;
+    // all target ids first: a load inside the row loop would wait on vmcnt, which also counts the stores of the rows before it
+    long long tgs[G::FM];
 #pragma unroll
     for (int i = 0; i < G::FM; ++i) {
         const int m = m0 + wm * (G::BM / G::WM) + i * 16 + t;
-        const long long tg = (m < p.M && p.tgt) ? p.tgt[m] : -1;
+        tgs[i] = (m < p.M && p.tgt) ? p.tgt[m] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < G::FM; ++i) {
+        const int m = m0 + wm * (G::BM / G::WM) + i * 16 + t;
+        const long long tg = tgs[i];
         float mx = -INFINITY;
         int ix = 0x7fffffff;
 #pragma unroll
