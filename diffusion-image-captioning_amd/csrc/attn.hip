@@ -74,6 +74,17 @@ __device__ __forceinline__ void store_out(const char* tile, bf16_t* dst, int ld,
         *(i32x4*)(dst + (size_t)row * ld + ch * 8) = *(const i32x4*)(tile + row * VSTRIDE + ch * 16);
     }
 }
+// Attention-probability dropout of the MFMA kernels: 16 mask bits per (head, query, key), two keys (2j, 2j+1) per 32-bit hash of the
+// 32-bit index ((pair*32 + query)*16 + j) -- a lane that holds one query's keys in registers (forward, backward pass 1) hashes
+// once per TWO probabilities, and nothing is 64-bit.  Forward and backward share the definition; the VALU kernels keep dropout1.
+__device__ __forceinline__ unsigned attn_seed_mix(unsigned long long seed) { return hash32((unsigned)seed) ^ (unsigned)(seed >> 32) * 0x9E3779B9u; }
+__device__ __forceinline__ unsigned attn_drop_hash(unsigned mix, unsigned pair, int q, int key) {
+    return hash32((((pair << 5) + (unsigned)q) << 4) + (unsigned)(key >> 1) ^ mix);
+}
+__device__ __forceinline__ float attn_drop(float v, unsigned h, int key, unsigned thr, float inv_keep) {
+    const unsigned w = (key & 1) ? (h >> 16) : (h & 0xffffu);
+    return w >= thr ? v * inv_keep : 0.f;
+}
 __device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
 
 // D[i][j] = sum_d X[i][d] * Y[j][d] over dh=64 with X rows as MFMA "A" (row index in registers after the MFMA) and
@@ -107,12 +118,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const ui
 
     const int q = lane & 31, hi = lane >> 5;
     // S^T[key][query]: lane = query column, register r = key reg_tok(r,hi)
+    // key-padding mask: one byte load per lane, shared as a 64-bit ballot (not 16 dependent byte loads per lane)
+    const unsigned long long mbits = __ballot(lane < Tk && key_mask[(size_t)n * Tk + (lane < Tk ? lane : 0)] != 0);
     f32x16 st = rowdot(K, ld, Q, ld, Tk, lane);
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int key = reg_tok(r, hi);
-        const bool ok = key < Tk && key_mask[(size_t)n * Tk + key] != 0;
+        const bool ok = (mbits >> key) & 1ull;
         st[r] = ok ? st[r] * scale : -INFINITY;
         mx = fmaxf(mx, st[r]);
     }
@@ -123,11 +136,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const ui
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     const float inv_keep = drop_inv_keep(p_drop);
+    const unsigned thr = drop_thr(p_drop), mix = attn_seed_mix(seed);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        st[r] *= inv;
-        if (p_drop > 0.f)
-            st[r] = dropout1(st[r], seed, ((unsigned long long)pair * Tk + q) * Tk + reg_tok(r, hi), p_drop, inv_keep);
+    for (int r = 0; r < 16; r += 2) {
+        st[r] *= inv; st[r + 1] *= inv;
+        if (p_drop > 0.f) {
+            const unsigned hsh = attn_drop_hash(mix, (unsigned)pair, q, reg_tok(r, hi));      // keys reg_tok(r), reg_tok(r)+1
+            st[r] = (hsh & 0xffffu) >= thr ? st[r] * inv_keep : 0.f;
+            st[r + 1] = (hsh >> 16) >= thr ? st[r + 1] * inv_keep : 0.f;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);   // V tile stores by this wave are complete (wave-private LDS region, no barrier needed)
     __builtin_amdgcn_wave_barrier();
@@ -209,7 +226,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
 
     const int c = lane & 31, hi = lane >> 5;
     const float inv_keep = drop_inv_keep(p_drop);
-    const uint8_t* km = key_mask + (size_t)n * Tk;
+    const unsigned thr = drop_thr(p_drop), mix = attn_seed_mix(seed);
+    const unsigned long long mbits = __ballot(lane < Tk && key_mask[(size_t)n * Tk + (lane < Tk ? lane : 0)] != 0);
 
     // ---- pass 1 (query-major): lane = query c, registers = keys.  P, delta, dS -> dQ
     {
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = reg_tok(r, hi);
-            const bool ok = key < Tk && km[key] != 0;
+            const bool ok = (mbits >> key) & 1ull;
             st[r] = ok ? st[r] * scale : -INFINITY;
             mx = fmaxf(mx, st[r]);
         }
@@ -231,10 +249,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
         f32x16 dpt = rowdot_reg(fv, fo);                                           // dPd^T[key][query]
         float delta = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            st[r] *= inv;                                                          // P
-            if (p_drop > 0.f) dpt[r] = dropout1(dpt[r], seed, ((unsigned long long)pair * Tk + c) * Tk + reg_tok(r, hi), p_drop, inv_keep);
-            delta += dpt[r] * st[r];
+        for (int r = 0; r < 16; r += 2) {
+            st[r] *= inv; st[r + 1] *= inv;                                        // P
+            if (p_drop > 0.f) {
+                const unsigned hsh = attn_drop_hash(mix, (unsigned)pair, c, reg_tok(r, hi));
+                dpt[r] = (hsh & 0xffffu) >= thr ? dpt[r] * inv_keep : 0.f;
+                dpt[r + 1] = (hsh >> 16) >= thr ? dpt[r + 1] * inv_keep : 0.f;
+            }
+            delta += dpt[r] * st[r] + dpt[r + 1] * st[r + 1];
         }
         delta += __shfl_xor(delta, 32, 64);
         if (hi == 0) { stats[c] = mx; stats[32 + c] = inv; stats[64 + c] = delta; }
@@ -256,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
     {
         f32x16 s2 = rowdot_reg(fq, fk);                                             // S[query(reg)][key(lane)]
         f32x16 dp2 = rowdot_reg(fo, fv);                                            // dPd[query][key]
-        const bool kok = c < Tk && km[c < Tk ? c : 0] != 0;
+        const bool kok = (mbits >> c) & 1ull;
         f32x16 pd, ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -265,9 +287,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
             float pr = (kok && m_ > -INFINITY) ? __expf(s2[r] * scale - m_) * inv : 0.f;
             float dpr = dp2[r], pdr = pr;
             if (p_drop > 0.f) {
-                const unsigned long long idx = ((unsigned long long)pair * Tk + qi) * Tk + c;
-                dpr = dropout1(dpr, seed, idx, p_drop, inv_keep);
-                pdr = dropout1(pr, seed, idx, p_drop, inv_keep);
+                const unsigned hsh = attn_drop_hash(mix, (unsigned)pair, qi, c);
+                dpr = attn_drop(dpr, hsh, c, thr, inv_keep);
+                pdr = attn_drop(pr, hsh, c, thr, inv_keep);
             }
             pd[r] = pdr;
             ds[r] = pr * (dpr - delta) * scale;
@@ -416,6 +438,7 @@ extern "C" int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask,
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     DIC_REQUIRE(Tk <= TMAX, "dic_attn: at most 64 tokens per sequence");
+    DIC_REQUIRE((long long)N * H < (1ll << 23), "dic_attn: at most 2^23 (sequence, head) pairs per launch (32-bit dropout index)");
     if (dtype == DIC_BF16 && Tk > 32) {      // beyond one 32x32 MFMA tile (seq_len 32 + CLIP rows): exact-fp32-math kernel on bf16 I/O
         size_t lds = (size_t)(3 * Tk * PADW + Tk * (Tk + 1)) * sizeof(float);
         hipLaunchKernelGGL(attn_fwd_f32<bf16_t>, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
@@ -435,6 +458,7 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
     const float scale = 0.125f;
     hipStream_t st = (hipStream_t)stream;
     DIC_REQUIRE(Tk <= TMAX, "dic_attn: at most 64 tokens per sequence");
+    DIC_REQUIRE((long long)N * H < (1ll << 23), "dic_attn: at most 2^23 (sequence, head) pairs per launch (32-bit dropout index)");
     if (dtype == DIC_BF16 && Tk > 32) {
         size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);
         static bool attr2 = false;
