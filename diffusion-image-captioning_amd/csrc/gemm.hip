@@ -373,6 +373,13 @@ template <class C> struct Geo {
     static constexpr int C_PASSES = BM / C_ROWS;
 };
 
+// workgroup barrier that waits for this wave's LDS traffic only: outstanding global STORES (epilogue output) keep draining across
+// it.  (__syncthreads() carries vmcnt(0), i.e. a full round trip of every store issued so far.)
+__device__ __forceinline__ void barrier_lds_only() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
+
 template <class C, int EPI, bool PF>
 __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN], const DicGemmParams& p, int m0, int n0, int wm, int wn,
                                              int lane, int tid, char* smem) {
@@ -434,7 +441,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
                     r_sc[kk] = ok ? row_scale(p, m) : 0.f;
                 }
             }
-            if (g0 == 0) __syncthreads();
+            if (g0 == 0) barrier_lds_only();                     // the parked tile is complete
             if (issued) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the group's side inputs are in registers
 #pragma unroll(GENERAL ? 1 : GRP)
             for (int kk = 0; kk < GRP; ++kk) {
@@ -508,7 +515,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN
     const bool general = EPI == DIC_EPI_AFFINE && (p.accumulate || (p.R != nullptr && (!SIDE || (p.N & 7) != 0)));
 #pragma unroll
     for (int pass = 0; pass < G::C_PASSES; ++pass) {
-        if (pass > 0) __syncthreads();
+        if (pass > 0) barrier_lds_only();                                // every wave has read its rows of the previous pass
         const int wrow0 = wm * (G::BM / G::WM) - pass * G::C_ROWS;       // this wave's first row relative to the parked block
         if (wrow0 >= 0 && wrow0 < G::C_ROWS) {
 #pragma unroll
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         if (unit >= total) break;
         tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
         setup(tl);
-        __syncthreads();                 // every wave is done with the LDS-staged output tile
+        barrier_lds_only();              // every wave is done with the LDS-staged output tile; its stores drain under the next DMA
         if (tl.kt0 < tl.kt1) issue(0);
         __syncthreads();
     }
