@@ -73,3 +73,19 @@ def sweep():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
     sweep()
+
+
+def grouped_potential():
+    """What one launch covering a layer's four weight gradients could reach: same tile count as a single (9216 x 768) x 18432 problem."""
+    print("--- aggregated dW shape (2304+768+3072+3072) x 768, K=18432")
+    for sp in (1, 2, 3, 4, 7):
+        run("dW  layer-aggregate (KM,KM) f32", 9216, D, T, 1, 1, split=sp, out_f32=1)
+    print("--- today: four launches")
+    run("dW  qkv", 3 * D, D, T, 1, 1, split=9, out_f32=1)
+    run("dW  out", D, D, T, 1, 1, split=14, out_f32=1)
+    run("dW  ffn1", F, D, T, 1, 1, split=7, out_f32=1)
+    run("dW  ffn2", D, F, T, 1, 1, split=7, out_f32=1)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "grouped":
+    grouped_potential()

@@ -153,6 +153,28 @@ def test_gemm_tile256_all_layouts_and_epilogues(L, layout):
             assert relerr(Cs, acc) < 2e-6 and relerr(cs, Ad.float().cpu().double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_bf16_epilogue_general_path(L, tile):
+    """The rarely used epilogue combinations that need loads inside the row loop: accumulate into an fp32 C, and a residual
+    with N % 8 == 4 (the last 8-column item of a row is half valid)."""
+    M, N, K = 300, 772, 192
+    g = torch.Generator().manual_seed(tile)
+    A, B = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3
+    bias, Rr = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd, Rd = dev(A, torch.bfloat16), dev(B, torch.bfloat16), dev(Rr, torch.bfloat16)
+    acc = Ad.float().cpu().double() @ Bd.float().cpu().double().t()
+    Cd = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), R=p(Rd), ldr=N, tile=tile)
+    assert relerr(Cd.float(), acc + bias.double() + Rd.float().cpu().double()) < 6e-3
+    Cf = torch.full((M, N), 2.0, dtype=torch.float32, device="cuda")
+    gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cf), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=1, accumulate=1, tile=tile)
+    assert relerr(Cf, acc + 2.0) < 2e-6
+    # and the fast path on the same ragged N without a residual: nothing may be written beyond column N-1 of a row
+    Cp = torch.full((M, N + 4), 7.0, dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cp), M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 4, tile=tile)
+    assert relerr(Cp[:, :N].float(), acc) < 6e-3 and bool((Cp[:, N:] == 7.0).all())
+
+
 @pytest.mark.parametrize("split", [1, 3])
 def test_gemm_fused_bias_gradient(L, split):
     """bf16 weight-gradient GEMM also returns colsum(dY) (the bias gradient) from the LDS-resident A tiles."""
