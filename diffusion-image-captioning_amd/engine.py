@@ -171,6 +171,16 @@ class Denoiser:
         self.params.load_state(state)
         self.refresh_shadows()
 
+    def state_dict(self):
+        """Trainable tensors under the reference's parameter names (`nn.Module.state_dict` for the parts the step trains)."""
+        return self.params.state_dict()
+
+    def load_state_dict(self, state, strict=True):
+        missing = [n for n in self.params.names if n not in state]
+        if missing and strict:
+            raise KeyError(f"load_state_dict: missing {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        self.load_state(state)
+
     def train(self, mode=True):
         self.training = mode
         return self
