@@ -245,7 +245,7 @@ class Denoiser:
         ws["partial"] = f(NPART, 3 * D)
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
-        ws["splitk"] = f(32 * 1024 * 1024)          # 128 MB: split_k * M * N fp32 partial tiles of one dW GEMM
+        ws["splitk"] = f(64 * 1024 * 1024)          # 256 MB: split_k * M * N fp32 partial tiles of one dW GEMM / the rounding dX GEMM
         self._ws[key] = ws
         return ws
 
@@ -482,8 +482,9 @@ class Denoiser:
         ws_split = self._saved["splitk"]
         o.gemm(_p(cw["xr"]), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_DLOGITS,
                tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b)
-        # 128 x 6 = 768 output tiles on 512 resident workgroups is 1.5 rounds: cut the 30592-deep contraction in two
-        sk = 2 if (M * 768 * 2 <= ws_split.numel() and M >= 2048) else 1
+        # 64 x 3 = 192 256-tiles are 0.75 of a round and x2 slices 1.5 rounds: four slices of the 30592-deep contraction fill
+        # three rounds exactly (measured at M = 16384: 862 us vs 1064 us for two slices, 1032 us unsplit)
+        sk = next((k for k in (4, 2) if M * 768 * k <= ws_split.numel() and M >= 2048), 1)
         o.gemm(_p(cw["dlogits"]), _p(self.W_lm_c), _p(cw["dxr"]), M, 768, self.vpad, self.vpad, 768, 768, b_km=1, out_f32=1,
                split_k=sk, split_ws=_p(ws_split) if sk > 1 else 0)
         return cw["dxr"]

@@ -89,3 +89,9 @@ def grouped_potential():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "grouped":
     grouped_potential()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ce":
+    for sp in (1, 2, 3, 4, 6):
+        run("rounding dX    (KC,KM) f32", 16384, D, V, 0, 1, out_f32=1, split=sp)
+    run("rounding logits(KC,KC) plain", 16384, V, D, 0, 0)
