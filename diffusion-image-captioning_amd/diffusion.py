@@ -238,6 +238,11 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     return sc["out"][0], sc["out"][1], prob
 
 
+import os as _os
+
+_STREAMED_ADAMW = _os.environ.get("DIC_STREAMED_ADAMW", "1") == "1"      # A/B switch for measurements
+
+
 # ------------------------------------------------------------------ AdamW (ref :335)
 class AdamW:
     """torch.optim.AdamW semantics (lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0.01, one param group covering
@@ -259,18 +264,45 @@ class AdamW:
     def zero_grad(self, set_to_none=False):
         self.store.G.zero_()
 
-    def step(self):
+    def _launch(self, lo, hi):
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        self.t += 1
         s = self.store
         st = torch.cuda.current_stream().cuda_stream
+        sh = (_p(s.Pb) + 2 * lo) if s.Pb is not None else 0
+        _lib.check(_lib.lib().dic_adamw(_p(s.P) + 4 * lo, _p(s.G) + 4 * lo, _p(self.m) + 4 * lo, _p(self.v) + 4 * lo, sh, hi - lo,
+                                        float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                                        self.grad_scale, st), "adamw")
+
+    # Streamed stepping (single-GPU training): the update of an encoder layer's slice is an HBM-bound pass that can run on the
+    # weight-gradient stream as soon as that layer's gradients are final, under the MFMA-bound backward of the layers below it.
+    # begin_step() ... step_range(lo, hi) per finished slice ... step() then only covers what is left.  Same arithmetic, same
+    # step counter: the result is bit-identical to one launch over the whole buffer.
+    def begin_step(self):
+        self.t += 1
+        self._streamed = []
+
+    def step_range(self, lo, hi):
+        self._launch(lo, hi)
+        self._streamed.append((lo, hi))
+
+    def step(self):
+        streamed = getattr(self, "_streamed", None)
+        self._streamed = None
+        if streamed is None:
+            self.t += 1
+            streamed = []
         # torch skips tensors whose .grad is None (unused this step: text_linear under "add" fusion without guidance)
-        for lo, hi in s.active_ranges():
-            sh = (_p(s.Pb) + 2 * lo) if s.Pb is not None else 0
-            _lib.check(_lib.lib().dic_adamw(_p(s.P) + 4 * lo, _p(s.G) + 4 * lo, _p(self.m) + 4 * lo, _p(self.v) + 4 * lo, sh, hi - lo,
-                                            float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
-                                            self.grad_scale, st), "adamw")
+        for lo, hi in self.store.active_ranges():
+            cur = lo
+            for a, b in sorted(streamed):
+                if b <= cur or a >= hi:
+                    continue
+                if a > cur:
+                    self._launch(cur, a)
+                cur = max(cur, b)
+            if cur < hi:
+                self._launch(cur, hi)
 
     def state_dict(self):
         return dict(t=self.t, m=self.m.clone(), v=self.v.clone(), param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
@@ -308,7 +340,16 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
         if not model._pending:
             raise RuntimeError("train_func(train=True) called under torch.no_grad()")
         reducer = parallel.GradReducer(model)
-        model.backward(layer_done=reducer.layer_done if reducer.active else None)
+        layer_done = reducer.layer_done if reducer.active else None
+        if layer_done is None and isinstance(trainer, AdamW) and _STREAMED_ADAMW:
+            store = model.params
+            trainer.begin_step()
+
+            def layer_done(i):        # runs on the weight-gradient stream, ordered after layer i's last gradient kernel
+                lo = store.off(f"L{i}.Wqkv")
+                hi = store.off(f"L{i + 1}.Wqkv") if i + 1 < store.n_layers else store.off("pos")
+                trainer.step_range(lo, hi)
+        model.backward(layer_done=layer_done)
         reducer.finish(trainer)
         if not isinstance(trainer, AdamW):
             model.params.relink_grads()
