@@ -242,7 +242,7 @@ class Denoiser:
         ws["du"], ws["dqkv"] = [e(T, Hd), e(T, Hd)], [e(T, 3 * D), e(T, 3 * D)]
         ws["dsa"], ws["dctx"] = e(T, D), e(T, D)
         ws["dy0"] = f(N, Tk, D)
-        ws["partial"] = f(NPART, 3 * D)
+        ws["partial"] = [f(NPART, 3 * D) for _ in range(4)]       # [layer parity][which LayerNorm]: folded on the side stream
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
         ws["splitk"] = f(64 * 1024 * 1024)          # 256 MB: split_k * M * N fp32 partial tiles of one dW GEMM / the rounding dX GEMM
@@ -332,7 +332,7 @@ class Denoiser:
         seed, ph, pa = ws["seed"], ws["ph"], ws["pa"]
         dx = ws["dx_out"] if dx_out is None else dx_out
         csw = _p(ws["cs_ws"])
-        part = _p(ws["partial"])
+        parts = [_p(t_) for t_ in ws["partial"]]
 
         skw = _p(ws["splitk"])
         skcap = ws["splitk"].numel()
@@ -378,6 +378,11 @@ class Denoiser:
         def colsum(in_dtype, src, rows, cols, ld, dst, acc=0):
             _lib.check(lib.dic_colsum(in_dtype, src, rows, cols, ld, dst, acc, csw, st), "colsum")
 
+        def fold(pbuf, cols, dst):
+            """Column sums of a LayerNorm-backward partial buffer -> gamma/beta/bias gradients.  Nothing on the dX chain reads them,
+            so the fold runs on the weight-gradient stream (one launch + one dependent-launch gap less on the main stream per LayerNorm)."""
+            on_side(lambda: _lib.check(lib.dic_colsum(DIC_F32, pbuf, NPART, cols, cols, dst, 0, csw, o.stream), "colsum"))
+
         def finish_layer(j):
             """dW launches of layer j are queued: mark it, and hand the layer's gradient slice to the data-parallel reducer."""
             if use_side:
@@ -397,8 +402,8 @@ class Denoiser:
         nl = self.n_layers
         sp = nl & 1
         dyb = ws["dy"][sp]
-        _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), part, NPART, T, D, st), "gelu_ln_bwd")
-        colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr("vln_g", "G"))                      # [vln_g | vln_b | bvt]
+        _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), parts[2 * sp], NPART, T, D, st), "gelu_ln_bwd")
+        fold(parts[2 * sp], 3 * D, P.ptr("vln_g", "G"))                                      # [vln_g | vln_b | bvt]
         wgrad(_p(dyb), _p(ws["h"][-1]), "Wvt", D, D, D, D)
         finish_layer(nl)
         dH, dHn = ws["dHa"], ws["dHb"]
@@ -413,8 +418,8 @@ class Denoiser:
             dy_, dyd_, dy1_, du_, dqkv_ = ws["dy"][sp], ws["dyd"][sp], ws["dy1"][sp], ws["du"][sp], ws["dqkv"][sp]
             # output_layer_norm backward; bias grad of lin2 folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
-                                      _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, part, NPART, T, D, st), "ln_bwd")
-            colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln2g", "G"))              # [ln2g | ln2b | b2]
+                                      _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
+            fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                              # [ln2g | ln2b | b2]
             dyd = dyd_ if use_drop else dy_
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
@@ -422,8 +427,8 @@ class Denoiser:
             o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
-                                      0, 0.0, 0, part, NPART, T, D, st), "ln_bwd")
-            colsum(DIC_F32, part, NPART, 3 * D, 3 * D, P.ptr(pre + "ln1g", "G"))              # [ln1g | ln1b | bo]
+                                      0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
+            fold(parts[2 * sp + 1], 3 * D, P.ptr(pre + "ln1g", "G"))                          # [ln1g | ln1b | bo]
             wgrad(_p(dy1_), _p(Lw["ctx"]), pre + "Wo", D, D, D, D)
             o.gemm(_p(dy1_), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
             _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(dqkv_), N, Tk, self.n_heads, 64, pa,
@@ -438,8 +443,8 @@ class Denoiser:
         mode = ws["mode"]
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                        P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
-                                       _p(ws["dy0"]), part, NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
-        colsum(DIC_F32, part, NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"))                       # [eln_g | eln_b]
+                                       _p(ws["dy0"]), parts[0], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
+        colsum(DIC_F32, parts[0], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"))                   # [eln_g | eln_b]
         dy0 = _p(ws["dy0"])
         colsum(DIC_F32, dy0, N, Tk * D, Tk * D, P.ptr("pos", "G"))                            # dpos[0:Tk]
         if self.concat:
