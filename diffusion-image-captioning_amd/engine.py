@@ -242,7 +242,7 @@ class Denoiser:
         ws["du"], ws["dqkv"] = [e(T, Hd), e(T, Hd)], [e(T, 3 * D), e(T, 3 * D)]
         ws["dsa"], ws["dctx"] = e(T, D), e(T, D)
         ws["dy0"] = f(N, Tk, D)
-        ws["partial"] = [f(NPART, 3 * D) for _ in range(4)]       # [layer parity][which LayerNorm]: folded on the side stream
+        ws["partial"] = [f(NPART, 3 * D) for _ in range(5)]       # [layer parity][which LayerNorm] (folded on the side stream) + embeddings LN
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
         ws["splitk"] = f(64 * 1024 * 1024)          # 256 MB: split_k * M * N fp32 partial tiles of one dW GEMM / the rounding dX GEMM
@@ -437,14 +437,12 @@ class Denoiser:
             o.gemm(_p(dqkv_), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(dy1_), ldr=D)
             dH, dHn = dHn, dH
             finish_layer(i)
-        if use_side:
-            main.wait_stream(side)                    # every weight gradient is in G before anything downstream (AdamW, all-reduce tail)
-        # embeddings LayerNorm + fusion backward
+        # embeddings LayerNorm + fusion backward (touches none of the side stream's buffers: runs under layer 0's weight gradients)
         mode = ws["mode"]
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                        P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
-                                       _p(ws["dy0"]), parts[0], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
-        colsum(DIC_F32, parts[0], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"))                   # [eln_g | eln_b]
+                                       _p(ws["dy0"]), parts[4], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
+        colsum(DIC_F32, parts[4], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"))                   # [eln_g | eln_b]
         dy0 = _p(ws["dy0"])
         colsum(DIC_F32, dy0, N, Tk * D, Tk * D, P.ptr("pos", "G"))                            # dpos[0:Tk]
         if self.concat:
@@ -461,6 +459,8 @@ class Denoiser:
         if mode != 2:      # text row dropped: text_linear's gradient is exactly zero (G was zeroed by zero_grad)
             o.gemm(dtxt, _p(ws["txt_in"]), P.ptr("Wtxt", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
             colsum(DIC_F32, dtxt, N, D, ldd, P.ptr("btxt", "G"))
+        if use_side:
+            main.wait_stream(side)                    # every weight gradient is in G before anything downstream (AdamW, all-reduce tail)
 
     # ------------------------------------------------------------------ rounding head: streaming CE / argmax (ref :323, 436-437, 620)
     def rounding(self, xr, M, tgt=None, ce_ws=None, dtype=None):
