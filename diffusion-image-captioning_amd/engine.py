@@ -345,18 +345,30 @@ class Denoiser:
         side = self._side_stream() if use_side else None
         done = {}                                     # layer -> event on the side stream after that layer's dW launches
 
-        def on_side(fn):
-            if not use_side:
-                fn()
+        # Each side launch is handed over as soon as its inputs exist (one event on the main stream per hand-over).  Batching the
+        # hand-overs to two per layer (DIC_SIDE_BATCH=1) saves events but starts the side work later: measured 1.5 % slower.
+        pending = []
+        batch_side = _os.environ.get("DIC_SIDE_BATCH", "0") == "1"
+
+        def flush_side():
+            if not pending:
                 return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            o.stream = side.cuda_stream
+            if use_side:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                o.stream = side.cuda_stream
             try:
-                fn()
+                for fn in pending:
+                    fn()
             finally:
                 o.stream = st
+                pending.clear()
+
+        def on_side(fn):
+            pending.append(fn)
+            if not (use_side and batch_side):
+                flush_side()
 
         def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
@@ -385,6 +397,7 @@ class Denoiser:
 
         def finish_layer(j):
             """dW launches of layer j are queued: mark it, and hand the layer's gradient slice to the data-parallel reducer."""
+            flush_side()
             if use_side:
                 done[j] = torch.cuda.Event()
                 done[j].record(side)
@@ -424,6 +437,7 @@ class Denoiser:
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
             wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                                # dW1 (+ db1)
+            flush_side()
             o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),

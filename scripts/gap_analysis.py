@@ -5,9 +5,9 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows]
 ev.sort()
-# steady-state window: from the 2nd-to-last adamw launch to the last one = exactly one step
-adam = [e for e in ev if "adamw" in e[2]]
-t0, t1 = adam[-2][1], adam[-1][1]
+# steady-state window: from one step's first kernel (the embedding gather) to the next step's = exactly one step
+marks = [e for e in ev if "embed_gather" in e[2]]
+t0, t1 = marks[-2][0], marks[-1][0]
 win = [e for e in ev if e[0] >= t0 and e[1] <= t1]
 pts = []
 for s, e, _, _ in win:
