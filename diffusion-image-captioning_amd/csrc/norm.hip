@@ -49,6 +49,11 @@ __device__ __forceinline__ void fold_partials(f32x4 (&acc)[K][NCH], float* parti
     }
 }
 
+// Backward LayerNorm kernels run persistent blocks of 8 waves: with a few hundred blocks they are bound by memory LATENCY (every
+// row iteration is one load round trip), so waves in flight per CU are what buy bandwidth (256 blocks x 4 waves: 35 us for 108 MB,
+// 512 x 8: 20 us).
+constexpr int LNB_WAVES = 8;
+
 // ---------------------------------------------------------------------------------------------- fused input rows
 // mode 0 concat (ref :299-300): rows t<L: x + seg0 + pos[t]; row L: img + seg1 + pos[L]; row L+1: txt + seg1 + pos[L+1]
 // mode 1 add    (ref :306-307): rows t<L: x + img (+ txt if add_txt[n]) + pos[t]
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float*
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_ln_bwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+__global__ __launch_bounds__(64 * LNB_WAVES) void fuse_ln_bwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
                                                            const float* seg, const float* pos, const float* gamma, const T* dh,
                                                            const float* mean, const float* rstd, float* dy, float* partial, int N, int L, int Tk,
                                                            float p_drop, unsigned long long seed) {
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void fuse_ln_bwd_kernel(int mode, const float*
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float inv_keep = drop_inv_keep(p_drop);
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH], d[NCH];
         fused_row(mode, x, img, txt, add_txt, seg, pos, n, t, L, lane, v);
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void fuse_ln_bwd_kernel(int mode, const float*
             for (int k = 0; k < 4; ++k) d[c][k] = rs * (d[c][k] - c1 - v[c][k] * c2);
         store_row<float>(dy + (size_t)row * D, lane, d);
     }
-    fold_partials<2>(acc, partial, lds);
+    fold_partials<2, LNB_WAVES>(acc, partial, lds);
 }
 
 // ---------------------------------------------------------------------------------------------- plain LayerNorm
@@ -178,9 +183,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* y, const float* ga
     }
 }
 
-// (8 waves per block: with a few hundred persistent blocks the kernel is bound by memory LATENCY -- every row iteration is one
-// load round trip -- so waves in flight per CU are what buy bandwidth; 256 blocks x 4 waves ran at 35 us, 108 MB)
-constexpr int LNB_WAVES = 8;
 template <typename T>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
                                                       float p_drop, unsigned long long seed, float* partial, int rows) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const T* u, const floa
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dx_out, const T* u, const float* gamma, const float* mean, const float* rstd, T* du,
+__global__ __launch_bounds__(64 * LNB_WAVES) void gelu_ln_bwd_kernel(const float* dx_out, const T* u, const float* gamma, const float* mean, const float* rstd, T* du,
                                                            float* partial, int rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dx_out, c
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         f32x4 uu[NCH], v[NCH], d[NCH];
         load_row<T>(u + (size_t)row * D, lane, uu);
         load_row<float>(dx_out + (size_t)row * D, lane, d);
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void gelu_ln_bwd_kernel(const float* dx_out, c
         }
         store_row<T>(du + (size_t)row * D, lane, d);
     }
-    fold_partials<3>(acc, partial, lds);
+    fold_partials<3, LNB_WAVES>(acc, partial, lds);
 }
 
 inline int rows_grid(int rows, int cap) { int g = (rows + 3) / 4; return g < 1 ? 1 : (g > cap ? cap : g); }
@@ -321,8 +323,8 @@ extern "C" int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float*
                                uint64_t seed, void* stream) {
     DIC_REQUIRE(Dd == D && n_partial_blocks > 0, "dic_fuse_ln_bwd: D must be 768");
     const int Tk = mode == 0 ? L + 2 : (mode == 2 ? L + 1 : L);
-    dim3 grid(n_partial_blocks), block(256);
-    const size_t lds = 4 * 2 * D * sizeof(float);
+    dim3 grid(n_partial_blocks), block(64 * LNB_WAVES);
+    const size_t lds = LNB_WAVES * 2 * D * sizeof(float);            // 48 KB
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(fuse_ln_bwd_kernel<bf16_t>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, gamma, (const bf16_t*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed),
@@ -373,8 +375,14 @@ extern "C" int dic_gelu_ln_fwd(int dtype, const void* u, const float* gamma, con
 extern "C" int dic_gelu_ln_bwd(int dtype, const float* dx_out, const void* u, const float* gamma, const float* mean, const float* rstd,
                                void* du, float* partial, int n_partial_blocks, int T, int Dd, void* stream) {
     DIC_REQUIRE(Dd == D && T > 0 && n_partial_blocks > 0, "dic_gelu_ln_bwd: D must be 768");
-    dim3 grid(n_partial_blocks), block(256);
-    const size_t lds = 4 * 3 * D * sizeof(float);
+    dim3 grid(n_partial_blocks), block(64 * LNB_WAVES);
+    const size_t lds = LNB_WAVES * 3 * D * sizeof(float);            // 72 KB: above the 64 KB default cap of dynamic LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gelu_ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gelu_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(gelu_ln_bwd_kernel<bf16_t>, grid, block, lds, st, dx_out, (const bf16_t*)u, gamma, mean, rstd, (bf16_t*)du, partial, T),

@@ -245,6 +245,7 @@ class Denoiser:
         ws["partial"] = [f(NPART, 3 * D) for _ in range(5)]       # [layer parity][which LayerNorm] (folded on the side stream) + embeddings LN
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
+        ws["splitk_tail"] = f(8 * (768 * 512 + 768))   # fp32 CLIP-projection weight gradients (main stream, while the side stream owns "splitk")
         ws["splitk"] = f(64 * 1024 * 1024)          # 256 MB: split_k * M * N fp32 partial tiles of one dW GEMM / the rounding dX GEMM
         self._ws[key] = ws
         return ws
@@ -468,10 +469,13 @@ class Denoiser:
             # "add" fusion: the projected CLIP rows were broadcast over the sequence -> sum the row gradients
             _lib.check(lib.dic_seq_sum(dy0, _p(ws["addtxt"]), _p(ws["dimg"]), _p(ws["dtxt"]), N, L, D, st), "seq_sum")
             dimg, dtxt, ldd = _p(ws["dimg"]), _p(ws["dtxt"]), D
-        o.gemm(dimg, _p(ws["img_in"]), P.ptr("Wimg", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+        # 768 x 512 outputs = 24 tiles of the fp32 kernel: cut the contraction over the N sequences so the launch is not 24 workgroups
+        skt = max(1, min(8, N // 128))
+        skt_ws = _p(ws["splitk_tail"]) if skt > 1 else 0
+        o.gemm(dimg, _p(ws["img_in"]), P.ptr("Wimg", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32, split_k=skt, split_ws=skt_ws)
         colsum(DIC_F32, dimg, N, D, ldd, P.ptr("bimg", "G"))
         if mode != 2:      # text row dropped: text_linear's gradient is exactly zero (G was zeroed by zero_grad)
-            o.gemm(dtxt, _p(ws["txt_in"]), P.ptr("Wtxt", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+            o.gemm(dtxt, _p(ws["txt_in"]), P.ptr("Wtxt", "G"), D, 512, N, ldd, 512, 512, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32, split_k=skt, split_ws=skt_ws)
             colsum(DIC_F32, dtxt, N, D, ldd, P.ptr("btxt", "G"))
         if use_side:
             main.wait_stream(side)                    # every weight gradient is in G before anything downstream (AdamW, all-reduce tail)

@@ -33,3 +33,11 @@ for q, es in byq.items():
 q = max(byq, key=lambda k: len(byq[k])); es = byq[q]
 g = sorted(((es[i + 1][0] - es[i][1], es[i][2][:50], es[i + 1][2][:50]) for i in range(len(es) - 1)), reverse=True)[:12]
 for d, a, b in g: print(f"    gap {d/1e3:7.1f} us after {a} -> {b}")
+if len(sys.argv) > 2 and sys.argv[2] == "tail":
+    print("--- last kernels of the step (offset from step end, us)")
+    for s_, e_, name, q_ in sorted(win, key=lambda e: e[1])[-40:]:
+        print(f"  q{q_} start {(s_ - t1)/1e3:9.1f} end {(e_ - t1)/1e3:9.1f} dur {(e_-s_)/1e3:7.1f}  {name[:90]}")
+if len(sys.argv) > 2 and sys.argv[2] == "head":
+    print("--- first kernels of the step (offset from step start, us)")
+    for s_, e_, name, q_ in sorted(win)[:45]:
+        print(f"  q{q_} start {(s_ - t0)/1e3:9.1f} end {(e_ - t0)/1e3:9.1f} dur {(e_-s_)/1e3:7.1f}  {name[:100]}")
