@@ -146,8 +146,10 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
 
     # ---- one stacked encoder batch: [x_t rows | guided copies | x_1 rows]
     xin = ws["xin"]
-    xin[:Nt].copy_(x_t)
-    xin[Nt + Ng:].copy_(x_1)
+    if x_t.data_ptr() != xin.data_ptr():                  # (train_func lets q_sample write into the workspace directly)
+        xin[:Nt].copy_(x_t)
+    if x_1.data_ptr() != xin[Nt + Ng:].data_ptr():
+        xin[Nt + Ng:].copy_(x_1)
     img = image_clip.to(dev, torch.float32)
     txt = text_clip.to(dev, torch.float32)
     img_rep, txt_rep = img.repeat(S, 1), txt.repeat(S, 1)
@@ -262,7 +264,10 @@ class AdamW:
         self.grad_scale = 1.0          # 1/world_size after the RCCL sum (parallel.py)
 
     def zero_grad(self, set_to_none=False):
-        self.store.G.zero_()
+        # Denoiser.backward overwrites every gradient it produces; only the few slots a step may leave untouched (position rows
+        # beyond the sequence, text_linear when the text row is skipped) need clearing, and backward() does that itself when
+        # this flag is set -- instead of a 347 MB fill per step.
+        self.store.zero_pending = True
 
     def _launch(self, lo, hi):
         g = self.param_groups[0]
@@ -324,13 +329,20 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
         t = parallel.shared_randint(0, cfg.STEP_TOT, (S, 1, 1), dev)     # one t-vector per step shared by the batch (ref :461)
     t = t.to(dev)
     nz = list(noises) if noises is not None else [None, None, None]
+    # without classifier-free guidance the stacked encoder batch is [x_t rows | x_1 rows]: q_sample writes straight into it
+    out_t = out_1 = None
+    if float(cfg.CLASSIFIER_FREE_WEIGHT) <= 0 and cfg.X_0_PREDICTION:
+        Bc, Lc = x_0.shape[0], x_0.shape[1]
+        Nt = t.numel() * Bc
+        xin = model._workspace(Nt + Bc, Lc, model.concat and cfg.DROP_UNUSED_TEXT_ROW)["xin"]
+        out_t, out_1 = xin[:Nt], xin[Nt:]
     if cfg.X_0_PREDICTION:
-        x_t = diffuse_t(x_0, t, noise=nz.pop(0))
+        x_t = diffuse_t(x_0, t, noise=nz.pop(0), out=out_t)
         x_tgt = None
     else:
         t_next = torch.max(t - cfg.X_T_STEP_INTERVAL, torch.zeros_like(t))
         x_t, x_tgt = generate_diffuse_pair(x_0, t, t_next, noises=(nz.pop(0), nz.pop(0)))
-    x_1 = diffuse_t(x_0, torch.ones(1, dtype=torch.int64, device=dev), noise=nz.pop(0))
+    x_1 = diffuse_t(x_0, torch.ones(1, dtype=torch.int64, device=dev), noise=nz.pop(0), out=out_1)
     if train:
         trainer.zero_grad()
     x_t_loss, x_1_loss, prob_loss = loss(model, x_t, x_1, x_tgt, x_0, x["image_clip"], x["text_clip"], x["attention_mask"],

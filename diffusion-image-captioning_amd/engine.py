@@ -341,6 +341,12 @@ class Denoiser:
         # ---- weight gradients on a second stream.  dW = dY^T X depends only on dY and on activations saved by the forward, never
         # feeds the dX chain, and is MFMA-bound, while the chain it leaves behind alternates MFMA-bound GEMMs with HBM-bound
         # LayerNorm / attention kernels and store-heavy epilogues: letting the two streams share the CUs overlaps those phases.
+        if P.zero_pending:          # zero_grad(): clear what this backward will not overwrite
+            P.zero_pending = False
+            P.slot_view(P.G, "pos")[Tk:].zero_()
+            if ws["mode"] == 2:
+                P.slot_view(P.G, "Wtxt").zero_()
+                P.slot_view(P.G, "btxt").zero_()
         main = torch.cuda.current_stream()
         use_side = self.bf16 and _os.environ.get("DIC_WGRAD_STREAM", "1") == "1" and self.wgrad_stream_enabled
         side = self._side_stream() if use_side else None

@@ -50,6 +50,7 @@ class ParamStore:
             add("seg", (2, dim))
         self.numel = off
         self.text_unused = False      # set per step by diffusion.loss(): text_linear takes no part in the graph
+        self.zero_pending = False     # set by AdamW.zero_grad(): the next backward clears the gradient slots it does not write
         self.P = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.G = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if bf16_shadow else None
