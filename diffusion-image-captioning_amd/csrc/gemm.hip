@@ -638,7 +638,26 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
     const unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;
     const unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
 
-    __amdgpu_buffer_rsrc_t rsA, rsB;
+    // The LDS-DMA is issued through inline asm on purpose.  With the builtin, the compiler's waitcnt pass cannot tell which LDS bytes a
+    // pending `buffer_load ... lds` will write, so it puts `s_waitcnt vmcnt(0)` in front of EVERY later ds_read: the K loop then
+    // waits for the DMA of the next stage before it reads the current one, and the two stages run back to back instead of
+    // overlapping (measured: 1.58 us per K-step = 1.21 us of LDS reads + MFMA plus most of the 0.90 us DMA).  Hidden from the
+    // pass, the DMA is ordered by the explicit `s_waitcnt vmcnt(0)` + `s_barrier` that publishes a stage (dma_barrier below).
+    i32x4 rsA, rsB;                                   // buffer resource words: base, base_hi (stride 0), num_records, flags
+    auto make_rsrc = [](const void* base, long long bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+        r[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        r[3] = 0x00020000;
+        return r;
+    };
+    auto dma16 = [](unsigned voff, const i32x4& rsrc, unsigned lds_addr) {   // 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1 KiB)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+    };
+    // every wave's DMA pieces of the stage being published have landed, and every wave is done reading the stage being recycled
+    auto dma_barrier = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     unsigned voA[G::PA], voB[G::PB];
     auto setup = [&](const TileId& tl) {          // descriptors anchored at the tile origin: OOB rows/k read as zero
         const int m0 = tl.bm * G::BM, n0 = tl.bn * G::BN;
@@ -648,8 +667,8 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         long long b_bytes = BKM ? ((long long)(p.K - 1) * p.ldb + (p.N - n0)) * S : ((long long)(p.N - n0 - 1) * p.ldb + p.K) * S;
         if (a_bytes > 0xFFFFFFF0ll) a_bytes = 0xFFFFFFF0ll;
         if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_bytes, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_bytes, 0x00020000);
+        rsA = make_rsrc(Ab, a_bytes);
+        rsB = make_rsrc(Bb, b_bytes);
         const unsigned ka = (unsigned)tl.kt0 * stepA, kb = (unsigned)tl.kt0 * stepB;
 #pragma unroll
         for (int j = 0; j < G::PA; ++j) {
@@ -664,17 +683,18 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
             else { constexpr int CPRW = G::BN / 8; const int row = q * (64 / CPRW) + lane / CPRW; voB[j] = kb + (unsigned)row * (unsigned)p.ldb * 2u + (((lane % CPRW) ^ km_key(row)) << 4); }
         }
     };
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_PTR(char))smem;
     auto issue = [&](int stage) {
-        char* dstA = smem + stage * G::STAGE + wave * (G::PA * 1024);
-        char* dstB = smem + stage * G::STAGE + G::A_BYTES + wave * (G::PB * 1024);
+        const unsigned dstA = __builtin_amdgcn_readfirstlane(lds_base + stage * G::STAGE + wave * (G::PA * 1024));
+        const unsigned dstB = __builtin_amdgcn_readfirstlane(lds_base + stage * G::STAGE + G::A_BYTES + wave * (G::PB * 1024));
 #pragma unroll
         for (int j = 0; j < G::PA; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_PTR(void))(dstA + j * 1024), 16, (int)voA[j], 0, 0, 0);
+            dma16(voA[j], rsA, dstA + j * 1024);
             voA[j] += stepA;
         }
 #pragma unroll
         for (int j = 0; j < G::PB; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_PTR(void))(dstB + j * 1024), 16, (int)voB[j], 0, 0, 0);
+            dma16(voB[j], rsB, dstB + j * 1024);
             voB[j] += stepB;
         }
     };
@@ -726,6 +746,41 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         }
     };
 
+    // ---- 256-tile main loop, software-pipelined across the per-step barrier ------------------------------------------------------
+    // A K-step's barrier sits before its LAST MFMA group; right after it the wave (a) re-arms the stage it has just finished reading
+    // with the DMA of K-step kt+2 and (b) reads the first fragment group of stage kt+1, and only then issues the last MFMA group
+    // of stage kt from fragments already in registers.  No wave starts a K-step waiting on LDS, and a DMA batch has ~1.75 K-steps
+    // to land instead of one.  (128-tiles: two workgroups per CU already cover each other; the plain order measured faster.)
+    auto ldB = [&](const char* lb, int kk, bf16x8 (&fb)[G::FN]) {
+#pragma unroll
+        for (int j = 0; j < G::FN; ++j) fb[j] = frag(lb, BKM ? ofB[j] + kk * 32 * ROWB_B : ofB[j] ^ (kk * 64), BKM, ROWB_B);
+    };
+    auto ldA = [&](const char* la, int kk, int ih, bf16x8 (&fa)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = frag(la, AKM ? ofA[ih + i] + kk * 32 * ROWB_A : ofA[ih + i] ^ (kk * 64), AKM, ROWB_A);
+    };
+    auto mm = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[G::FN], int ih) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < G::FN; ++j)
+                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih + i][j], 0, 0, 0);
+    };
+    auto colsum_step = [&](const char* la) {
+        if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
+            if (do_cs) {
+#pragma unroll
+                for (int r = 0; r < 64 / CS_GROUPS; ++r) {
+                    const int rho = tid / CS_CPR + CS_GROUPS * r;
+                    f32x4 a, b;
+                    unpack8(*(const i32x4*)(la + rho * ROWB_A + (((tid % CS_CPR) ^ km_key(rho)) << 4)), a, b);
+                    cs0 += a; cs1 += b;
+                }
+            }
+        }
+    };
+    constexpr bool PIPE = G::FM == 8;
+
     // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
     // addressing set-up is paid once per workgroup and the tail of the launch is balanced by unit order, not dispatch order.
     const int total = total_units(p, G::BM, G::BN);
@@ -733,7 +788,8 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
     TileId tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
-    __syncthreads();                     // (the compiler drains the LDS-DMA with vmcnt(0) ahead of the barrier)
+    if constexpr (PIPE) { if (tl.kt0 + 1 < tl.kt1) issue(1); }
+    dma_barrier();
     for (;;) {
 #pragma unroll
         for (int i = 0; i < G::FM; ++i)
@@ -745,11 +801,33 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         }
         const int nk = tl.kt1;
         int cur = 0;
-        for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
-            if (kt + 1 < nk) issue(cur ^ 1);           //  register allocator keep two copies of the accumulator tile)
-            compute(cur);                              // next K-step's DMA flies under this step's MFMAs
-            __syncthreads();
-            cur ^= 1;
+        if constexpr (PIPE) {
+            bf16x8 pa[4], pb[G::FN], qa[4], qb[G::FN];
+            if (tl.kt0 < nk) { ldB(smem + G::A_BYTES, 0, pb); ldA(smem, 0, 0, pa); }
+            for (int kt = tl.kt0; kt < nk; ++kt) {
+                const char* la = smem + cur * G::STAGE;
+                const char* lb = la + G::A_BYTES;
+                const char* na = smem + (cur ^ 1) * G::STAGE;
+                colsum_step(la);
+                ldA(la, 0, 4, qa);
+                mm(pa, pb, 0);
+                ldB(lb, 1, qb); ldA(la, 1, 0, pa);
+                mm(qa, pb, 4);
+                ldA(la, 1, 4, qa);
+                mm(pa, qb, 0);
+                dma_barrier();                                // stage kt+1 has landed everywhere; stage kt is read out
+                if (kt + 2 < nk) issue(cur);
+                if (kt + 1 < nk) { ldB(na + G::A_BYTES, 0, pb); ldA(na, 0, 0, pa); }
+                mm(qa, qb, 4);
+                cur ^= 1;
+            }
+        } else {
+            for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
+                if (kt + 1 < nk) issue(cur ^ 1);           //  register allocator keep two copies of the accumulator tile)
+                compute(cur);                              // next K-step's DMA flies under this step's MFMAs
+                dma_barrier();
+                cur ^= 1;
+            }
         }
         DicGemmParams pe = p;
         if (p.split_k > 1) redirect_to_slab(pe, tl.kz);
@@ -783,7 +861,8 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         setup(tl);
         barrier_lds_only();              // every wave is done with the LDS-staged output tile; its stores drain under the next DMA
         if (tl.kt0 < tl.kt1) issue(0);
-        __syncthreads();
+        if constexpr (PIPE) { if (tl.kt0 + 1 < tl.kt1) issue(1); }
+        dma_barrier();
     }
 }
 
