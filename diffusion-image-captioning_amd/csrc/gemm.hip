@@ -746,41 +746,6 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         }
     };
 
-    // ---- 256-tile main loop, software-pipelined across the per-step barrier ------------------------------------------------------
-    // A K-step's barrier sits before its LAST MFMA group; right after it the wave (a) re-arms the stage it has just finished reading
-    // with the DMA of K-step kt+2 and (b) reads the first fragment group of stage kt+1, and only then issues the last MFMA group
-    // of stage kt from fragments already in registers.  No wave starts a K-step waiting on LDS, and a DMA batch has ~1.75 K-steps
-    // to land instead of one.  (128-tiles: two workgroups per CU already cover each other; the plain order measured faster.)
-    auto ldB = [&](const char* lb, int kk, bf16x8 (&fb)[G::FN]) {
-#pragma unroll
-        for (int j = 0; j < G::FN; ++j) fb[j] = frag(lb, BKM ? ofB[j] + kk * 32 * ROWB_B : ofB[j] ^ (kk * 64), BKM, ROWB_B);
-    };
-    auto ldA = [&](const char* la, int kk, int ih, bf16x8 (&fa)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = frag(la, AKM ? ofA[ih + i] + kk * 32 * ROWB_A : ofA[ih + i] ^ (kk * 64), AKM, ROWB_A);
-    };
-    auto mm = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[G::FN], int ih) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < G::FN; ++j)
-                acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih + i][j], 0, 0, 0);
-    };
-    auto colsum_step = [&](const char* la) {
-        if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
-            if (do_cs) {
-#pragma unroll
-                for (int r = 0; r < 64 / CS_GROUPS; ++r) {
-                    const int rho = tid / CS_CPR + CS_GROUPS * r;
-                    f32x4 a, b;
-                    unpack8(*(const i32x4*)(la + rho * ROWB_A + (((tid % CS_CPR) ^ km_key(rho)) << 4)), a, b);
-                    cs0 += a; cs1 += b;
-                }
-            }
-        }
-    };
-    constexpr bool PIPE = G::FM == 8;
-
     // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
     // addressing set-up is paid once per workgroup and the tail of the launch is balanced by unit order, not dispatch order.
     const int total = total_units(p, G::BM, G::BN);
@@ -788,7 +753,6 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
     TileId tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
-    if constexpr (PIPE) { if (tl.kt0 + 1 < tl.kt1) issue(1); }
     dma_barrier();
     for (;;) {
 #pragma unroll
@@ -801,33 +765,13 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         }
         const int nk = tl.kt1;
         int cur = 0;
-        if constexpr (PIPE) {
-            bf16x8 pa[4], pb[G::FN], qa[4], qb[G::FN];
-            if (tl.kt0 < nk) { ldB(smem + G::A_BYTES, 0, pb); ldA(smem, 0, 0, pa); }
-            for (int kt = tl.kt0; kt < nk; ++kt) {
-                const char* la = smem + cur * G::STAGE;
-                const char* lb = la + G::A_BYTES;
-                const char* na = smem + (cur ^ 1) * G::STAGE;
-                colsum_step(la);
-                ldA(la, 0, 4, qa);
-                mm(pa, pb, 0);
-                ldB(lb, 1, qb); ldA(la, 1, 0, pa);
-                mm(qa, pb, 4);
-                ldA(la, 1, 4, qa);
-                mm(pa, qb, 0);
-                dma_barrier();                                // stage kt+1 has landed everywhere; stage kt is read out
-                if (kt + 2 < nk) issue(cur);
-                if (kt + 1 < nk) { ldB(na + G::A_BYTES, 0, pb); ldA(na, 0, 0, pa); }
-                mm(qa, qb, 4);
-                cur ^= 1;
-            }
-        } else {
-            for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
-                if (kt + 1 < nk) issue(cur ^ 1);           //  register allocator keep two copies of the accumulator tile)
-                compute(cur);                              // next K-step's DMA flies under this step's MFMAs
-                dma_barrier();
-                cur ^= 1;
-            }
+        // (A software-pipelined variant -- barrier before the last MFMA group, first fragments of the next stage prefetched across it,
+        // DMA re-armed 1.75 K-steps ahead -- was measured: +2-5 % on isolated GEMMs, -2 % on the training step; not kept.)
+        for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
+            if (kt + 1 < nk) issue(cur ^ 1);           //  register allocator keep two copies of the accumulator tile)
+            compute(cur);                              // next K-step's DMA flies under this step's MFMAs
+            dma_barrier();
+            cur ^= 1;
         }
         DicGemmParams pe = p;
         if (p.split_k > 1) redirect_to_slab(pe, tl.kz);
@@ -861,7 +805,6 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         setup(tl);
         barrier_lds_only();              // every wave is done with the LDS-staged output tile; its stores drain under the next DMA
         if (tl.kt0 < tl.kt1) issue(0);
-        if constexpr (PIPE) { if (tl.kt0 + 1 < tl.kt1) issue(1); }
         dma_barrier();
     }
 }

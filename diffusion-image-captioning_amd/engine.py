@@ -62,6 +62,7 @@ class Ops:
 import os as _os
 
 _TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "auto" (A/B switch for measurements)
+_WGRAD_TILE = _os.environ.get("DIC_WGRAD_TILE", "auto")    # tile of the weight-gradient GEMMs (A/B switch)
 _V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the register-staged v1 kernel (128-tiles only)
 N_CU = 256
 
@@ -88,6 +89,8 @@ def pick_split_k(M, N, K, bk=64, max_split=32):
     big = _TILE_MODE != "128" and M % 256 == 0 and N >= 256 and M * N >= 2304 * 768
     if _TILE_MODE == "256" and M % 256 == 0 and N >= 256:
         big = True
+    if _WGRAD_TILE in ("128", "256"):
+        big = _WGRAD_TILE == "256" and M % 256 == 0 and N >= 256
     tile, resident = (256, N_CU) if big else (128, 2 * N_CU)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     return max(1, min(max_split, resident // max(tiles, 1), nk // 8)), tile
