@@ -102,12 +102,12 @@ def main():
         # HBM traffic of the same kernels comes from PMC passes (rocprofv3 --pmc cannot run inside this process): the committed
         # summary of the last collection, valid for the default workload only
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v6_pmc_gemm_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v7_pmc_gemm_traffic.json")
         if os.path.exists(pmc) and (B, S, L, args.layers, args.dtype) == (512, 1, 16, 12, "bf16"):
             with open(pmc) as fh:
                 pj = json.load(fh)
             traffic = round(pj["gemm_fetch_bytes_per_launch_x2"] + pj["gemm_write_bytes_per_launch"])
-            traffic_src = "bytes/launch averaged over the step's GEMM launches, FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_v6_pmc_gemm_traffic.json"
+            traffic_src = "bytes/launch averaged over the step's GEMM launches, FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_v7_pmc_gemm_traffic.json"
         roof = {"bound": "mfma", "kernel": "gemm_kernel (all layouts/epilogues)", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_src, "launches_per_step": n.value // max(args.steps, 1),
                 "gemm_ms_per_step": round(ms.value / args.steps, 3), "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}

@@ -36,7 +36,9 @@ for k, n, a, b, c in rows[:40]:
 print(f"TOTAL per step ({steps} steps): fetch_x2 {2*tot_f/steps/1e6:.2f} GB  write {tot_w/steps/1e6:.2f} GB")
 ad = [r for r in rows if "adamw" in r[0]]
 if ad:
-    print(f"calibration: adamw_kernel fetch_x2 {ad[0][3]:.1f} MB, write {ad[0][4]:.1f} MB per launch (expected 16 B and 14 B per parameter)")
+    k, n, a, b, c = ad[0]
+    print(f"calibration: adamw_kernel fetch_x2 {b * n / steps:.1f} MB, write {c * n / steps:.1f} MB per step over {n // steps} launches "
+          f"(exact: 16 B read and 14 B written per parameter)")
 if len(sys.argv) > 4:
     g = gemm
     out = {"gemm_launches_per_step": g["launches"] / steps, "gemm_fetch_bytes_per_launch_x2": 2e3 * g["fetch_kb"] / g["launches"],
