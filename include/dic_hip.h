@@ -63,7 +63,7 @@ typedef struct DicGemmParams {
     int ce_rows_a; float ce_scale_a, ce_scale_b;
     int split_k; void* split_ws;/* >1: K is cut into split_k slices (fills the chip when M*N has few tiles -- the dW GEMMs);
                                    slices write fp32 partial tiles to split_ws [split_k][M*N (+M)], then folded into C in fixed order */
-    int tile;                   /* 0/128: 128x128 workgroup tiles; 256: 256x256 tiles, 8 waves (bf16, not CE_PARTIAL) -- half the
+    int tile;                   /* 0/128: 128x128 workgroup tiles; 256: 256x256 tiles, 8 waves (bf16 kernel) -- half the
                                    L2->LDS traffic per flop; worth it when M*N/65536 tiles still fill the 256 CUs */
     int cu_cap;                 /* >0: cap the persistent grid at this many CUs' worth of workgroups (bf16 kernel), leaving the rest of the chip
                                    to a kernel on another stream */
