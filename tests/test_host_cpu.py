@@ -27,6 +27,36 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert L.dic_version() >= 10
 
 
+def test_gemm_params_ctypes_mirror_matches_the_header_struct():
+    """The Python side passes DicGemmParams by pointer: field order and C types must follow include/dic_hip.h exactly
+    (and so must the binding shown in INTEGRATION.md)."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "include", "dic_hip.h")).read()
+    body = re.search(r"typedef struct DicGemmParams \{(.*?)\} DicGemmParams;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        head, *rest = [d.strip() for d in decl.split(",")]
+        ctype = head.rsplit(None, 1)[0].replace("const ", "").strip() if "*" not in head else "ptr"
+        name = head.replace("*", " ").split()[-1]
+        fields.append((name, ctype))
+        for r in rest:
+            fields.append((r.replace("*", " ").split()[-1], "ptr" if "*" in r else ctype))
+    kind = {"ptr": C.c_void_p, "int": C.c_int, "float": C.c_float, "uint64_t": C.c_uint64}
+    mirror = dic._lib.GemmParams._fields_
+    assert [n for n, _ in mirror] == [n for n, _ in fields]
+    for (n, t), (_, ct) in zip(mirror, fields):
+        assert t is kind[ct], f"{n}: {t} vs {ct}"
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    doc_fields = re.findall(r'\("(\w+)", ', doc[doc.index("class GemmParams"):doc.index("L.dic_gemm.argtypes")])
+    assert doc_fields == [n for n, _ in fields]
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
