@@ -85,8 +85,9 @@ class GradReducer:
     def __init__(self, model):
         self.G = model.params.G
         self.store = model.params
-        self.handles = []
-        self.active = is_initialized() and world_size() > 1
+        self.handles = []            # (work handle, lo, hi) in issue order
+        # DIC_FORCE_REDUCER=1: run the exchange path at world size 1 too (single-GPU test of the data-parallel code path)
+        self.active = is_initialized() and (world_size() > 1 or os.environ.get("DIC_FORCE_REDUCER", "0") == "1")
 
     def layer_done(self, i):
         """Called by Denoiser.backward right after layer i's parameter gradients are complete."""
@@ -94,21 +95,31 @@ class GradReducer:
             return
         lo = self.store.off(f"L{i}.Wqkv")
         hi = self.store.off(f"L{i + 1}.Wqkv") if i + 1 < self.store.n_layers else self.store.off("pos")
-        self.handles.append(dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.handles.append((dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
 
     def finish(self, trainer=None):
+        """Reduce the tail, then hand every slice to the optimizer as soon as ITS exchange has finished: with the fused AdamW the
+        update of the early (deep) layers runs while the last slices are still on the wire; `trainer.step()` afterwards only
+        covers what is left.  Other optimizers get the plain wait-all + 1/world scaling."""
         if not self.active:
             return
         tail = self.store.off("pos")
-        self.handles.append(dist.all_reduce(self.G[tail:], op=dist.ReduceOp.SUM, async_op=True))
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+        self.handles.append((dist.all_reduce(self.G[tail:], op=dist.ReduceOp.SUM, async_op=True), tail, self.store.numel))
         w = world_size()
-        if trainer is not None and hasattr(trainer, "grad_scale"):
+        streamed = trainer is not None and hasattr(trainer, "step_range") and hasattr(trainer, "begin_step")
+        if streamed:
             trainer.grad_scale = 1.0 / w
-        else:
-            self.G.mul_(1.0 / w)
+            trainer.begin_step()
+        for h, lo, hi in self.handles:
+            h.wait()                                   # the current stream waits for this slice only
+            if streamed and hi <= tail:
+                trainer.step_range(lo, hi)
+        self.handles = []
+        if not streamed:
+            if trainer is not None and hasattr(trainer, "grad_scale"):
+                trainer.grad_scale = 1.0 / w
+            else:
+                self.G.mul_(1.0 / w)
 
 
 def allreduce_grads(model, trainer=None):

@@ -164,6 +164,44 @@ def test_training_with_dropout_runs_and_is_replayable():
     assert all(np.isfinite(losses[0])) and losses[0][2] < losses[0][0]
 
 
+def test_data_parallel_code_path_on_one_gpu_matches_the_plain_step(monkeypatch):
+    """RCCL at world size 1 with the exchange path forced on: per-layer all-reduce slices issued from the backward, AdamW
+    stepping each slice as its exchange finishes.  Must take bit-identical steps to the single-process path."""
+    import torch.distributed as dist
+    dic.cfg.update(BATCH_SIZE=4, SAMPLE_SIZE=2, MAX_LENGTH=16, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0,
+                   X_0_PREDICTION=True, VOCAB_SIZE=2000)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(2000, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(4, 16, 2000, 1).items()}
+
+    def run():
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=2, dropout=0.1, attention_dropout=0.1), dtype="bf16", seed=3)
+        model.load_state(synth.denoiser_state(2, 0))
+        trainer = dic.AdamW(model.parameters(), lr=1e-4)
+        dic.seed_noise(99)
+        ls = []
+        for step in range(3):
+            t = torch.from_numpy(synth.uniform_int(synth.stream_id("t", step), (2, 1, 1), 0, 100))
+            l, *_ = dic.train_func(model, trainer, x, t=t)
+            ls.append(f(l))
+        torch.cuda.synchronize()
+        return ls, model.params.P.clone()
+
+    plain_losses, plain_P = run()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29731")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("DIC_FORCE_REDUCER", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dp_losses, dp_P = run()
+    finally:
+        dist.destroy_process_group()
+    assert dp_losses == plain_losses
+    assert torch.equal(dp_P, plain_P)
+
+
 def test_reference_trainer_torch_adamw_also_works():
     z, m = load_golden("base_b4s3l16")
     model, x = build_model(m, "fp32", z)
