@@ -466,13 +466,22 @@ class Denoiser:
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                        P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
                                        _p(ws["dy0"]), parts[4], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
-        colsum(DIC_F32, parts[4], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"))                   # [eln_g | eln_b]
         dy0 = _p(ws["dy0"])
-        colsum(DIC_F32, dy0, N, Tk * D, Tk * D, P.ptr("pos", "G"))                            # dpos[0:Tk]
+        small_rows = N <= 1024                   # dic_colsum's single-launch path needs no workspace (the two-stage path shares `csw`)
+
+        def embedding_grads():                   # feed only G: under the CLIP-projection GEMMs below, on the side stream
+            s_ = o.stream
+            _lib.check(lib.dic_colsum(DIC_F32, parts[4], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"), 0, csw, s_), "colsum")   # [eln_g | eln_b]
+            _lib.check(lib.dic_colsum(DIC_F32, dy0, N, Tk * D, Tk * D, P.ptr("pos", "G"), 0, csw, s_), "colsum")             # dpos[0:Tk]
+            if self.concat:
+                gpos = P.ptr("pos", "G")
+                _lib.check(lib.dic_colsum(DIC_F32, gpos, L, D, D, P.ptr("seg", "G"), 0, csw, s_), "colsum")                  # dseg[0] = sum_{t<L}
+                _lib.check(lib.dic_colsum(DIC_F32, gpos + L * D * 4, Tk - L, D, D, P.ptr("seg", "G") + D * 4, 0, csw, s_), "colsum")   # dseg[1]
+        if small_rows:
+            on_side(embedding_grads)
+        else:
+            embedding_grads()
         if self.concat:
-            gpos = P.ptr("pos", "G")
-            colsum(DIC_F32, gpos, L, D, D, P.ptr("seg", "G"))                                  # dseg[0] = sum_{t<L}
-            colsum(DIC_F32, gpos + L * D * 4, Tk - L, D, D, P.ptr("seg", "G") + D * 4)         # dseg[1] = rows L (, L+1)
             dimg, dtxt, ldd = dy0 + L * D * 4, dy0 + (L + 1) * D * 4, Tk * D
         else:
             # "add" fusion: the projected CLIP rows were broadcast over the sequence -> sum the row gradients
