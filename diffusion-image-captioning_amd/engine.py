@@ -43,7 +43,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -56,12 +56,14 @@ class Ops:
         if tile is None:
             tile = choose_tile(M, N, split_k, epi) if (dt == DIC_BF16 and epi != EPI_CE_PARTIAL and (not a_km or M % 256 == 0)) else 128
         g.tile = tile
+        g.cu_cap = cu_cap
         _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
 
 
 import os as _os
 
 _TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "auto" (A/B switch for measurements)
+_WGRAD_CU_CAP = int(_os.environ.get("DIC_WGRAD_CU_CAP", "0"))   # >0: weight-gradient GEMMs keep to this many CUs (A/B switch)
 _WGRAD_TILE = _os.environ.get("DIC_WGRAD_TILE", "auto")    # tile of the weight-gradient GEMMs (A/B switch)
 _V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the register-staged v1 kernel (128-tiles only)
 N_CU = 256
@@ -392,7 +394,7 @@ class Denoiser:
 
             def launch():
                 o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0,
-                       colsum_out=cs, tile=tile)
+                       colsum_out=cs, tile=tile, cu_cap=_WGRAD_CU_CAP if use_side else 0)
             on_side(launch)
             if bias_slot is not None and not self.bf16:
                 colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
