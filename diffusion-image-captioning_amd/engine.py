@@ -156,7 +156,7 @@ class Denoiser:
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("DIC_SIDE_PRIO", "0")))
         return self._side
 
     def refresh_shadows(self):
