@@ -23,6 +23,7 @@ EXPORTS = [
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
+    "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
 ]
 
 
@@ -88,6 +89,11 @@ def lib():
             if not hasattr(L, name):
                 raise RuntimeError(f"{LIB_PATH} does not export {name}")
         L.dic_last_error.restype = C.c_char_p
+        for fn, args in (("dic_gemm_split_ws_bytes", 4), ("dic_ce_partial_bytes", 3), ("dic_colsum_ws_bytes", 3), ("dic_ln_partial_bytes", 3)):
+            getattr(L, fn).restype = C.c_size_t
+            getattr(L, fn).argtypes = [C.c_int] * args
+        L.dic_ce_n_partials.restype = C.c_int
+        L.dic_ce_n_partials.argtypes = [C.c_int, C.c_int]
         L.dic_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmParams), C.c_void_p]
         P, I, F, U64, I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
         L.dic_ce_combine.argtypes = [P, P, I, I, P, P, P, P]

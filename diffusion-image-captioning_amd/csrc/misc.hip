@@ -310,6 +310,21 @@ __global__ __launch_bounds__(64 * CS_WAVES) void colsum_small(const float* in, i
         *(f32x4*)(out + c) = v;
     }
 }
+// ---- workspace-size queries (host only) ---------------------------------------------------------------------------------
+extern "C" size_t dic_gemm_split_ws_bytes(int M, int N, int split_k, int with_colsum) {
+    if (split_k <= 1) return 0;
+    return (size_t)split_k * ((size_t)M * N + (with_colsum ? M : 0)) * sizeof(float);
+}
+extern "C" int dic_ce_n_partials(int N, int tile) { return tile == 256 ? 4 * ((N + 255) / 256) : 2 * ((N + 127) / 128); }
+extern "C" size_t dic_ce_partial_bytes(int M, int N, int tile) { return (size_t)M * dic_ce_n_partials(N, tile) * 4 * sizeof(float); }
+extern "C" size_t dic_colsum_ws_bytes(int in_dtype, int rows, int cols) {
+    if (in_dtype == DIC_F32 && rows <= 1024) return 0;
+    int nslab = (rows + 3) / 4;
+    if (nslab > 64) nslab = 64;
+    return (size_t)nslab * cols * sizeof(float);
+}
+extern "C" size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D) { return (size_t)n_partial_blocks * n_vectors * D * sizeof(float); }
+
 extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream) {
     DIC_REQUIRE(cols % 4 == 0 && rows > 0, "dic_colsum: cols must be a multiple of 4");
     if (in_dtype == DIC_F32 && rows <= 1024) {

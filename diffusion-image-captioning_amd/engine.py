@@ -259,7 +259,7 @@ class Denoiser:
         ws = self._ws.get(("ce", M))
         if ws is None:
             dev = self.device
-            np_ = max(2 * ((self.vocab + 127) // 128), 4 * ((self.vocab + 255) // 256))     # 64-column records, either tile size
+            np_ = max(self.ops.L.dic_ce_n_partials(self.vocab, 128), self.ops.L.dic_ce_n_partials(self.vocab, 256))   # either tile size
             ws = dict(M=M, np=np_, xr=torch.empty(M, 768, dtype=self.tdtype, device=dev),
                       partial=torch.empty(M, np_, 4, dtype=torch.float32, device=dev),
                       tgt_logit=torch.zeros(M, dtype=torch.float32, device=dev), lse=torch.empty(M, dtype=torch.float32, device=dev),
@@ -509,7 +509,7 @@ class Denoiser:
         W = self.W_lm_c if dtype is None else (self.W_lm if dtype == DIC_F32 else self.W_lm_c)
         f32 = dtype == DIC_F32 or (dtype is None and not self.bf16)
         tile = 128 if (f32 or _V1_BF16) else choose_tile(M, self.vocab, 1, EPI_CE_PARTIAL)
-        np_ = 4 * ((self.vocab + 255) // 256) if tile == 256 else 2 * ((self.vocab + 127) // 128)
+        np_ = o.L.dic_ce_n_partials(self.vocab, tile)
         o.gemm(_p(xr), _p(W), 0, M, self.vocab, 768, 768, 768, 0, epi=EPI_CE_PARTIAL, tgt=_p(tgt) if tgt is not None else 0,
                partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), dtype=dtype, tile=tile)
         _lib.check(o.L.dic_ce_combine(_p(cw["partial"]), _p(cw["tgt_logit"]), M, np_, _p(cw["lse"]), _p(cw["argmax"]),

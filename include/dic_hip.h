@@ -17,6 +17,7 @@
  */
 #ifndef DIC_HIP_H
 #define DIC_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -72,6 +73,18 @@ typedef struct DicGemmParams {
 } DicGemmParams;
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
+
+/* Workspace sizes (bytes) the caller must provide -- kernels never allocate.
+ *   dic_gemm_split_ws_bytes : split_ws of a split-K launch (split_k slabs of M*N fp32, + M when colsum_out is used)
+ *   dic_ce_n_partials       : records per row written to `partial` by CE_PARTIAL for this N and tile (pass to dic_ce_combine)
+ *   dic_ce_partial_bytes    : size of `partial` ([M][n_partials][4] fp32)
+ *   dic_colsum_ws_bytes     : `ws` of dic_colsum (0 when the single-launch path is taken)
+ *   dic_ln_partial_bytes    : `partial` of the LayerNorm backward kernels (n_blocks rows of n_vectors*D fp32)             */
+size_t dic_gemm_split_ws_bytes(int M, int N, int split_k, int with_colsum);
+int    dic_ce_n_partials(int N, int tile);
+size_t dic_ce_partial_bytes(int M, int N, int tile);
+size_t dic_colsum_ws_bytes(int in_dtype, int rows, int cols);
+size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
 
 /* Measurement hooks for bench.py: between begin/end every dic_gemm launch is bracketed by hipEvents recorded on its own
  * stream; end() (after the caller synchronised) returns the summed kernel time, algorithmic flops (2*M*N*K) and count. */

@@ -19,7 +19,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     dic.build()
     L = dic.lib()
     header = open(os.path.join(ROOT, "include", "dic_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(dic_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(dic_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 25, declared
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
@@ -55,6 +55,18 @@ def test_gemm_params_ctypes_mirror_matches_the_header_struct():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     doc_fields = re.findall(r'\("(\w+)", ', doc[doc.index("class GemmParams"):doc.index("L.dic_gemm.argtypes")])
     assert doc_fields == [n for n, _ in fields]
+
+
+def test_workspace_size_queries():
+    """Host-only entry points of the C-ABI: callers size every workspace from these (kernels never allocate)."""
+    L = dic.lib()
+    assert L.dic_gemm_split_ws_bytes(768, 768, 1, 0) == 0
+    assert L.dic_gemm_split_ws_bytes(3072, 768, 7, 1) == 7 * (3072 * 768 + 3072) * 4
+    assert L.dic_ce_n_partials(30522, 128) == 2 * 239 and L.dic_ce_n_partials(30522, 256) == 4 * 120
+    assert L.dic_ce_partial_bytes(16384, 30522, 256) == 16384 * 480 * 16
+    assert L.dic_colsum_ws_bytes(0, 512, 2304) == 0                      # fp32, <= 1024 rows: single launch, no workspace
+    assert L.dic_colsum_ws_bytes(1, 18432, 768) == 64 * 768 * 4
+    assert L.dic_ln_partial_bytes(512, 3, 768) == 512 * 3 * 768 * 4
 
 
 def test_product_path_fails_loudly_without_gpu():
