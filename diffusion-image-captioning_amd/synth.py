@@ -67,9 +67,11 @@ def uniform(stream: int, shape) -> np.ndarray:
 # model state (names follow the reference module tree: CLIP-DDPM.py:227-256 + HF DistilBERT)
 # ----------------------------------------------------------------------------------------
 
-def denoiser_param_specs(n_layers: int, dim: int = 768, hidden: int = 3072, max_pos: int = 512, clip_dim: int = 512):
+def denoiser_param_specs(n_layers: int, dim: int = 768, hidden: int = 3072, max_pos: int = 512, clip_dim: int = 512,
+                         train_embedding_vocab: int | None = None, in_channel: int = 16):
     """(name, shape, scale, shift) in the order `DistilBertModel.parameters()` returns them
-    (CLIP-DDPM.py:258-269): HF encoder params, image_linear, text_linear, segment_embedding."""
+    (CLIP-DDPM.py:258-269): HF encoder params, image_linear, text_linear, [TRAIN_EMBEDDING: embedding, lm_head,
+    input_projection, output_projection (:260-262)], segment_embedding."""
     specs = [
         ("model.distilbert.embeddings.position_embeddings.weight", (max_pos, dim), 0.02, 0.0),
         ("model.distilbert.embeddings.LayerNorm.weight", (dim,), 0.1, 1.0),
@@ -97,8 +99,18 @@ def denoiser_param_specs(n_layers: int, dim: int = 768, hidden: int = 3072, max_
         ("image_linear.bias", (dim,), 0.02, 0.0),
         ("text_linear.weight", (dim, clip_dim), 0.04, 0.0),
         ("text_linear.bias", (dim,), 0.02, 0.0),
-        ("segment_embedding.weight", (2, dim), 0.5, 0.0),
     ]
+    if train_embedding_vocab is not None:      # learned 16-d token space (CLIP-DDPM.py:238-243)
+        v, c = train_embedding_vocab, in_channel
+        specs += [
+            ("embedding.weight", (v, c), 1.0, 0.0),
+            ("lm_head.weight", (v, c), 0.15, 0.0),
+            ("input_projection.weight", (dim, c), 0.15, 0.0),
+            ("input_projection.bias", (dim,), 0.1, 0.0),
+            ("output_projection.weight", (c, dim), 0.03, 0.0),
+            ("output_projection.bias", (c,), 0.02, 0.0),
+        ]
+    specs.append(("segment_embedding.weight", (2, dim), 0.5, 0.0))
     return specs
 
 

@@ -126,17 +126,22 @@ def set_schedule(ns, schedule_node, cosine: bool, step_tot: int):
     exec(compile(ast.Module(body=[schedule_node], type_ignores=[]), REF, "exec"), ns)
 
 
-def build_reference_model(ns, n_layers: int, vocab: int, wseed: int):
+def build_reference_model(ns, n_layers: int, vocab: int, wseed: int, train_embedding: bool = False):
     from transformers import DistilBertConfig
     ns["VOCAB_SIZE"] = vocab
     cfg = DistilBertConfig(n_layers=n_layers, dropout=0.0, attention_dropout=0.0)
-    E = synth.vocab_embedding(vocab, 768, wseed)
-    emb = nn.Embedding(vocab, 768)
-    emb.weight.data = torch.from_numpy(E.copy())
-    proj = nn.Linear(768, vocab)
-    proj.weight.data = torch.from_numpy(E.copy())
-    model = ns["DistilBertModel"](emb, proj, config=cfg)
-    state = {k: torch.from_numpy(v) for k, v in synth.denoiser_state(n_layers, wseed).items()}
+    if train_embedding:                 # CLIP-DDPM.py:325-327: the model builds its own 16-d embedding, head and projections
+        model = ns["DistilBertModel"](config=cfg)
+        state = synth.denoiser_state(n_layers, wseed, train_embedding_vocab=vocab, in_channel=ns["IN_CHANNEL"])
+    else:
+        E = synth.vocab_embedding(vocab, 768, wseed)
+        emb = nn.Embedding(vocab, 768)
+        emb.weight.data = torch.from_numpy(E.copy())
+        proj = nn.Linear(768, vocab)
+        proj.weight.data = torch.from_numpy(E.copy())
+        model = ns["DistilBertModel"](emb, proj, config=cfg)
+        state = synth.denoiser_state(n_layers, wseed)
+    state = {k: torch.from_numpy(v) for k, v in state.items()}
     if ns["CLIP_ADDING_METHOD"] != "concat":
         state.pop("segment_embedding.weight")
     missing, unexpected = model.load_state_dict(state, strict=False)
@@ -161,20 +166,23 @@ def row_stats(logits: torch.Tensor, idx: torch.Tensor):
 
 def run_case(name, *, B, S, L, n_layers, vocab=30522, cosine=True, step_tot=1000, cfg_w=0.0,
              fusion="concat", loss_name="series_sum_sample_mean", x0_pred=True, rounding_weight=0.5,
-             store_hidden=True, n_steps=2, wseed=0, dseed=1):
+             store_hidden=True, n_steps=2, wseed=0, dseed=1, train_embedding=False):
     rng = Rng()
     ns, sched = load_reference_namespace(rng)
     ns.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, CLASSIFIER_FREE_WEIGHT=cfg_w,
               CLIP_ADDING_METHOD=fusion, LOSS_FUNC=ns[loss_name], X_0_PREDICTION=x0_pred,
               ROUNDING_WEIGHT=rounding_weight)
+    if train_embedding:                 # the reference's constants block :98-102, read at call time
+        ns.update(TRAIN_EMBEDDING=True, IN_CHANNEL=16)
     set_schedule(ns, sched, cosine, step_tot)
-    model = build_reference_model(ns, n_layers, vocab, wseed)
+    model = build_reference_model(ns, n_layers, vocab, wseed, train_embedding)
     x = torch_batch(synth.batch(B, L, vocab, dseed))
     out = {"alpha_cumprod": ns["alpha_cumprod"].numpy()}
     meta = dict(name=name, B=B, S=S, L=L, n_layers=n_layers, vocab=vocab, cosine=cosine,
                 step_tot=step_tot, cfg_w=cfg_w, cfg_prob=ns["CLASSIFIER_FREE_PROB"], fusion=fusion,
                 loss=loss_name, x0_pred=x0_pred, rounding_weight=rounding_weight, wseed=wseed,
-                dseed=dseed, lr=1e-4, x_t_step_interval=ns["X_T_STEP_INTERVAL"],
+                dseed=dseed, lr=1e-4, x_t_step_interval=ns["X_T_STEP_INTERVAL"], train_embedding=train_embedding,
+                in_channel=ns["IN_CHANNEL"],
                 torch=torch.__version__, transformers=importlib.import_module("transformers").__version__)
 
     # ---- eval-mode forward pieces, step seed 123 (the same draws train step 0 will use)
@@ -224,13 +232,14 @@ def run_case(name, *, B, S, L, n_layers, vocab=30522, cosine=True, step_tot=1000
     # ---- training steps (dropout p=0 in the config so train == eval numerics), AdamW as CLIP-DDPM.py:335
     model.train()
     trainer = optim.AdamW(model.parameters(), lr=1e-4)
-    names = [n for n, _, _, _ in synth.denoiser_param_specs(n_layers)]
+    spec_kw = dict(train_embedding_vocab=vocab, in_channel=ns["IN_CHANNEL"]) if train_embedding else {}
+    names = [n for n, _, _, _ in synth.denoiser_param_specs(n_layers, **spec_kw)]
     if fusion != "concat":
         names = names[:-1]
     params = model.parameters()
     assert len(params) == len(names)
     for (n, p), q in zip(zip(names, params), params):
-        assert tuple(p.shape) == tuple(dict((a, b) for a, b, _, _ in synth.denoiser_param_specs(n_layers))[n]), n
+        assert tuple(p.shape) == tuple(dict((a, b) for a, b, _, _ in synth.denoiser_param_specs(n_layers, **spec_kw))[n]), n
     step_losses, grad_norms, param_norms, grad_heads, param_heads = [], [], [], [], []
     for step in range(n_steps):
         rng.reset(123 + step)
@@ -319,6 +328,8 @@ def main():
              cfg_w=0.3, store_hidden=False, vocab=2000)
     # E: sampling loop
     run_sampling_case("sample_b3k3", B=3, L=16, n_layers=2, steps=3)
+    # F: TRAIN_EMBEDDING ablation (:98-102, 238-243, 292-293, 319-320): learned 16-d embedding / head / projections
+    run_case("trainemb_b3s2l16", B=3, S=2, L=16, n_layers=2, vocab=2000, cosine=False, step_tot=100, train_embedding=True)
 
 
 if __name__ == "__main__":

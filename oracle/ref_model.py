@@ -43,6 +43,7 @@ class Config:
     USE_X_1_LOSS: bool = True
     USE_PROB_LOSS: bool = True
     IN_CHANNEL: int = 768
+    TRAIN_EMBEDDING: bool = False  # :98-102: learned 16-d embedding + projections instead of the frozen DistilBERT one
     LEARNING_RATE: float = 1e-4
     # denoiser (HF DistilBertConfig defaults, CLIP-DDPM.py:236,330)
     n_layers: int = 6
@@ -145,10 +146,10 @@ class Denoiser:
         return [self.p[n] for n in names]
 
     def embedding(self, ids):            # CLIP-DDPM.py:459
-        return self.E[ids]
+        return (self.p["embedding.weight"] if self.cfg.TRAIN_EMBEDDING else self.E)[ids]
 
-    def lm_head(self, h):                # CLIP-DDPM.py:323 (bias == 0)
-        return h @ self.W_lm.t()
+    def lm_head(self, h):                # CLIP-DDPM.py:323 (bias == 0; TRAIN_EMBEDDING: trainable, bias=False, :240)
+        return h @ (self.p["lm_head.weight"] if self.cfg.TRAIN_EMBEDDING else self.W_lm).t()
 
     # ---- HF encoder + MLM-head transform (hf:92-118, 150-259, 501-513)
     def encoder(self, x, key_mask):
@@ -180,6 +181,8 @@ class Denoiser:
         assert image_clip.shape == text_clip.shape == (n, 1, 512)
         assert mask.shape == (n, L) and concat_mask.shape == (n, 2)
         guided = concat_mask[:, 1] == 1
+        if cfg.TRAIN_EMBEDDING:            # :292-293
+            x = F.linear(x, p["input_projection.weight"], p["input_projection.bias"])
         img = F.linear(image_clip, p["image_linear.weight"], p["image_linear.bias"])
         txt = F.linear(text_clip, p["text_linear.weight"], p["text_linear.bias"])
         mask = mask.to(torch.int64)
@@ -201,6 +204,8 @@ class Denoiser:
             g_out = self.encoder(xg[guided], guided_mask[guided])
             mixed = (1 + w) * g_out - w * x_out[guided]
             x_out = x_out.index_put((guided.nonzero().squeeze(1),), mixed)
+        if cfg.TRAIN_EMBEDDING:            # :319-320
+            x_out = F.linear(x_out, p["output_projection.weight"], p["output_projection.bias"])
         logits = self.lm_head(x_out[:, :L, :]) if with_logits else None
         return logits, x_out
 
