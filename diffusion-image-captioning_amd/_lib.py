@@ -24,6 +24,7 @@ EXPORTS = [
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
+    "dic_te_dx0", "dic_embed_scatter",
 ]
 
 
@@ -93,6 +94,8 @@ def lib():
             getattr(L, fn).restype = C.c_size_t
             getattr(L, fn).argtypes = [C.c_int] * args
         L.dic_ce_n_partials.restype = C.c_int
+        L.dic_te_dx0.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
+        L.dic_embed_scatter.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
         L.dic_ce_n_partials.argtypes = [C.c_int, C.c_int]
         L.dic_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmParams), C.c_void_p]
         P, I, F, U64, I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64

@@ -310,6 +310,57 @@ __global__ __launch_bounds__(64 * CS_WAVES) void colsum_small(const float* in, i
         *(f32x4*)(out + c) = v;
     }
 }
+// ------------------------------------------------------------------------------------------------ TRAIN_EMBEDDING ablation
+// ref :98-102, 238-243, 459-468: with a learned embedding x_0 = E[ids] carries gradient -- through q_sample into every noised copy
+// (x_t[s] = sqrt_ac[t_s] x_0 + ..., x_1 = sqrt_ac[1] x_0 + ...) and as the TARGET of both embedding losses.
+//   dx0[b][l][c] = sum_s ( sqrt_ac[t_s] * dxin[s*B+b][l][c] - g[s*B+b][l][c] ) + sqrt_ac[1] * dxin[S*B+b][l][c] - g[S*B+b][l][c]
+// dxin = gradient wrt the stacked 16-d encoder input, g = gradient of the embedding losses wrt the model's 16-d output
+// (both [S*B + B][Tk][C], rows t < L used).
+__global__ void te_dx0_kernel(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, int S, int B, int L, int Tk,
+                              int C, int step_tot, float* dx0) {
+    const int n = B * L * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = i % C, l = (i / C) % L, b = i / (C * L);
+        float acc = 0.f;
+        for (int s_ = 0; s_ <= S; ++s_) {
+            long long ts = s_ < S ? t[s_] : 1;
+            ts = ts < 0 ? 0 : (ts >= step_tot ? step_tot - 1 : ts);
+            const size_t row = ((size_t)(s_ * B + b) * Tk + l) * C + c;
+            acc += sqrt_ac[ts] * dxin[row] - g[row];
+        }
+        dx0[i] = acc;
+    }
+}
+extern "C" int dic_te_dx0(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, int S, int B, int L, int Tk, int C,
+                          int step_tot, float* dx0, void* stream) {
+    DIC_REQUIRE(S > 0 && B > 0 && L > 0 && Tk >= L && C > 0, "dic_te_dx0: bad arguments");
+    hipLaunchKernelGGL(te_dx0_kernel, dim3(grid_for((long long)B * L * C, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dxin, g, sqrt_ac, t, S,
+                       B, L, Tk, C, step_tot, dx0);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+// dE[id][:] = sum of dx0 rows of the token positions holding `id` (nn.Embedding backward), in ascending position order: the
+// caller passes the ids sorted (stable) with the permutation, so the sum has a fixed order and needs no atomics.  dE is
+// zeroed by the caller; ids outside [0, V) are ignored.
+__global__ void embed_scatter_kernel(const int64_t* sorted_ids, const int64_t* order, const float* dx0, int n_tokens, int C, int V, float* dE) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tokens * C; i += gridDim.x * blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        const int64_t id = sorted_ids[r];
+        if (id < 0 || id >= V || (r > 0 && sorted_ids[r - 1] == id)) continue;        // only the first position of a run works
+        float acc = 0.f;
+        for (int q = r; q < n_tokens && sorted_ids[q] == id; ++q) acc += dx0[(size_t)order[q] * C + c];
+        dE[(size_t)id * C + c] = acc;
+    }
+}
+extern "C" int dic_embed_scatter(const int64_t* sorted_ids, const int64_t* order, const float* dx0, int n_tokens, int C, int V, float* dE,
+                                 void* stream) {
+    DIC_REQUIRE(n_tokens > 0 && C > 0 && V > 0, "dic_embed_scatter: bad arguments");
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid_for((long long)n_tokens * C, 256, 1024)), dim3(256), 0, (hipStream_t)stream, sorted_ids,
+                       order, dx0, n_tokens, C, V, dE);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- workspace-size queries (host only) ---------------------------------------------------------------------------------
 extern "C" size_t dic_gemm_split_ws_bytes(int M, int N, int split_k, int with_colsum) {
     if (split_k <= 1) return 0;

@@ -119,6 +119,9 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     assert mask.shape == (B, L)
     assert idx.shape == (B, L)
     kind = _loss_kind(loss_func)
+    if model.te:
+        from . import train_embedding
+        return train_embedding.loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind)
     dev = model.device
     lib = _lib.lib()
     Nt = S * B
@@ -331,7 +334,7 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
     nz = list(noises) if noises is not None else [None, None, None]
     # without classifier-free guidance the stacked encoder batch is [x_t rows | x_1 rows]: q_sample writes straight into it
     out_t = out_1 = None
-    if float(cfg.CLASSIFIER_FREE_WEIGHT) <= 0 and cfg.X_0_PREDICTION:
+    if float(cfg.CLASSIFIER_FREE_WEIGHT) <= 0 and cfg.X_0_PREDICTION and not model.te:
         Bc, Lc = x_0.shape[0], x_0.shape[1]
         Nt = t.numel() * Bc
         xin = model._workspace(Nt + Bc, Lc, model.concat and cfg.DROP_UNUSED_TEXT_ROW)["xin"]
@@ -362,6 +365,9 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
                 hi = store.off(f"L{i + 1}.Wqkv") if i + 1 < store.n_layers else store.off("pos")
                 trainer.step_range(lo, hi)
         model.backward(layer_done=layer_done)
+        if model.te:
+            from . import train_embedding
+            train_embedding.backward_tail(model, t)      # projections, q_sample and embedding backward (x_0 carries gradient)
         reducer.finish(trainer)
         if not isinstance(trainer, AdamW):
             model.params.relink_grads()
@@ -396,6 +402,9 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
     """x_0-prediction refinement from pure noise: `steps` encoder passes feeding the prediction straight back in,
     then round to token ids.  The logits are only needed after the last pass, and only their argmax: the
     rounding GEMM runs in exact fp32 (MFMA f32) with a streaming arg-max, so ids match the CPU oracle bit-for-bit."""
+    if model.te:
+        from . import train_embedding
+        return train_embedding.sample(model, image_clip, steps, start, return_hidden)
     dev = model.device
     B, L = image_clip.shape[0], cfg.MAX_LENGTH
     Tk = L + 2 if model.concat else L

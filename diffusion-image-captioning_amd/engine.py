@@ -123,9 +123,19 @@ class Denoiser:
             raise NotImplementedError(cfg.CLIP_ADDING_METHOD)
         self.training = True
         self.ops = Ops(self.dt)
-        self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16)
+        # TRAIN_EMBEDDING ablation (ref :98-102, 238-243): learned 16-d embedding / head + projections, see train_embedding.py
+        self.te = bool(cfg.TRAIN_EMBEDDING)
+        te_kw = dict(train_embedding_vocab=int(cfg.VOCAB_SIZE), in_channel=int(cfg.IN_CHANNEL)) if self.te else {}
+        self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16, **te_kw)
         self.params.init_like_reference(seed)
-        self._set_embedding(embedding, projection)
+        if self.te:
+            assert cfg.IN_CHANNEL % 4 == 0 and cfg.IN_CHANNEL <= 32, "TRAIN_EMBEDDING: IN_CHANNEL must be a multiple of 4, at most 32"
+            self.vocab = int(cfg.VOCAB_SIZE)
+            self.vpad = (self.vocab + 127) // 128 * 128
+            self.E = self.W_lm = self.W_lm_c = None
+            self._te_pending = None
+        else:
+            self._set_embedding(embedding, projection)
         self.refresh_shadows()
         self._ws = {}
         self._seed = 0x5EED0000 + seed
@@ -197,15 +207,20 @@ class Denoiser:
         return self
 
     def embedding(self, ids):
-        """ref :459 -- frozen nn.Embedding lookup -> fp32 [..., 768]."""
+        """ref :459 -- nn.Embedding lookup -> fp32 [..., IN_CHANNEL] (frozen 768-d table, or the learned 16-d one)."""
         ids = ids.to(self.device, torch.int64).contiguous()
-        out = torch.empty(*ids.shape, 768, dtype=torch.float32, device=self.device)
+        d = self.params.in_channel if self.te else 768
+        table = self.params.slot_view(self.params.P, "E16") if self.te else self.E
+        out = torch.empty(*ids.shape, d, dtype=torch.float32, device=self.device)
         self.ops.begin()
-        _lib.check(self.ops.L.dic_embed_gather(_p(ids), _p(self.E), _p(out), ids.numel(), 768, self.vocab, self.ops.stream), "embed")
+        _lib.check(self.ops.L.dic_embed_gather(_p(ids), _p(table), _p(out), ids.numel(), d, self.vocab, self.ops.stream), "embed")
         return out
 
     def lm_head(self, h):
         """ref :323 -- logits = h @ W^T (bias is zero); materialises [.., V] fp32 (API use; training never does)."""
+        if self.te:
+            from . import train_embedding
+            return train_embedding.lm_head(self, h)
         shp = h.shape[:-1]
         x = h.reshape(-1, 768).to(self.device, self.tdtype).contiguous()
         M = x.shape[0]
@@ -554,6 +569,9 @@ class Denoiser:
         assert image_clip.shape == text_clip.shape == (n, 1, 512)
         assert mask.shape == (n, L)
         assert concat_mask.shape == (n, 2)
+        if self.te:
+            from . import train_embedding
+            return train_embedding.forward(self, x, image_clip, text_clip, mask, concat_mask, with_logits)
         dev = self.device
         x, mask, concat_mask = x.to(dev, torch.float32), mask.to(dev), concat_mask.to(dev)
         image_clip, text_clip = image_clip.to(dev, torch.float32), text_clip.to(dev, torch.float32)

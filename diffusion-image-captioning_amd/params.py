@@ -23,8 +23,10 @@ ALIGN = 64  # floats (256 B)
 
 class ParamStore:
     def __init__(self, n_layers: int, device, concat: bool = True, dim: int = 768, hidden: int = 3072,
-                 max_pos: int = 512, clip_dim: int = 512, bf16_shadow: bool = True):
+                 max_pos: int = 512, clip_dim: int = 512, bf16_shadow: bool = True, train_embedding_vocab: int | None = None,
+                 in_channel: int = 16):
         self.n_layers, self.dim, self.hidden, self.concat = n_layers, dim, hidden, concat
+        self.te_vocab, self.in_channel = train_embedding_vocab, in_channel
         self.device = torch.device(device)
         self._slots = {}     # internal slot name -> (offset, shape)
         off = 0
@@ -48,6 +50,13 @@ class ParamStore:
         add("Wtxt", (dim, clip_dim)); add("btxt", (dim,))
         if concat:
             add("seg", (2, dim))
+        if train_embedding_vocab is not None:
+            # TRAIN_EMBEDDING ablation (ref :238-243): learned token embedding / rounding head in a 16-d space and the two
+            # projections to and from the encoder width.  The head is stored with its rows padded to a tile multiple
+            # (zero rows: no gradient, no decay effect) so its weight-gradient GEMM can write whole tiles.
+            v, c = train_embedding_vocab, in_channel
+            add("E16", (v, c)); add("Wlm16", ((v + 127) // 128 * 128, c))
+            add("Win", (dim, c)); add("bin", (dim,)); add("Wout", (c, dim)); add("bout", (c,))
         self.numel = off
         self.text_unused = False      # set per step by diffusion.loss(): text_linear takes no part in the graph
         self.zero_pending = False     # set by AdamW.zero_grad(): the next backward clears the gradient slots it does not write
@@ -56,7 +65,8 @@ class ParamStore:
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if bf16_shadow else None
 
         # reference-named views, in the order of CLIP-DDPM.py:258-269
-        self.names = [n for n, _, _, _ in synth.denoiser_param_specs(n_layers)]
+        te = dict(train_embedding_vocab=train_embedding_vocab, in_channel=in_channel) if train_embedding_vocab is not None else {}
+        self.names = [n for n, _, _, _ in synth.denoiser_param_specs(n_layers, **te)]
         if not concat:
             self.names = [n for n in self.names if n != "segment_embedding.weight"]
         self._views = {n: self._view(self.P, n) for n in self.names}
@@ -89,6 +99,12 @@ class ParamStore:
         }
         if ref_name in simple:
             return self.slot_view(buf, simple[ref_name])
+        te = {"embedding.weight": "E16", "input_projection.weight": "Win", "input_projection.bias": "bin",
+              "output_projection.weight": "Wout", "output_projection.bias": "bout"}
+        if ref_name in te:
+            return self.slot_view(buf, te[ref_name])
+        if ref_name == "lm_head.weight":
+            return self.slot_view(buf, "Wlm16")[:self.te_vocab]
         assert ref_name.startswith(pre + "transformer.layer."), ref_name
         rest = ref_name[len(pre + "transformer.layer."):]
         i, rest = rest.split(".", 1)
@@ -145,12 +161,18 @@ class ParamStore:
             v = self._views[n]
             if "LayerNorm.weight" in n or "layer_norm.weight" in n:
                 v.fill_(1.0)
+            elif n in ("input_projection.bias", "output_projection.bias"):
+                bound = 1.0 / np.sqrt(self.in_channel if n.startswith("input") else self.dim)
+                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * bound).to(self.device))
             elif n.endswith(".bias") and not n.startswith(("image_linear", "text_linear")):
                 v.zero_()
             elif n.startswith(("image_linear", "text_linear")):
                 bound = 1.0 / np.sqrt(512)
                 v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * bound).to(self.device))
-            elif n == "segment_embedding.weight":
+            elif n in ("segment_embedding.weight", "embedding.weight"):           # nn.Embedding default: N(0, 1)
                 v.copy_(torch.randn(v.shape, generator=g).to(self.device))
+            elif n in ("lm_head.weight", "input_projection.weight", "output_projection.weight"):   # nn.Linear default init
+                bound = 1.0 / np.sqrt(v.shape[1])
+                v.copy_(((torch.rand(v.shape, generator=g) * 2 - 1) * bound).to(self.device))
             else:
                 v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(self.device))

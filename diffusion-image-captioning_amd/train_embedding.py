@@ -1,0 +1,284 @@
+"""TRAIN_EMBEDDING ablation of the reference (CLIP-DDPM.py:98-102, 238-243, 260-262, 292-293, 319-320, 325-327).
+
+Instead of DistilBERT's frozen 768-d token embedding the model learns a `IN_CHANNEL` = 16-d embedding and rounding head;
+`input_projection` (16 -> 768) and `output_projection` (768 -> 16) sit around the unchanged encoder, diffusion and both
+losses live in the 16-d space, and x_0 = embedding(ids) carries gradient (into q_sample and as the loss target).
+
+Not a hot path of the metric: the 16-wide GEMMs run on the exact-fp32 MFMA kernel with K padded to its 32-deep step, whatever
+the encoder's dtype; everything else reuses the kernels of the main path (q_sample, encoder forward/backward, embedding
+losses, streaming CE / dlogits, AdamW over the same flat buffers).  Supported: concat and add fusion, the four loss
+functions, x_0 prediction, no classifier-free guidance (the reference never combined the two; asking for it raises).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import DIC_F32
+from .config import cfg
+
+KP = 32          # K-step of the fp32 MFMA GEMM: the 16-d operands are zero-padded to it
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+def _check_supported(model):
+    if float(cfg.CLASSIFIER_FREE_WEIGHT) > 0:
+        raise NotImplementedError("TRAIN_EMBEDDING with classifier-free guidance is not built")
+    if not cfg.X_0_PREDICTION:
+        raise NotImplementedError("TRAIN_EMBEDDING with x_{t-1} prediction is not built")
+    assert cfg.IN_CHANNEL == model.params.in_channel, "cfg.IN_CHANNEL changed after the model was built"
+
+
+def _buffers(model, N, L, Tk, M):
+    """Scratch of the 16-d side, cached per batch geometry."""
+    key = ("te", N, L, Tk, M)
+    b = model._ws.get(key)
+    if b is None:
+        dev, C, V = model.device, model.params.in_channel, model.vocab
+
+        def f(*s):
+            return torch.zeros(*s, dtype=torch.float32, device=dev)
+        b = dict(x16=f(N, L, C), x16p=f(N * L, KP), Winp=f(768, KP), x_out16=f(N, Tk, C), Woutp=f(KP, 768), dx16=f(N, Tk, C), g16=f(N, Tk, C),
+                 dx16p=f(N * Tk, KP), xr16=f(M, C), xr32=f(M, KP), Wlm32=f(model.vpad, KP), dxr32=f(M, KP), dxr16=f(M, C),
+                 x16Tk=f(N, Tk, C), dxin16=f(N, Tk, C), dx0=f(cfg.BATCH_SIZE, L, C), dlogits=None, per_seq=f(N), gscale=f(N), out=f(8),
+                 cs=f(64 * max(Tk * C, 768)))
+        model._ws[key] = b
+    return b
+
+
+def refresh_padded_weights(model, b):
+    """Padded operand copies of the three 16-wide weights (the parameters themselves stay [.,16] in the flat buffer)."""
+    P, C = model.params, model.params.in_channel
+    b["Winp"][:, :C].copy_(P.slot_view(P.P, "Win"))
+    b["Woutp"][:C].copy_(P.slot_view(P.P, "Wout"))
+    b["Wlm32"][:, :C].copy_(P.slot_view(P.P, "Wlm16"))
+
+
+def project_in(model, b, x16, N, L):
+    """:292-293  x = input_projection(x): [N,L,16] -> the encoder's input buffer [N,L,768]."""
+    C = model.params.in_channel
+    ws = model._workspace(N, L, b["drop_txt"])
+    b["x16"].copy_(x16)
+    b["x16p"][:, :C].copy_(x16.reshape(N * L, C))
+    o, P = model.ops, model.params
+    o.begin()
+    o.gemm(_p(b["x16p"]), _p(b["Winp"]), _p(ws["xin"]), N * L, 768, KP, KP, KP, 768, bias=P.ptr("bin"), out_f32=1, dtype=DIC_F32)
+    return ws["xin"]
+
+
+def project_out(model, b, x_out768, N, Tk):
+    """:319-320  x_out = output_projection(x_out): [N,Tk,768] -> [N,Tk,16]."""
+    C = model.params.in_channel
+    o, P = model.ops, model.params
+    o.begin()
+    o.gemm(_p(x_out768), P.ptr("Wout"), _p(b["x_out16"]), N * Tk, C, 768, 768, 768, C, bias=P.ptr("bout"), out_f32=1, dtype=DIC_F32)
+    return b["x_out16"]
+
+
+def _masks(model, mask, S, B, L, drop_txt):
+    dev = model.device
+    m = (mask.to(dev) != 0).to(torch.uint8)
+    m_rep = m.repeat(S, 1)
+    if model.concat:
+        one_t = torch.ones(S * B, 1, dtype=torch.uint8, device=dev)
+        one_b = torch.ones(B, 1, dtype=torch.uint8, device=dev)
+        pt = torch.cat([m_rep, one_t] if drop_txt else [m_rep, one_t, 0 * one_t], 1)
+        pb = torch.cat([m, one_b] if drop_txt else [m, one_b, 0 * one_b], 1)
+        return torch.cat([pt, pb])
+    return torch.cat([m_rep, m])
+
+
+def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind):
+    """`loss` (ref :382-445) with the learned embedding: returns the three loss scalars and, under grad mode, leaves the encoder's
+    output gradient in the workspace (so `model.backward()` runs as usual) plus what `backward_tail` needs."""
+    _check_supported(model)
+    S, B, L, C = cfg.SAMPLE_SIZE, cfg.BATCH_SIZE, cfg.MAX_LENGTH, cfg.IN_CHANNEL
+    dev, lib = model.device, _lib.lib()
+    Nt = S * B
+    N = Nt + B
+    M = N * L
+    want_grad = torch.is_grad_enabled()
+    drop_txt = model.concat and cfg.DROP_UNUSED_TEXT_ROW
+    ws = model._workspace(N, L, drop_txt)
+    Tk = ws["Tk"]
+    b = _buffers(model, N, L, Tk, M)
+    b["drop_txt"] = drop_txt
+    model.params.text_unused = not model.concat
+    refresh_padded_weights(model, b)
+    x16 = torch.cat([x_t.to(dev, torch.float32), x_1.to(dev, torch.float32)])
+    xin = project_in(model, b, x16, N, L)
+    img = image_clip.to(dev, torch.float32)
+    txt = text_clip.to(dev, torch.float32)
+    ic, tc = torch.cat([img.repeat(S, 1), img]), torch.cat([txt.repeat(S, 1), txt])
+    km = _masks(model, mask, S, B, L, drop_txt)
+    add_txt = torch.zeros(N, dtype=torch.uint8, device=dev)
+    x_out768 = model.encode(xin, ic, tc, km, add_txt, drop_txt=drop_txt)
+    x_out16 = project_out(model, b, x_out768, N, Tk)
+    st = model.ops.stream
+
+    # ---- embedding losses on the 16-d output (ref :77-87: the mean / the literal 768 of `series_sum` are the reference's)
+    if kind == 0:
+        sa, sb = 1.0 / (Nt * C), 1.0 / (B * C)
+    elif kind == 1:
+        sa = sb = 1.0 / cfg.BATCH_SIZE / 768 / 100
+    elif kind == 2:
+        sa, sb = 1.0 / Nt, 1.0 / B
+    else:
+        sa = sb = 1.0 / cfg.BATCH_SIZE
+    if not cfg.USE_X_T_LOSS:
+        sa = 0.0
+    if not cfg.USE_X_1_LOSS:
+        sb = 0.0
+    b["gscale"][:Nt].fill_(sa)
+    b["gscale"][Nt:].fill_(sb)
+    x_0c = x_0.to(dev, torch.float32).contiguous()
+    dx = _p(b["dx16"]) if want_grad else 0
+    row = Tk * C
+    _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16), _p(x_0c), B, _p(b["per_seq"]), dx, _p(b["gscale"]), _p(b["xr16"]), Nt, L, Tk, C, st),
+               "emb_loss")
+    off = Nt * row * 4
+    _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16) + off, _p(x_0c), B, _p(b["per_seq"]) + Nt * 4, (dx + off) if want_grad else 0,
+                                _p(b["gscale"]) + Nt * 4, _p(b["xr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "emb_loss")
+    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), N, Nt, sa, sb, _p(b["out"]), st), "seg_sum")
+    if want_grad:
+        b["g16"].copy_(b["dx16"])                  # the loss gradient alone: its negative flows into the target x_0
+
+    # ---- rounding loss on the learned head (ref :323, 432-445)
+    if cfg.USE_PROB_LOSS:
+        cw = model._ce_workspace(M)
+        ids = idx.to(dev, torch.int64)
+        cw["tgt"][:Nt * L].copy_(ids.repeat(S, 1).reshape(-1))
+        cw["tgt"][Nt * L:].copy_(ids.reshape(-1))
+        b["xr32"][:, :C].copy_(b["xr16"])
+        o = model.ops
+        o.gemm(_p(b["xr32"]), _p(b["Wlm32"]), 0, M, model.vocab, KP, KP, KP, 0, epi=_EPI_CE_PARTIAL, tgt=_p(cw["tgt"]),
+               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), dtype=DIC_F32, tile=128)
+        _lib.check(lib.dic_ce_combine(_p(cw["partial"]), _p(cw["tgt_logit"]), M, lib.dic_ce_n_partials(model.vocab, 128), _p(cw["lse"]),
+                                      _p(cw["argmax"]), _p(cw["nll"]), st), "ce_combine")
+        ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
+        cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
+        rw = float(cfg.ROUNDING_WEIGHT)
+        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(b["out"]) + 4 * 4, st), "seg_sum")
+        if want_grad:
+            if b["dlogits"] is None:
+                b["dlogits"] = torch.empty(M, model.vpad, dtype=torch.float32, device=dev)
+            o.gemm(_p(b["xr32"]), _p(b["Wlm32"]), _p(b["dlogits"]), M, model.vocab, KP, KP, KP, model.vpad, epi=_EPI_CE_DLOGITS, tgt=_p(cw["tgt"]),
+                   lse=_p(cw["lse"]), ce_rows_a=Nt * L, ce_scale_a=rw * ca, ce_scale_b=rw * cb, dtype=DIC_F32, tile=128)
+            # d(lm_head.weight) = dlogits^T x_out16 ; d x_out16 += dlogits W_lm
+            P = model.params
+            o.gemm(_p(b["dlogits"]), _p(b["xr16"]), P.ptr("Wlm16", "G"), model.vpad, C, M, model.vpad, C, C, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+            o.gemm(_p(b["dlogits"]), _p(b["Wlm32"]), _p(b["dxr32"]), M, KP, model.vpad, model.vpad, KP, KP, b_km=1, out_f32=1, dtype=DIC_F32)
+            b["dxr16"].copy_(b["dxr32"][:, :C])
+            _lib.check(lib.dic_add_rows(_p(b["dx16"]), _p(b["dxr16"]), Nt, L, Tk, C, st), "add_rows")
+            _lib.check(lib.dic_add_rows(_p(b["dx16"]) + off, _p(b["dxr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "add_rows")
+        prob = b["out"][6]
+    else:
+        prob = torch.zeros((), dtype=torch.float32, device=dev)
+        if want_grad:
+            model.params.slot_view(model.params.G, "Wlm16").zero_()
+
+    if want_grad:
+        # ---- output_projection backward: dW, db, and the encoder's output gradient dx768 = dx16 W_out
+        o, P = model.ops, model.params
+        T = N * Tk
+        o.gemm(_p(b["dx16"]), _p(x_out768), P.ptr("Wout", "G"), C, 768, T, C, 768, 768, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+        _lib.check(lib.dic_colsum(DIC_F32, _p(b["dx16"]), T, C, C, P.ptr("bout", "G"), 0, _p(b["cs"]), st), "colsum")
+        b["dx16p"][:, :C].copy_(b["dx16"].reshape(T, C))
+        o.gemm(_p(b["dx16p"]), _p(b["Woutp"]), _p(ws["dx_out"]), T, 768, KP, KP, 768, 768, b_km=1, out_f32=1, dtype=DIC_F32)
+        model._te_pending = dict(b=b, N=N, L=L, Tk=Tk, S=S, B=B, ids=idx.to(dev, torch.int64), t=None)
+    model._pending = want_grad
+    return b["out"][0], b["out"][1], prob
+
+
+def backward_tail(model, t):
+    """After `model.backward()`: input_projection, q_sample and embedding backward (ref :459-468 under autograd)."""
+    st8 = model._te_pending
+    model._te_pending = None
+    b, N, L, Tk, S, B = st8["b"], st8["N"], st8["L"], st8["Tk"], st8["S"], st8["B"]
+    C = model.params.in_channel
+    o, P, lib = model.ops, model.params, _lib.lib()
+    o.begin()
+    st = o.stream
+    ws = model._saved
+    dy0 = ws["dy0"]                                     # [N,Tk,768]: gradient wrt the fused rows; rows t < L = d(input_projection(x))
+    T = N * Tk
+    b["x16Tk"].zero_()
+    b["x16Tk"][:, :L].copy_(b["x16"])
+    o.gemm(_p(dy0), _p(b["x16Tk"]), P.ptr("Win", "G"), 768, C, T, 768, C, C, a_km=1, b_km=1, out_f32=1, dtype=DIC_F32)
+    gpos = P.ptr("pos", "G")                            # dpos[t] = sum_n dy0[n][t]: its rows t < L add up to d(input_projection.bias)
+    _lib.check(lib.dic_colsum(DIC_F32, gpos, L, 768, 768, P.ptr("bin", "G"), 0, _p(b["cs"]), st), "colsum")
+    o.gemm(_p(dy0), P.ptr("Win"), _p(b["dxin16"]), T, C, 768, 768, C, C, b_km=1, out_f32=1, dtype=DIC_F32)
+    from . import diffusion
+    diffusion.alpha_cumprod_table(model.device)
+    tt = t.to(model.device, torch.int64).reshape(-1).contiguous()
+    _lib.check(lib.dic_te_dx0(_p(b["dxin16"]), _p(b["g16"]), _p(diffusion._state["sqrt_ac"]), _p(tt), S, B, L, Tk, C, cfg.STEP_TOT, _p(b["dx0"]), st),
+               "te_dx0")
+    ids = st8["ids"].reshape(-1)
+    sorted_ids, order = torch.sort(ids, stable=True)
+    gE = P.slot_view(P.G, "E16")
+    gE.zero_()
+    _lib.check(lib.dic_embed_scatter(_p(sorted_ids), _p(order), _p(b["dx0"]), ids.numel(), C, model.vocab, _p(gE), st), "embed_scatter")
+
+
+def forward(model, x, image_clip, text_clip, mask, concat_mask, with_logits=True):
+    """`model(...)` (ref :271-323) with the projections around the encoder: returns (logits [n,L,V], x_out [n,Tk,16])."""
+    _check_supported(model)
+    n, L, C = x.shape[0], cfg.MAX_LENGTH, cfg.IN_CHANNEL
+    dev = model.device
+    Tk = L + 2 if model.concat else L
+    b = _buffers(model, n, L, Tk, n * L)
+    b["drop_txt"] = False
+    refresh_padded_weights(model, b)
+    xin = project_in(model, b, x.to(dev, torch.float32), n, L)
+    m = (mask.to(dev) != 0).to(torch.uint8)
+    if model.concat:
+        one = torch.ones(n, 1, dtype=torch.uint8, device=dev)
+        km = torch.cat([m, one, 0 * one], 1)
+    else:
+        km = m
+    x768 = model.encode(xin, image_clip.to(dev, torch.float32).reshape(n, 512), text_clip.to(dev, torch.float32).reshape(n, 512), km,
+                        torch.zeros(n, dtype=torch.uint8, device=dev))
+    x_out = project_out(model, b, x768, n, Tk).clone()
+    logits = lm_head(model, x_out[:, :L, :]) if with_logits else None
+    return logits, x_out
+
+
+def lm_head(model, h):
+    """ref :323 with the learned head: [.., 16] -> [.., V] fp32 (materialised: API use only)."""
+    C = model.params.in_channel
+    shp = h.shape[:-1]
+    x = torch.zeros(h.numel() // C, KP, dtype=torch.float32, device=model.device)
+    x[:, :C].copy_(h.reshape(-1, C))
+    W = torch.zeros(model.vpad, KP, dtype=torch.float32, device=model.device)
+    W[:, :C].copy_(model.params.slot_view(model.params.P, "Wlm16"))
+    Vp = model.vocab + (-model.vocab) % 4
+    out = torch.empty(x.shape[0], Vp, dtype=torch.float32, device=model.device)
+    model.ops.begin()
+    model.ops.gemm(_p(x), _p(W), _p(out), x.shape[0], Vp, KP, KP, KP, Vp, out_f32=1, dtype=DIC_F32)
+    return out[:, :model.vocab].reshape(*shp, model.vocab)
+
+
+@torch.no_grad()
+def sample(model, image_clip, steps, start, return_hidden):
+    """The sampling loop (ref :611-621) in the 16-d space."""
+    _check_supported(model)
+    dev = model.device
+    B, L, C = image_clip.shape[0], cfg.MAX_LENGTH, cfg.IN_CHANNEL
+    restored = start.to(dev, torch.float32) if start is not None else torch.randn(B, L + 2, C, device=dev)
+    img = image_clip.to(dev, torch.float32)
+    x = restored[:, :L, :].contiguous()
+    ones = torch.ones(B, L, device=dev)
+    cm = torch.tensor([1, 0], device=dev).repeat(B, 1)
+    zeros = torch.zeros_like(img).unsqueeze(1)
+    x_out = None
+    for _ in range(steps):
+        _, x_out = forward(model, x, img.unsqueeze(1), zeros, ones, cm, with_logits=False)
+        x = x_out[:, :L, :].contiguous()
+    ids = lm_head(model, x).argmax(-1)
+    return (ids, x_out) if return_hidden else ids
+
+
+from .engine import EPI_CE_PARTIAL as _EPI_CE_PARTIAL, EPI_CE_DLOGITS as _EPI_CE_DLOGITS   # noqa: E402

@@ -146,6 +146,15 @@ int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask, void* ctx,
 int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask, const void* dctx, void* dqkv,
                  int N, int Tk, int H, int dh, float p_drop, uint64_t seed, void* stream);
 
+/* ---------------------------------------------------------------- TRAIN_EMBEDDING ablation (ref:98-102, 238-243, 459-468)
+ * dic_te_dx0: gradient wrt the learned embedding rows x_0 [B][L][C] gathered for this batch: through q_sample into the S noised
+ *   copies and the x_1 copy (dxin [S*B+B][Tk][C], rows t<L), and as the target of both embedding losses (g, same shape).
+ * dic_embed_scatter: nn.Embedding backward, dE[id] = sum over the positions holding id, fixed order (ids pre-sorted, stable). */
+int dic_te_dx0(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, int S, int B, int L, int Tk, int C,
+               int step_tot, float* dx0, void* stream);
+int dic_embed_scatter(const int64_t* sorted_ids, const int64_t* order, const float* dx0, int n_tokens, int C, int V, float* dE,
+                      void* stream);
+
 /* ---------------------------------------------------------------- losses (ref:77-87, 418, 428)
  * kind 0 series_sum_sample_mean, 1 series_sum, 2 mse_series_mean, 3 mse_series_sum.  x_out [N][Tk][D] f32 (rows
  * t<L used), target [N or B][L][D] f32 (index n % tgt_rows).  per_seq[n] = sum|d| (kinds 0,1) or sqrt(sum d^2);

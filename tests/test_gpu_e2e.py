@@ -24,16 +24,21 @@ def configure(m):
     dic.cfg.update(BATCH_SIZE=m["B"], SAMPLE_SIZE=m["S"], MAX_LENGTH=m["L"], STEP_TOT=m["step_tot"], COSIN_SCHEDULE=m["cosine"],
                    ROUNDING_WEIGHT=m["rounding_weight"], LOSS_FUNC=m["loss"], CLIP_ADDING_METHOD=m["fusion"],
                    CLASSIFIER_FREE_WEIGHT=m["cfg_w"], CLASSIFIER_FREE_PROB=m["cfg_prob"], X_0_PREDICTION=m["x0_pred"],
-                   X_T_STEP_INTERVAL=m["x_t_step_interval"], VOCAB_SIZE=m["vocab"])
+                   X_T_STEP_INTERVAL=m["x_t_step_interval"], VOCAB_SIZE=m["vocab"],
+                   TRAIN_EMBEDDING=m.get("train_embedding", False), IN_CHANNEL=m.get("in_channel", 768))
 
 
 def build_model(m, dtype, z=None):
     configure(m)
     # the cosine table depends on the host's torch.cos (not correctly rounded): use the table the reference host produced
     dic.set_alpha_cumprod(torch.from_numpy(z["alpha_cumprod"]) if z is not None else None)
-    E = synth.vocab_embedding(m["vocab"], 768, m["wseed"])
-    model = dic.DistilBertModel(E, E, config=dict(n_layers=m["n_layers"], dropout=0.0, attention_dropout=0.0), dtype=dtype)
-    model.load_state(synth.denoiser_state(m["n_layers"], m["wseed"]))
+    if m.get("train_embedding"):        # ref :325-327: the model builds its own embedding, head and projections
+        model = dic.DistilBertModel(config=dict(n_layers=m["n_layers"], dropout=0.0, attention_dropout=0.0), dtype=dtype)
+        model.load_state(synth.denoiser_state(m["n_layers"], m["wseed"], train_embedding_vocab=m["vocab"], in_channel=m["in_channel"]))
+    else:
+        E = synth.vocab_embedding(m["vocab"], 768, m["wseed"])
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=m["n_layers"], dropout=0.0, attention_dropout=0.0), dtype=dtype)
+        model.load_state(synth.denoiser_state(m["n_layers"], m["wseed"]))
     x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(m["B"], m["L"], m["vocab"], m["dseed"]).items()}
     return model, x
 
@@ -41,7 +46,7 @@ def build_model(m, dtype, z=None):
 def draws(m, seed):
     t = torch.from_numpy(synth.uniform_int(synth.stream_id("t", seed), (m["S"], 1, 1), 0, m["step_tot"]))
     n_noise = 2 if m["x0_pred"] else 3
-    noises = [torch.from_numpy(synth.noise((m["B"], m["L"], 768), seed, f"eps{i}")) for i in range(n_noise)]
+    noises = [torch.from_numpy(synth.noise((m["B"], m["L"], m.get("in_channel", 768)), seed, f"eps{i}")) for i in range(n_noise)]
     u = torch.from_numpy(synth.uniform(synth.stream_id("cfg", seed), (m["S"] * m["B"], 1)))
     return t, noises, u
 
@@ -68,7 +73,7 @@ def test_golden_eval_forward_fp32(name):
                        x["attention_mask"].repeat(S, 1), cm.cuda())
         l1, h1 = model(x_1, x["image_clip"].unsqueeze(1), x["text_clip"].unsqueeze(1), x["attention_mask"],
                        torch.tensor([1, 0]).repeat(B, 1).cuda())
-        stride = 1 if z["hid_t"].shape[-1] == 768 else 16
+        stride = 1 if z["hid_t"].shape[-1] == ht.shape[-1] else 16
         np.testing.assert_allclose(ht[:, :, ::stride].cpu().numpy(), z["hid_t"], rtol=0, atol=2e-4)
         np.testing.assert_allclose(h1[:, :, ::stride].cpu().numpy(), z["hid_1"], rtol=0, atol=2e-4)
         np.testing.assert_array_equal(lt.argmax(-1).cpu().numpy(), z["argmax_t"])       # token ids bit-exact
@@ -100,6 +105,42 @@ def test_golden_two_training_steps_fp32(name):
         assert (np.abs(gh - z["grad_heads"][step])[keep] / scale[keep]).max() < 2e-2, f"step {step} grad heads"
         pn = np.array([float(p.detach().double().norm()) for p in model.parameters()])
         np.testing.assert_allclose(pn[keep], z["param_norms"][step][keep], rtol=2e-6, err_msg=f"step {step} param norms")
+
+
+@pytest.fixture
+def restore_cfg():
+    yield
+    dic.cfg.update(TRAIN_EMBEDDING=False, IN_CHANNEL=768)
+
+
+def test_train_embedding_ablation_matches_reference_fp32(restore_cfg):
+    """TRAIN_EMBEDDING=True (ref :98-102, 238-243, 292-293, 319-320): learned 16-d embedding / head / projections.  Same bar as
+    the main path: eval forward + ids, then two AdamW steps (losses, per-tensor gradient norms -- embedding, lm_head and
+    projection gradients included --, parameter norms) against the fixture the reference itself produced."""
+    test_golden_eval_forward_fp32("trainemb_b3s2l16")
+    test_golden_two_training_steps_fp32("trainemb_b3s2l16")
+
+
+def test_train_embedding_ablation_bf16_encoder_and_sampling(restore_cfg):
+    z, m = load_golden("trainemb_b3s2l16")
+    model, x = build_model(m, "bf16", z)
+    trainer = dic.AdamW(model.parameters(), lr=m["lr"])
+    for step in range(2):
+        t, noises, u = draws(m, 123 + step)
+        l, a, b, c = dic.train_func(model, trainer, x, train=True, t=t, noises=noises, cfg_uniform=u)
+        got = np.array([f(l), f(a), f(b), f(c)])
+        np.testing.assert_allclose(got, z["step_losses"][step], rtol=5e-3)
+    # sampling loop in the 16-d space against the oracle (fp32 encoder: ids bit-exact)
+    model32, _ = build_model(m, "fp32", z)
+    model32.eval()
+    start = torch.from_numpy(synth.noise((m["B"], m["L"] + 2, m["in_channel"]), 77, "restored"))
+    ids, hid = dic.sample(model32, x["image_clip"], steps=3, start=start, return_hidden=True)
+    ocfg = R.Config(MAX_LENGTH=m["L"], n_layers=m["n_layers"], vocab=m["vocab"], TRAIN_EMBEDDING=True, IN_CHANNEL=m["in_channel"])
+    om = R.build(ocfg, synth.denoiser_state(m["n_layers"], m["wseed"], train_embedding_vocab=m["vocab"], in_channel=m["in_channel"]),
+                 synth.vocab_embedding(8, 768, 0), requires_grad=False)
+    oids, ohid = R.sample(om, x["image_clip"].cpu(), steps=3, start=start)
+    np.testing.assert_allclose(hid.cpu().numpy(), ohid.numpy(), atol=3e-4, rtol=0)
+    np.testing.assert_array_equal(ids.cpu().numpy(), oids.numpy())
 
 
 @pytest.mark.parametrize("name", ["base_b4s3l16", "deep6_b2s2l16"])
