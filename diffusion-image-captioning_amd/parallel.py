@@ -8,7 +8,8 @@ one direct reduce-scatter + all-gather across all 7 links, not 108 latency-bound
 factor is folded into the AdamW kernel (`grad_scale`), not a separate pass over the buffer.
 
 Reference caveats kept:
-  * one t-vector per step is shared by the whole *global* batch (ref :461) -> rank 0 draws it and broadcasts it;
+  * one t-vector per step is shared by the whole *global* batch (ref :461) -> every rank draws it from an identically
+    seeded generator (no per-step collective);
   * the noise eps is per item -> each rank seeds its Philox stream differently;
   * CFG forces rows 0/1 of the batch to unguided/guided (ref :408-409) -> only rank 0 does.
 Backend "nccl" IS RCCL on ROCm; the CPU tests run the same code with "gloo".
@@ -61,12 +62,21 @@ def shard(batch: dict, rank_: int | None = None, world: int | None = None) -> di
     return out
 
 
+_shared_gen = {}
+
+
 def shared_randint(lo: int, hi: int, shape, device) -> torch.Tensor:
-    """torch.randint whose result is identical on every rank (drawn on rank 0, broadcast)."""
-    t = torch.randint(lo, hi, shape, device=device)
-    if is_initialized() and world_size() > 1:
-        dist.broadcast(t, src=0)
-    return t
+    """torch.randint whose result is identical on every rank.  The reference draws ONE t-vector per step for the whole batch
+    (ref :461); data parallel, every rank draws it from its own generator seeded with the same value (DIC_SHARED_SEED, default
+    fixed), so the ranks agree without a per-step collective."""
+    if not (is_initialized() and world_size() > 1):
+        return torch.randint(lo, hi, shape, device=device)
+    key = str(device)
+    g = _shared_gen.get(key)
+    if g is None:
+        g = _shared_gen[key] = torch.Generator(device=device)
+        g.manual_seed(int(os.environ.get("DIC_SHARED_SEED", "20260929")))
+    return torch.randint(lo, hi, shape, device=device, generator=g)
 
 
 def allreduce_flat(flat: torch.Tensor) -> torch.Tensor:
@@ -78,9 +88,9 @@ def allreduce_flat(flat: torch.Tensor) -> torch.Tensor:
 
 class GradReducer:
     """Overlaps the gradient exchange with the backward pass: the flat buffer is laid out layer by layer, so as soon as the
-    backward of encoder layer i has written its slice, that slice (28 MB fp32) is all-reduced asynchronously on RCCL's stream
-    while layers i-1..0 are still computing; only the small tail (embeddings, MLM-head transform, CLIP projections) is
-    reduced after the backward.  Still one logical exchange of `G` per step -- just issued in layer-sized pieces."""
+    backward of a group of encoder layers has written its slice, that slice (3 layers = 85 MB fp32) is all-reduced asynchronously
+    on RCCL's stream while the layers below are still computing; only the small tail (embeddings, MLM-head transform, CLIP
+    projections) is reduced after the backward.  Still one logical exchange of `G` per step -- just issued in a few pieces."""
 
     def __init__(self, model):
         self.G = model.params.G
