@@ -94,7 +94,7 @@ def lib():
             getattr(L, fn).restype = C.c_size_t
             getattr(L, fn).argtypes = [C.c_int] * args
         L.dic_ce_n_partials.restype = C.c_int
-        L.dic_te_dx0.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
+        L.dic_te_dx0.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
         L.dic_embed_scatter.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
         L.dic_ce_n_partials.argtypes = [C.c_int, C.c_int]
         L.dic_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmParams), C.c_void_p]

@@ -313,11 +313,12 @@ __global__ __launch_bounds__(64 * CS_WAVES) void colsum_small(const float* in, i
 // ------------------------------------------------------------------------------------------------ TRAIN_EMBEDDING ablation
 // ref :98-102, 238-243, 459-468: with a learned embedding x_0 = E[ids] carries gradient -- through q_sample into every noised copy
 // (x_t[s] = sqrt_ac[t_s] x_0 + ..., x_1 = sqrt_ac[1] x_0 + ...) and as the TARGET of both embedding losses.
-//   dx0[b][l][c] = sum_s ( sqrt_ac[t_s] * dxin[s*B+b][l][c] - g[s*B+b][l][c] ) + sqrt_ac[1] * dxin[S*B+b][l][c] - g[S*B+b][l][c]
+//   dx0[b][l][c] = sum_s ( sqrt_ac[t_s] * dxin[s*B+b] - k_s * g[s*B+b] ) + sqrt_ac[1] * dxin[x1_row0+b] - g[x1_row0+b]     ([l][c] implied)
 // dxin = gradient wrt the stacked 16-d encoder input, g = gradient of the embedding losses wrt the model's 16-d output
-// (both [S*B + B][Tk][C], rows t < L used).
-__global__ void te_dx0_kernel(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, int S, int B, int L, int Tk,
-                              int C, int step_tot, float* dx0) {
+// (both [rows][Tk][C], rows t < L used; the x_1 sequences start at row x1_row0 -- guided copies may sit in between).
+// k_s = 1 when the x_t loss targets x_0 (x_0 prediction), sqrt_ac[t_next_s] when it targets the noised x_{t_next} (ref :364-380).
+__global__ void te_dx0_kernel(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, const int64_t* t_next, int S, int B,
+                              int L, int Tk, int C, int step_tot, int x1_row0, float* dx0) {
     const int n = B * L * C;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int c = i % C, l = (i / C) % L, b = i / (C * L);
@@ -325,17 +326,23 @@ __global__ void te_dx0_kernel(const float* dxin, const float* g, const float* sq
         for (int s_ = 0; s_ <= S; ++s_) {
             long long ts = s_ < S ? t[s_] : 1;
             ts = ts < 0 ? 0 : (ts >= step_tot ? step_tot - 1 : ts);
-            const size_t row = ((size_t)(s_ * B + b) * Tk + l) * C + c;
-            acc += sqrt_ac[ts] * dxin[row] - g[row];
+            float kt = 1.0f;
+            if (s_ < S && t_next) {
+                long long tn = t_next[s_];
+                tn = tn < 0 ? 0 : (tn >= step_tot ? step_tot - 1 : tn);
+                kt = sqrt_ac[tn];
+            }
+            const size_t row = ((size_t)((s_ < S ? s_ * B : x1_row0) + b) * Tk + l) * C + c;
+            acc += sqrt_ac[ts] * dxin[row] - kt * g[row];
         }
         dx0[i] = acc;
     }
 }
-extern "C" int dic_te_dx0(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, int S, int B, int L, int Tk, int C,
-                          int step_tot, float* dx0, void* stream) {
-    DIC_REQUIRE(S > 0 && B > 0 && L > 0 && Tk >= L && C > 0, "dic_te_dx0: bad arguments");
-    hipLaunchKernelGGL(te_dx0_kernel, dim3(grid_for((long long)B * L * C, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dxin, g, sqrt_ac, t, S,
-                       B, L, Tk, C, step_tot, dx0);
+extern "C" int dic_te_dx0(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, const int64_t* t_next, int S, int B,
+                          int L, int Tk, int C, int step_tot, int x1_row0, float* dx0, void* stream) {
+    DIC_REQUIRE(S > 0 && B > 0 && L > 0 && Tk >= L && C > 0 && x1_row0 >= S * B, "dic_te_dx0: bad arguments");
+    hipLaunchKernelGGL(te_dx0_kernel, dim3(grid_for((long long)B * L * C, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dxin, g, sqrt_ac, t,
+                       t_next, S, B, L, Tk, C, step_tot, x1_row0, dx0);
     DIC_CHECK_LAUNCH();
     return 0;
 }

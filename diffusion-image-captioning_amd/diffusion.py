@@ -121,7 +121,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     kind = _loss_kind(loss_func)
     if model.te:
         from . import train_embedding
-        return train_embedding.loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind)
+        return train_embedding.loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cfg_uniform=cfg_uniform)
     dev = model.device
     lib = _lib.lib()
     Nt = S * B
@@ -367,7 +367,7 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
         model.backward(layer_done=layer_done)
         if model.te:
             from . import train_embedding
-            train_embedding.backward_tail(model, t)      # projections, q_sample and embedding backward (x_0 carries gradient)
+            train_embedding.backward_tail(model, t, None if cfg.X_0_PREDICTION else t_next)   # projections, q_sample, embedding (x_0 carries gradient)
         reducer.finish(trainer)
         if not isinstance(trainer, AdamW):
             model.params.relink_grads()

@@ -6,8 +6,8 @@ losses live in the 16-d space, and x_0 = embedding(ids) carries gradient (into q
 
 Not a hot path of the metric: the 16-wide GEMMs run on the exact-fp32 MFMA kernel with K padded to its 32-deep step, whatever
 the encoder's dtype; everything else reuses the kernels of the main path (q_sample, encoder forward/backward, embedding
-losses, streaming CE / dlogits, AdamW over the same flat buffers).  Supported: concat and add fusion, the four loss
-functions, x_0 prediction, no classifier-free guidance (the reference never combined the two; asking for it raises).
+losses, streaming CE / dlogits, AdamW over the same flat buffers).  Every switch of the main path applies: concat / add
+fusion, the four loss functions, x_0 or x_{t-1} prediction, classifier-free guidance (guided copies stacked into the batch).
 """
 from __future__ import annotations
 
@@ -25,10 +25,6 @@ def _p(t):
 
 
 def _check_supported(model):
-    if float(cfg.CLASSIFIER_FREE_WEIGHT) > 0:
-        raise NotImplementedError("TRAIN_EMBEDDING with classifier-free guidance is not built")
-    if not cfg.X_0_PREDICTION:
-        raise NotImplementedError("TRAIN_EMBEDDING with x_{t-1} prediction is not built")
     assert cfg.IN_CHANNEL == model.params.in_channel, "cfg.IN_CHANNEL changed after the model was built"
 
 
@@ -78,7 +74,8 @@ def project_out(model, b, x_out768, N, Tk):
     return b["x_out16"]
 
 
-def _masks(model, mask, S, B, L, drop_txt):
+def _masks(model, mask, S, B, L, drop_txt, gi):
+    """Key masks of the stacked batch [x_t rows | guided copies | x_1 rows] (ref :296-297, 309-311)."""
     dev = model.device
     m = (mask.to(dev) != 0).to(torch.uint8)
     m_rep = m.repeat(S, 1)
@@ -87,37 +84,59 @@ def _masks(model, mask, S, B, L, drop_txt):
         one_b = torch.ones(B, 1, dtype=torch.uint8, device=dev)
         pt = torch.cat([m_rep, one_t] if drop_txt else [m_rep, one_t, 0 * one_t], 1)
         pb = torch.cat([m, one_b] if drop_txt else [m, one_b, 0 * one_b], 1)
+        if gi is not None:
+            return torch.cat([pt, torch.cat([m_rep[gi], one_t[:len(gi)], one_t[:len(gi)]], 1), pb])
         return torch.cat([pt, pb])
-    return torch.cat([m_rep, m])
+    return torch.cat([m_rep, m_rep[gi], m]) if gi is not None else torch.cat([m_rep, m])
 
 
-def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind):
+def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cfg_uniform=None):
     """`loss` (ref :382-445) with the learned embedding: returns the three loss scalars and, under grad mode, leaves the encoder's
     output gradient in the workspace (so `model.backward()` runs as usual) plus what `backward_tail` needs."""
     _check_supported(model)
     S, B, L, C = cfg.SAMPLE_SIZE, cfg.BATCH_SIZE, cfg.MAX_LENGTH, cfg.IN_CHANNEL
     dev, lib = model.device, _lib.lib()
     Nt = S * B
-    N = Nt + B
-    M = N * L
+    w = float(cfg.CLASSIFIER_FREE_WEIGHT)
     want_grad = torch.is_grad_enabled()
-    drop_txt = model.concat and cfg.DROP_UNUSED_TEXT_ROW
+    # ---- classifier-free-guidance draw (ref :406-412), as in diffusion.loss
+    gi = None
+    if w > 0:
+        u = cfg_uniform.to(dev) if cfg_uniform is not None else torch.rand((Nt, 1), device=dev)
+        cm = (u > cfg.CLASSIFIER_FREE_PROB).reshape(Nt)
+        if model.rank_rows_forced:
+            cm[0] = False
+            cm[1] = True
+        gi = cm.nonzero().squeeze(1)
+        if gi.numel() == 0:
+            gi = None
+    Ng = 0 if gi is None else int(gi.numel())
+    N = Nt + Ng + B
+    M = (Nt + B) * L
+    drop_txt = model.concat and Ng == 0 and cfg.DROP_UNUSED_TEXT_ROW
     ws = model._workspace(N, L, drop_txt)
     Tk = ws["Tk"]
     b = _buffers(model, N, L, Tk, M)
     b["drop_txt"] = drop_txt
-    model.params.text_unused = not model.concat
+    model.params.text_unused = (not model.concat) and Ng == 0
     refresh_padded_weights(model, b)
-    x16 = torch.cat([x_t.to(dev, torch.float32), x_1.to(dev, torch.float32)])
+    x_t = x_t.to(dev, torch.float32)
+    x16 = torch.cat([x_t, x_t[gi], x_1.to(dev, torch.float32)]) if Ng else torch.cat([x_t, x_1.to(dev, torch.float32)])
     xin = project_in(model, b, x16, N, L)
     img = image_clip.to(dev, torch.float32)
     txt = text_clip.to(dev, torch.float32)
-    ic, tc = torch.cat([img.repeat(S, 1), img]), torch.cat([txt.repeat(S, 1), txt])
-    km = _masks(model, mask, S, B, L, drop_txt)
+    img_rep, txt_rep = img.repeat(S, 1), txt.repeat(S, 1)
+    ic = torch.cat([img_rep, img_rep[gi], img]) if Ng else torch.cat([img_rep, img])
+    tc = torch.cat([txt_rep, txt_rep[gi], txt]) if Ng else torch.cat([txt_rep, txt])
+    km = _masks(model, mask, S, B, L, drop_txt, gi)
     add_txt = torch.zeros(N, dtype=torch.uint8, device=dev)
+    if Ng:
+        add_txt[Nt:Nt + Ng] = 1
     x_out768 = model.encode(xin, ic, tc, km, add_txt, drop_txt=drop_txt)
-    x_out16 = project_out(model, b, x_out768, N, Tk)
     st = model.ops.stream
+    if Ng:          # ref :314-317: the mix happens on the encoder output, before output_projection
+        _lib.check(lib.dic_cfg_mix_fwd(_p(x_out768), _p(x_out768) + Nt * Tk * 768 * 4, _p(gi), Ng, Tk * 768, w, st), "cfg_mix_fwd")
+    x_out16 = project_out(model, b, x_out768, N, Tk)
 
     # ---- embedding losses on the 16-d output (ref :77-87: the mean / the literal 768 of `series_sum` are the reference's)
     if kind == 0:
@@ -135,16 +154,23 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind):
     b["gscale"][:Nt].fill_(sa)
     b["gscale"][Nt:].fill_(sb)
     x_0c = x_0.to(dev, torch.float32).contiguous()
+    if cfg.X_0_PREDICTION:
+        tgt_t, tgt_rows = x_0c, B
+    else:
+        assert x_tgt.shape == x_t.shape
+        tgt_t, tgt_rows = x_tgt.to(dev, torch.float32).contiguous(), Nt
     dx = _p(b["dx16"]) if want_grad else 0
     row = Tk * C
-    _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16), _p(x_0c), B, _p(b["per_seq"]), dx, _p(b["gscale"]), _p(b["xr16"]), Nt, L, Tk, C, st),
-               "emb_loss")
-    off = Nt * row * 4
+    if want_grad and Ng:
+        b["dx16"][Nt:Nt + Ng].zero_()              # the guided copies' own outputs feed nothing after the mix
+    _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16), _p(tgt_t), tgt_rows, _p(b["per_seq"]), dx, _p(b["gscale"]), _p(b["xr16"]), Nt, L, Tk,
+                                C, st), "emb_loss")
+    off = (Nt + Ng) * row * 4
     _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16) + off, _p(x_0c), B, _p(b["per_seq"]) + Nt * 4, (dx + off) if want_grad else 0,
                                 _p(b["gscale"]) + Nt * 4, _p(b["xr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "emb_loss")
-    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), N, Nt, sa, sb, _p(b["out"]), st), "seg_sum")
+    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), Nt + B, Nt, sa, sb, _p(b["out"]), st), "seg_sum")
     if want_grad:
-        b["g16"].copy_(b["dx16"])                  # the loss gradient alone: its negative flows into the target x_0
+        b["g16"].copy_(b["dx16"])                  # the loss gradient alone: its negative flows into the targets
 
     # ---- rounding loss on the learned head (ref :323, 432-445)
     if cfg.USE_PROB_LOSS:
@@ -188,13 +214,16 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind):
         _lib.check(lib.dic_colsum(DIC_F32, _p(b["dx16"]), T, C, C, P.ptr("bout", "G"), 0, _p(b["cs"]), st), "colsum")
         b["dx16p"][:, :C].copy_(b["dx16"].reshape(T, C))
         o.gemm(_p(b["dx16p"]), _p(b["Woutp"]), _p(ws["dx_out"]), T, 768, KP, KP, 768, 768, b_km=1, out_f32=1, dtype=DIC_F32)
-        model._te_pending = dict(b=b, N=N, L=L, Tk=Tk, S=S, B=B, ids=idx.to(dev, torch.int64), t=None)
+        if Ng:
+            _lib.check(lib.dic_cfg_mix_bwd(_p(ws["dx_out"]), _p(ws["dx_out"]) + Nt * Tk * 768 * 4, _p(gi), Ng, Tk * 768, w, st), "cfg_mix_bwd")
+        model._te_pending = dict(b=b, N=N, L=L, Tk=Tk, S=S, B=B, ids=idx.to(dev, torch.int64), gi=gi, Ng=Ng)
     model._pending = want_grad
     return b["out"][0], b["out"][1], prob
 
 
-def backward_tail(model, t):
-    """After `model.backward()`: input_projection, q_sample and embedding backward (ref :459-468 under autograd)."""
+def backward_tail(model, t, t_next=None):
+    """After `model.backward()`: input_projection, q_sample and embedding backward (ref :459-468 under autograd).
+    t_next: the second timestep vector of x_{t-1} prediction (the x_t loss then targets diffuse_t(x_0, t_next), ref :364-380)."""
     st8 = model._te_pending
     model._te_pending = None
     b, N, L, Tk, S, B = st8["b"], st8["N"], st8["L"], st8["Tk"], st8["S"], st8["B"]
@@ -213,9 +242,13 @@ def backward_tail(model, t):
     o.gemm(_p(dy0), P.ptr("Win"), _p(b["dxin16"]), T, C, 768, 768, C, C, b_km=1, out_f32=1, dtype=DIC_F32)
     from . import diffusion
     diffusion.alpha_cumprod_table(model.device)
+    gi, Ng = st8["gi"], st8["Ng"]
+    if Ng:          # a guided copy is the same x_t row projected a second time: its input gradient belongs to that row
+        b["dxin16"].index_add_(0, gi, b["dxin16"][S * B:S * B + Ng].clone())
     tt = t.to(model.device, torch.int64).reshape(-1).contiguous()
-    _lib.check(lib.dic_te_dx0(_p(b["dxin16"]), _p(b["g16"]), _p(diffusion._state["sqrt_ac"]), _p(tt), S, B, L, Tk, C, cfg.STEP_TOT, _p(b["dx0"]), st),
-               "te_dx0")
+    tn = t_next.to(model.device, torch.int64).reshape(-1).contiguous() if t_next is not None else None
+    _lib.check(lib.dic_te_dx0(_p(b["dxin16"]), _p(b["g16"]), _p(diffusion._state["sqrt_ac"]), _p(tt), _p(tn) if tn is not None else 0, S, B, L, Tk,
+                              C, cfg.STEP_TOT, S * B + Ng, _p(b["dx0"]), st), "te_dx0")
     ids = st8["ids"].reshape(-1)
     sorted_ids, order = torch.sort(ids, stable=True)
     gE = P.slot_view(P.G, "E16")

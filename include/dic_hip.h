@@ -150,8 +150,8 @@ int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask, const void
  * dic_te_dx0: gradient wrt the learned embedding rows x_0 [B][L][C] gathered for this batch: through q_sample into the S noised
  *   copies and the x_1 copy (dxin [S*B+B][Tk][C], rows t<L), and as the target of both embedding losses (g, same shape).
  * dic_embed_scatter: nn.Embedding backward, dE[id] = sum over the positions holding id, fixed order (ids pre-sorted, stable). */
-int dic_te_dx0(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, int S, int B, int L, int Tk, int C,
-               int step_tot, float* dx0, void* stream);
+int dic_te_dx0(const float* dxin, const float* g, const float* sqrt_ac, const int64_t* t, const int64_t* t_next /* or NULL */, int S,
+               int B, int L, int Tk, int C, int step_tot, int x1_row0, float* dx0, void* stream);
 int dic_embed_scatter(const int64_t* sorted_ids, const int64_t* order, const float* dx0, int n_tokens, int C, int V, float* dE,
                       void* stream);
 

@@ -330,6 +330,10 @@ def main():
     run_sampling_case("sample_b3k3", B=3, L=16, n_layers=2, steps=3)
     # F: TRAIN_EMBEDDING ablation (:98-102, 238-243, 292-293, 319-320): learned 16-d embedding / head / projections
     run_case("trainemb_b3s2l16", B=3, S=2, L=16, n_layers=2, vocab=2000, cosine=False, step_tot=100, train_embedding=True)
+    run_case("trainemb_cfg_b3s2l16", B=3, S=2, L=16, n_layers=2, vocab=2000, cosine=False, step_tot=100, train_embedding=True,
+             cfg_w=0.3, store_hidden=False)
+    run_case("trainemb_xprev_add_b3s2l16", B=3, S=2, L=16, n_layers=2, vocab=2000, train_embedding=True, fusion="add",
+             loss_name="mse_series_mean", x0_pred=False, store_hidden=False)
 
 
 if __name__ == "__main__":

@@ -121,6 +121,21 @@ def test_train_embedding_ablation_matches_reference_fp32(restore_cfg):
     test_golden_two_training_steps_fp32("trainemb_b3s2l16")
 
 
+@pytest.mark.parametrize("name", ["trainemb_cfg_b3s2l16", "trainemb_xprev_add_b3s2l16"])
+def test_train_embedding_with_guidance_and_with_xprev_targets(restore_cfg, name):
+    """The ablation combined with the other switches: classifier-free guidance (guided copies share the projected input and send
+    their input gradient back to the row they copy), and x_{t-1} prediction under "add" fusion with the L2-norm loss (the x_t loss
+    then targets a noised copy of x_0, which scales the target gradient by sqrt(abar[t_next]))."""
+    test_golden_two_training_steps_fp32(name)
+    z, m = load_golden(name)
+    model, x = build_model(m, "fp32", z)
+    model.eval()
+    t, noises, u = draws(m, 123)
+    with torch.no_grad():
+        l, a, b, c = dic.train_func(model, None, x, train=False, t=t, noises=noises, cfg_uniform=u)
+    np.testing.assert_allclose(np.array([f(l), f(a), f(b), f(c)]), z["eval_losses"], rtol=1e-4)
+
+
 def test_train_embedding_ablation_bf16_encoder_and_sampling(restore_cfg):
     z, m = load_golden("trainemb_b3s2l16")
     model, x = build_model(m, "bf16", z)

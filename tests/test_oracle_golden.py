@@ -12,7 +12,7 @@ from oracle import ref_model as R
 synth = importlib.import_module("diffusion-image-captioning_amd.synth")
 
 TRAIN_CASES = ["base_b4s3l16", "cfg_b2s2l32", "deep6_b2s2l16", "add_mse_b3s2l16", "xprev_sum_b3s2l16",
-               "addcfg_msesum_b3s2l16", "trainemb_b3s2l16"]
+               "addcfg_msesum_b3s2l16", "trainemb_b3s2l16", "trainemb_cfg_b3s2l16", "trainemb_xprev_add_b3s2l16"]
 
 
 def cfg_from_meta(m):
