@@ -106,9 +106,11 @@ class GradReducer:
         per-link bound, fewer and larger collectives use them better than one per layer) as soon as a group is complete."""
         if not self.active:
             return
-        if i % self.group != 0:
+        # groups [.., 2g..3g), [g..2g), then the last g layers one by one: what is exchanged AFTER the backward has nothing left to
+        # hide it, so the final pieces are kept small
+        if i >= self.group and i % self.group != 0:
             return
-        last = min(i + self.group, self.store.n_layers)
+        last = min(i + self.group, self.store.n_layers) if i >= self.group else i + 1
         lo = self.store.off(f"L{i}.Wqkv")
         hi = self.store.off(f"L{last}.Wqkv") if last < self.store.n_layers else self.store.off("pos")
         self.handles.append((dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
