@@ -86,6 +86,15 @@ def allreduce_flat(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def exchange_group(i: int, n_layers: int, group: int):
+    """Layers finish in descending order; when layer i finishes, which layers [first, last) are exchanged now (or None)?
+    Groups [.., 2g..3g), [g..2g), then the last g layers one by one: what is exchanged AFTER the backward has nothing left to hide
+    it, so the final pieces are kept small."""
+    if i >= group and i % group != 0:
+        return None
+    return (i, min(i + group, n_layers)) if i >= group else (i, i + 1)
+
+
 class GradReducer:
     """Overlaps the gradient exchange with the backward pass: the flat buffer is laid out layer by layer, so as soon as the
     backward of a group of encoder layers has written its slice, that slice (3 layers = 85 MB fp32) is all-reduced asynchronously
@@ -106,11 +115,10 @@ class GradReducer:
         per-link bound, fewer and larger collectives use them better than one per layer) as soon as a group is complete."""
         if not self.active:
             return
-        # groups [.., 2g..3g), [g..2g), then the last g layers one by one: what is exchanged AFTER the backward has nothing left to
-        # hide it, so the final pieces are kept small
-        if i >= self.group and i % self.group != 0:
+        rng = exchange_group(i, self.store.n_layers, self.group)
+        if rng is None:
             return
-        last = min(i + self.group, self.store.n_layers) if i >= self.group else i + 1
+        last = rng[1]
         lo = self.store.off(f"L{i}.Wqkv")
         hi = self.store.off(f"L{last}.Wqkv") if last < self.store.n_layers else self.store.off("pos")
         self.handles.append((dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))

@@ -69,6 +69,21 @@ def test_workspace_size_queries():
     assert L.dic_ln_partial_bytes(512, 3, 768) == 512 * 3 * 768 * 4
 
 
+def test_data_parallel_exchange_groups_cover_every_layer_once():
+    for n_layers in (1, 2, 6, 12, 13):
+        for group in (1, 2, 3, 4):
+            seen = []
+            for i in reversed(range(n_layers)):                 # the backward finishes layers in descending order
+                r = dic.parallel.exchange_group(i, n_layers, group)
+                if r is not None:
+                    assert r[0] == i
+                    seen += list(range(*r))
+            assert sorted(seen) == list(range(n_layers)), (n_layers, group, seen)
+            # a group is only exchanged once all of its layers are done: every layer of it is >= the trigger layer
+    assert dic.parallel.exchange_group(9, 12, 3) == (9, 12) and dic.parallel.exchange_group(2, 12, 3) == (2, 3)
+    assert dic.parallel.exchange_group(10, 12, 3) is None
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
