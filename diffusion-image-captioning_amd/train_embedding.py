@@ -24,7 +24,7 @@ def _p(t):
     return t.data_ptr()
 
 
-def _check_supported(model):
+def _check_config(model):
     assert cfg.IN_CHANNEL == model.params.in_channel, "cfg.IN_CHANNEL changed after the model was built"
 
 
@@ -33,7 +33,7 @@ def _buffers(model, N, L, Tk, M):
     key = ("te", N, L, Tk, M)
     b = model._ws.get(key)
     if b is None:
-        dev, C, V = model.device, model.params.in_channel, model.vocab
+        dev, C = model.device, model.params.in_channel
 
         def f(*s):
             return torch.zeros(*s, dtype=torch.float32, device=dev)
@@ -93,7 +93,7 @@ def _masks(model, mask, S, B, L, drop_txt, gi):
 def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cfg_uniform=None):
     """`loss` (ref :382-445) with the learned embedding: returns the three loss scalars and, under grad mode, leaves the encoder's
     output gradient in the workspace (so `model.backward()` runs as usual) plus what `backward_tail` needs."""
-    _check_supported(model)
+    _check_config(model)
     S, B, L, C = cfg.SAMPLE_SIZE, cfg.BATCH_SIZE, cfg.MAX_LENGTH, cfg.IN_CHANNEL
     dev, lib = model.device, _lib.lib()
     Nt = S * B
@@ -258,7 +258,7 @@ def backward_tail(model, t, t_next=None):
 
 def forward(model, x, image_clip, text_clip, mask, concat_mask, with_logits=True):
     """`model(...)` (ref :271-323) with the projections around the encoder: returns (logits [n,L,V], x_out [n,Tk,16])."""
-    _check_supported(model)
+    _check_config(model)
     n, L, C = x.shape[0], cfg.MAX_LENGTH, cfg.IN_CHANNEL
     dev = model.device
     Tk = L + 2 if model.concat else L
@@ -297,7 +297,7 @@ def lm_head(model, h):
 @torch.no_grad()
 def sample(model, image_clip, steps, start, return_hidden):
     """The sampling loop (ref :611-621) in the 16-d space."""
-    _check_supported(model)
+    _check_config(model)
     dev = model.device
     B, L, C = image_clip.shape[0], cfg.MAX_LENGTH, cfg.IN_CHANNEL
     restored = start.to(dev, torch.float32) if start is not None else torch.randn(B, L + 2, C, device=dev)
