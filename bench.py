@@ -32,6 +32,27 @@ def gflop_per_seq(L, layers):
     return (fwd + bwd) / 1e9
 
 
+def relaunch(n):
+    """Re-exec this command under torch.distributed.run with n ranks on this node; never returns."""
+    import socket
+    import subprocess
+    try:
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,10 +67,14 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI) exactly as the driver would
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch(args.gpus)
     import torch
     dic = importlib.import_module("diffusion-image-captioning_amd")
     rank, world, local = dic.parallel.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}: refusing to report a line for a different GPU count")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, S, L = args.batch, args.sample_size, args.seq_len
@@ -62,7 +87,7 @@ def main():
     dic.parallel.configure_model_for_rank(model)
     trainer = dic.AdamW(model.parameters(), lr=1e-4)
     x = {k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=1 + rank).items()}
-    dic.seed_noise(1234 + 7919 * rank)
+    dic.seed_noise(dic.parallel.rank_seed(1234))          # every rank its own eps stream (configure_model_for_rank did dropout + guidance)
 
     def barrier():
         if world > 1:

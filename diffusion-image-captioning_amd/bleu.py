@@ -5,9 +5,12 @@ weights, one score per validation batch, averaged over batches) and `torchtext.d
 (same definition).  Neither package is installed here, so this restates the published definition (Papineni et al. 2002,
 corpus level): clipped n-gram matches and candidate n-gram totals are summed over the whole corpus per order n = 1..4,
 precision_n = matches_n / total_n, BLEU = BP * exp(mean_n log precision_n), BP = 1 if c > r else exp(1 - r/c) with r the
-sum of the reference lengths closest to each candidate's length (ties -> the shorter).  Any zero precision gives 0 (no
-smoothing).  PARITY UNPINNED against torchmetrics itself (absent); pinned by hand-computed cases and a brute-force
-restatement in tests/test_next_rows.py.
+sum of the reference lengths closest to each candidate's length.  Ties in |len(ref) - len(cand)| go to the FIRST such reference
+in list order: torchmetrics' `_bleu_score_update` takes `target_len_list[target_len_diff.index(min(target_len_diff))]`, and
+`list.index` returns the first minimum (NLTK's corpus_bleu would take the shorter one -- the two differ exactly when a longer
+reference precedes an equally distant shorter one, which tests/test_next_rows.py pins).  Any zero precision gives 0 (no
+smoothing).  PARITY UNPINNED against torchmetrics itself (absent here, no network); pinned by hand-computed cases and a
+brute-force restatement in tests/test_next_rows.py.
 """
 from __future__ import annotations
 
@@ -33,7 +36,8 @@ def corpus_bleu(candidates: Iterable, references: Iterable[Iterable], n_gram: in
         cand = _tokens(cand)
         refs = [_tokens(r) for r in refs]
         c_len += len(cand)
-        r_len += min((abs(len(r) - len(cand)), len(r)) for r in refs)[1]
+        diffs = [abs(len(r) - len(cand)) for r in refs]
+        r_len += len(refs[diffs.index(min(diffs))])          # first closest reference in list order (torchmetrics' rule)
         for n in range(1, n_gram + 1):
             cg = _ngrams(cand, n)
             if not cg:

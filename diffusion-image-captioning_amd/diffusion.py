@@ -20,7 +20,11 @@ from . import _lib
 from .config import LOSS_KINDS, cfg
 from .engine import Denoiser, _p
 
-_state = {"ac_key": None, "ac": None, "noise_seed": 0xD1FF0000, "val_loader": None, "trainer": None}
+NOISE_SEED_BASE = 0xD1FF0000          # q_sample's Philox stream (parallel.configure_model_for_rank mixes the rank in)
+GUIDANCE_SEED_BASE = 0xC1A55F4EE        # classifier-free-guidance uniforms (ref :407), drawn from a generator of their own
+LOSS_RING = 4096                       # loss() returns views into a ring of result slots: valid until LOSS_RING later calls
+
+_state = {"ac_key": None, "ac": None, "noise_seed": NOISE_SEED_BASE, "val_loader": None, "trainer": None, "cfg_gen": {}}
 
 
 # ------------------------------------------------------------------ schedule (ref :337-346)
@@ -67,6 +71,22 @@ def set_alpha_cumprod(table):
 
 def seed_noise(seed: int):
     _state["noise_seed"] = int(seed)
+
+
+def seed_guidance(seed: int, device=None):
+    """(Re)seed the generator the classifier-free-guidance uniforms come from (one per device; per rank under data parallelism)."""
+    dev = torch.device(device if device is not None else "cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    _state["cfg_gen"][str(dev)] = g
+    return g
+
+
+def _guidance_uniform(n, dev):
+    g = _state["cfg_gen"].get(str(torch.device(dev)))
+    if g is None:
+        g = seed_guidance(GUIDANCE_SEED_BASE, dev)
+    return torch.rand((n, 1), device=dev, generator=g)
 
 
 def _next_seed():
@@ -131,7 +151,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     # ---- classifier-free-guidance draw (ref :406-412)
     gi = None
     if w > 0:
-        u = cfg_uniform.to(dev) if cfg_uniform is not None else torch.rand((Nt, 1), device=dev)
+        u = cfg_uniform.to(dev) if cfg_uniform is not None else _guidance_uniform(Nt, dev)
         cm = (u > cfg.CLASSIFIER_FREE_PROB).reshape(Nt)
         if model.rank_rows_forced:
             cm[0] = False
@@ -144,7 +164,9 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     N = Nt + Ng + B
     # without a guided row the text row is masked as a key everywhere and its outputs are unused: leave it out (Tk = L+1)
     drop_txt = model.concat and Ng == 0 and cfg.DROP_UNUSED_TEXT_ROW
-    ws = model._workspace(N, L, drop_txt)
+    # guidance: the number of guided copies is a fresh Binomial(Nt, 1 - p) draw every step -> one workspace sized for the worst case
+    cap = (2 * Nt + B) if w > 0 else N
+    ws = model._workspace(N, L, drop_txt, cap)
     Tk = ws["Tk"]
 
     # ---- one stacked encoder batch: [x_t rows | guided copies | x_1 rows]
@@ -174,7 +196,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         add_txt[Nt:Nt + Ng] = 1
     else:
         ic, tc, km = torch.cat([img_rep, img]), torch.cat([txt_rep, txt]), torch.cat([plain_t, plain_b])
-    x_out = model.encode(xin, ic, tc, km, add_txt, drop_txt=drop_txt)
+    x_out = model.encode(xin[:N], ic, tc, km, add_txt, drop_txt=drop_txt, cap=cap)
     st = model.ops.stream
     row = Tk * 768
     if Ng:
@@ -183,9 +205,13 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     # ---- embedding losses (ref :77-87, 418, 428) + compact rows for the rounding head
     sc = ws.get("loss_sc")
     if sc is None:
-        sc = ws["loss_sc"] = dict(per_seq=torch.zeros(N, dtype=torch.float32, device=dev),
-                                  gscale=torch.zeros(N, dtype=torch.float32, device=dev),
-                                  out=torch.zeros(8, dtype=torch.float32, device=dev))
+        sc = ws["loss_sc"] = dict(per_seq=torch.zeros(ws["cap"], dtype=torch.float32, device=dev),
+                                  gscale=torch.zeros(ws["cap"], dtype=torch.float32, device=dev),
+                                  ring=torch.zeros(LOSS_RING, 8, dtype=torch.float32, device=dev), slot=0)
+    # the reference returns fresh tensors; here every call gets its own slot of a ring (no extra kernel), so losses a caller keeps
+    # (a list of per-step values, an epoch accumulator) are not overwritten by the next step
+    sc["slot"] = (sc["slot"] + 1) % LOSS_RING
+    out = sc["ring"][sc["slot"]]
     inv768 = 1.0 / 768.0
     if kind == 0:
         sa, sb = inv768 / Nt, inv768 / B
@@ -218,7 +244,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     off = (Nt + Ng) * row * 4
     _lib.check(lib.dic_emb_loss(model.dt, kind, _p(x_out) + off, _p(x_0c), B, _p(sc["per_seq"]) + Nt * 4, (_p(dx) + off) if want_grad else 0,
                                 _p(sc["gscale"]) + Nt * 4, _p(cw["xr"]) + Nt * L * 768 * es, B, L, Tk, 768, st), "emb_loss")
-    _lib.check(lib.dic_seg_sum(_p(sc["per_seq"]), Nt + B, Nt, sa, sb, _p(sc["out"]), st), "seg_sum")
+    _lib.check(lib.dic_seg_sum(_p(sc["per_seq"]), Nt + B, Nt, sa, sb, _p(out), st), "seg_sum")
 
     # ---- rounding loss (ref :432-445): streaming GEMM + logsumexp + gather, logits never materialised
     if cfg.USE_PROB_LOSS:
@@ -229,18 +255,18 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         rw = float(cfg.ROUNDING_WEIGHT)
-        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(sc["out"]) + 4 * 4, st), "seg_sum")
+        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(out) + 4 * 4, st), "seg_sum")
         if want_grad:
             dxr = model.rounding_backward(cw, M, Nt * L, rw * ca, rw * cb)
             _lib.check(lib.dic_add_rows(_p(dx), _p(dxr), Nt, L, Tk, 768, st), "add_rows")
             _lib.check(lib.dic_add_rows(_p(dx) + off, _p(dxr) + Nt * L * 768 * 4, B, L, Tk, 768, st), "add_rows")
-        prob = sc["out"][6]
+        prob = out[6]
     else:
         prob = torch.zeros((), dtype=torch.float32, device=dev)
     if want_grad and Ng:
         _lib.check(lib.dic_cfg_mix_bwd(_p(dx), _p(dx) + Nt * row * 4, _p(gi), Ng, row, w, st), "cfg_mix_bwd")
     model._pending = want_grad
-    return sc["out"][0], sc["out"][1], prob
+    return out[0], out[1], prob
 
 
 import os as _os
@@ -348,6 +374,10 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
     x_1 = diffuse_t(x_0, torch.ones(1, dtype=torch.int64, device=dev), noise=nz.pop(0), out=out_1)
     if train:
         trainer.zero_grad()
+        if not isinstance(trainer, AdamW):
+            # a torch optimizer's zero_grad() only drops the .grad views: the slots this backward will not write (position rows
+            # beyond the sequence, text_linear when the text row is skipped) must still be cleared in the flat buffer
+            model.params.zero_pending = True
     x_t_loss, x_1_loss, prob_loss = loss(model, x_t, x_1, x_tgt, x_0, x["image_clip"], x["text_clip"], x["attention_mask"],
                                          x["input_ids"], cfg.LOSS_FUNC, cfg_uniform=cfg_uniform)
     l = x_t_loss + x_1_loss + prob_loss

@@ -137,8 +137,11 @@ class Denoiser:
         else:
             self._set_embedding(embedding, projection)
         self.refresh_shadows()
-        self._ws = {}
-        self._seed = 0x5EED0000 + seed
+        self._ws = {}            # encoder workspaces, keyed by capacity (a few; least recently created is dropped first)
+        self._ce_ws = {}         # rounding-head workspaces, keyed by row count (never dropped with the encoder's)
+        self._te_ws = {}         # TRAIN_EMBEDDING scratch (train_embedding._buffers)
+        self.dropout_seed_base = 0x5EED0000 + seed
+        self._seed = self.dropout_seed_base
         self._saved = None
         self._pending = False
         self._side = None
@@ -168,6 +171,11 @@ class Denoiser:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("DIC_SIDE_PRIO", "0")))
         return self._side
+
+    def set_dropout_seed(self, seed: int):
+        """(Re)start the dropout-mask stream.  Data parallel, every rank gets its own (parallel.configure_model_for_rank): the masks are
+        keyed by (seed, element index), so ranks sharing a seed would apply identical masks to their shards."""
+        self._seed = int(seed) & 0x7FFFFFFFFFFFFFFF
 
     def refresh_shadows(self):
         """bf16 copies of the parameters for the MFMA operands (dic_adamw keeps them fresh itself)."""
@@ -230,14 +238,24 @@ class Denoiser:
         return out[:, :self.vocab].reshape(*shp, self.vocab)
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, N, L, drop_txt=False):
+    @staticmethod
+    def _evict(cache, keep):
+        while len(cache) > keep:
+            cache.pop(next(iter(cache)))
+
+    def _workspace(self, N, L, drop_txt=False, cap=None):
+        """Activations + backward scratch for a stacked batch of N sequences.  Buffers are sized for `cap` >= N sequences and cached by
+        capacity: with classifier-free guidance N = S*B + (number of guided rows) + B changes every step, and a cache keyed by N
+        would allocate a fresh multi-GB workspace per step -- the caller passes the worst case instead and the kernels get the live N."""
         Tk = (L + 1 if drop_txt else L + 2) if self.concat else L
-        key = (N, L, Tk)
+        cap = N if cap is None else max(int(cap), N)
+        key = (cap, L, Tk)
         ws = self._ws.get(key)
         if ws is not None:
+            ws["N"], ws["T"] = N, N * Tk
             return ws
-        if len(self._ws) > 8:
-            self._ws.clear()
+        self._evict(self._ws, 2)
+        live_N, N = N, cap
         T, D, Hd, dev, td = N * Tk, self.dim, self.hidden, self.device, self.tdtype
         e = lambda *s, dtype=td: torch.empty(*s, dtype=dtype, device=dev)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -267,12 +285,14 @@ class Denoiser:
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
         ws["splitk_tail"] = f(8 * (768 * 512 + 768))   # fp32 CLIP-projection weight gradients (main stream, while the side stream owns "splitk")
         ws["splitk"] = f(64 * 1024 * 1024)          # 256 MB: split_k * M * N fp32 partial tiles of one dW GEMM / the rounding dX GEMM
+        ws["cap"], ws["N"], ws["T"] = cap, live_N, live_N * Tk
         self._ws[key] = ws
         return ws
 
     def _ce_workspace(self, M):
-        ws = self._ws.get(("ce", M))
+        ws = self._ce_ws.get(M)
         if ws is None:
+            self._evict(self._ce_ws, 3)
             dev = self.device
             np_ = max(self.ops.L.dic_ce_n_partials(self.vocab, 128), self.ops.L.dic_ce_n_partials(self.vocab, 256))   # either tile size
             ws = dict(M=M, np=np_, xr=torch.empty(M, 768, dtype=self.tdtype, device=dev),
@@ -281,16 +301,16 @@ class Denoiser:
                       argmax=torch.empty(M, dtype=torch.int64, device=dev), nll=torch.empty(M, dtype=torch.float32, device=dev),
                       tgt=torch.empty(M, dtype=torch.int64, device=dev), dxr=torch.empty(M, 768, dtype=torch.float32, device=dev),
                       dlogits=None)
-            self._ws[("ce", M)] = ws
+            self._ce_ws[M] = ws
         return ws
 
     # ------------------------------------------------------------------ encoder forward (hf:92-118, 150-259, 501-513)
-    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False):
+    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None):
         """x [N,L,768] fp32; image_clip/text_clip [N,512]; key_mask [N,Tk] uint8 -> x_out [N,Tk,768] fp32.
         Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training.
         drop_txt (concat fusion, no guided row in the batch): run with Tk = L+1, leaving the never-read text row out."""
         N, L, _ = x.shape
-        ws = self._workspace(N, L, drop_txt)
+        ws = self._workspace(N, L, drop_txt, cap)
         Tk, T, D, Hd = ws["Tk"], ws["T"], self.dim, self.hidden
         o, P, lib = self.ops, self.params, self.ops.L
         o.begin()
@@ -302,12 +322,15 @@ class Denoiser:
         seed = self._seed
         ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
         if x.data_ptr() != ws["xin"].data_ptr():
-            ws["xin"].copy_(x)
-        ws["img_in"].copy_(image_clip.reshape(N, 512))
-        ws["txt_in"].copy_(text_clip.reshape(N, 512))
-        ws["kmask"].copy_(key_mask)
-        if add_txt is not None:
-            ws["addtxt"].copy_(add_txt)
+            ws["xin"][:N].copy_(x)
+        if image_clip is not None:                     # None: the caller filled the workspace's input buffers itself
+            ws["img_in"][:N].copy_(image_clip.reshape(N, 512))
+            ws["txt_in"][:N].copy_(text_clip.reshape(N, 512))
+            ws["kmask"][:N].copy_(key_mask)
+            if add_txt is not None:
+                ws["addtxt"][:N].copy_(add_txt)
+            else:
+                ws["addtxt"][:N].zero_()               # a reused workspace must not keep an earlier batch's guided-row flags
         mode = ws["mode"]
         # K3: CLIP projections, exact fp32 MFMA (tiny)
         o.gemm(_p(ws["img_in"]), P.ptr("Wimg"), _p(ws["img_p"]), N, D, 512, 512, 512, D, bias=P.ptr("bimg"), out_f32=1, dtype=DIC_F32)
@@ -336,7 +359,7 @@ class Denoiser:
         o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"))
         _lib.check(lib.dic_gelu_ln_fwd(self.dt, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
         self._saved = ws
-        return ws["x_out"]
+        return ws["x_out"][:N]
 
     # ------------------------------------------------------------------ encoder backward
     def backward(self, dx_out=None, layer_done=None):

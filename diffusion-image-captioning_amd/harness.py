@@ -87,21 +87,22 @@ def fit(model, trainer, train_loader, val_loader, epochs=None, scheduler="linspa
         n = 0
         for x in train_loader:
             l, a, b, c = train_func(model, trainer, x)
-            acc = [acc[0] + a.clone(), acc[1] + b.clone(), acc[2] + c.clone(), acc[3] + l.clone()]
+            acc = [acc[0] + a, acc[1] + b, acc[2] + c, acc[3] + l]      # lazily, on the device (ref :530-533)
             n += 1
             if cfg.DYNAMIC_ROUNDING_WEIGHT > 0:
                 cfg.ROUNDING_WEIGHT = float(((acc[0] + acc[1]) / acc[2]).detach()) * cfg.DYNAMIC_ROUNDING_WEIGHT
             if cfg.DEBUG:
                 break
         val = validate(model, val_loader)
-        if float(val[0] + val[1] + val[2]) > cfg.EARLY_STOP_RATIO * float(acc[3]) / max(n, 1):
+        n_batches = len(train_loader) if hasattr(train_loader, "__len__") else max(n, 1)      # the reference divides by len(train_loader)
+        if float(val[0] + val[1] + val[2]) > cfg.EARLY_STOP_RATIO * float(acc[3]) / max(n_batches, 1):
             if not early_stopped:
                 if summary is not None:
                     summary.write("early stop! \n")
                 if checkpoint_path:
                     save_checkpoint(checkpoint_path, model, trainer, epoch=epoch, early_stop=True)
             early_stopped = True
-        line = log_line(epoch, acc[:3], max(n, 1), val)
+        line = log_line(epoch, acc[:3], max(n_batches, 1), val)
         if summary is not None:
             summary.write(line)
         history.append(line)

@@ -10,7 +10,8 @@ factor is folded into the AdamW kernel (`grad_scale`), not a separate pass over 
 Reference caveats kept:
   * one t-vector per step is shared by the whole *global* batch (ref :461) -> every rank draws it from an identically
     seeded generator (no per-step collective);
-  * the noise eps is per item -> each rank seeds its Philox stream differently;
+  * the noise eps, the dropout masks and the guidance uniforms are per item -> `configure_model_for_rank` mixes the rank into
+    all three seeds;
   * CFG forces rows 0/1 of the batch to unguided/guided (ref :408-409) -> only rank 0 does.
 Backend "nccl" IS RCCL on ROCm; the CPU tests run the same code with "gloo".
 """
@@ -170,6 +171,24 @@ def allreduce_scalars(*vals):
     return tuple(t[i] for i in range(len(vals)))
 
 
-def configure_model_for_rank(model):
-    model.rank_rows_forced = rank() == 0
+_RANK_MIX = 0x9E3779B97F4A7C15      # odd 64-bit constant: rank r shifts every per-rank seed by r * _RANK_MIX (mod 2^63)
+
+
+def rank_seed(base: int, rank_: int | None = None) -> int:
+    """Per-rank variant of a seed: identical on rank 0, distinct on every other rank (kept below 2^63: the C-ABI takes uint64,
+    torch generators take int64)."""
+    r = rank() if rank_ is None else rank_
+    return (int(base) + r * _RANK_MIX) & 0x7FFFFFFFFFFFFFFF
+
+
+def configure_model_for_rank(model, rank_: int | None = None):
+    """What differs between the ranks of a data-parallel job: the noise eps, the dropout masks and the
+    guidance uniforms are per item, so every rank draws its own (seeds mixed with the rank); the t-vector stays shared
+    (`shared_randint`); the forced unguided/guided rows 0/1 of ref :408-409 exist once per GLOBAL batch, i.e. on rank 0."""
+    from . import diffusion
+    r = rank() if rank_ is None else rank_
+    model.rank_rows_forced = r == 0
+    model.set_dropout_seed(rank_seed(model.dropout_seed_base, r))
+    diffusion.seed_noise(rank_seed(diffusion.NOISE_SEED_BASE, r))
+    diffusion.seed_guidance(rank_seed(diffusion.GUIDANCE_SEED_BASE, r), model.device)
     return model

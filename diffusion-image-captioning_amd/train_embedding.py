@@ -30,18 +30,19 @@ def _check_config(model):
 
 def _buffers(model, N, L, Tk, M):
     """Scratch of the 16-d side, cached per batch geometry."""
-    key = ("te", N, L, Tk, M)
-    b = model._ws.get(key)
+    key = (N, L, Tk, M)
+    b = model._te_ws.get(key)
     if b is None:
+        model._evict(model._te_ws, 2)
         dev, C = model.device, model.params.in_channel
 
         def f(*s):
             return torch.zeros(*s, dtype=torch.float32, device=dev)
         b = dict(x16=f(N, L, C), x16p=f(N * L, KP), Winp=f(768, KP), x_out16=f(N, Tk, C), Woutp=f(KP, 768), dx16=f(N, Tk, C), g16=f(N, Tk, C),
                  dx16p=f(N * Tk, KP), xr16=f(M, C), xr32=f(M, KP), Wlm32=f(model.vpad, KP), dxr32=f(M, KP), dxr16=f(M, C),
-                 x16Tk=f(N, Tk, C), dxin16=f(N, Tk, C), dx0=f(cfg.BATCH_SIZE, L, C), dlogits=None, per_seq=f(N), gscale=f(N), out=f(8),
+                 x16Tk=f(N, Tk, C), dxin16=f(N, Tk, C), dx0=f(cfg.BATCH_SIZE, L, C), dlogits=None, per_seq=f(N), gscale=f(N), ring=f(256, 8), slot=0,
                  cs=f(64 * max(Tk * C, 768)))
-        model._ws[key] = b
+        model._te_ws[key] = b
     return b
 
 
@@ -91,6 +92,7 @@ def _masks(model, mask, S, B, L, drop_txt, gi):
 
 
 def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cfg_uniform=None):
+    from .diffusion import _guidance_uniform
     """`loss` (ref :382-445) with the learned embedding: returns the three loss scalars and, under grad mode, leaves the encoder's
     output gradient in the workspace (so `model.backward()` runs as usual) plus what `backward_tail` needs."""
     _check_config(model)
@@ -102,7 +104,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
     # ---- classifier-free-guidance draw (ref :406-412), as in diffusion.loss
     gi = None
     if w > 0:
-        u = cfg_uniform.to(dev) if cfg_uniform is not None else torch.rand((Nt, 1), device=dev)
+        u = cfg_uniform.to(dev) if cfg_uniform is not None else _guidance_uniform(Nt, dev)
         cm = (u > cfg.CLASSIFIER_FREE_PROB).reshape(Nt)
         if model.rank_rows_forced:
             cm[0] = False
@@ -168,7 +170,9 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
     off = (Nt + Ng) * row * 4
     _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16) + off, _p(x_0c), B, _p(b["per_seq"]) + Nt * 4, (dx + off) if want_grad else 0,
                                 _p(b["gscale"]) + Nt * 4, _p(b["xr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "emb_loss")
-    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), Nt + B, Nt, sa, sb, _p(b["out"]), st), "seg_sum")
+    b["slot"] = (b["slot"] + 1) % 256           # ring of result slots, as diffusion.loss (returned losses stay valid for 256 calls)
+    out = b["ring"][b["slot"]]
+    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), Nt + B, Nt, sa, sb, _p(out), st), "seg_sum")
     if want_grad:
         b["g16"].copy_(b["dx16"])                  # the loss gradient alone: its negative flows into the targets
 
@@ -187,7 +191,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
         ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         rw = float(cfg.ROUNDING_WEIGHT)
-        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(b["out"]) + 4 * 4, st), "seg_sum")
+        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(out) + 4 * 4, st), "seg_sum")
         if want_grad:
             if b["dlogits"] is None:
                 b["dlogits"] = torch.empty(M, model.vpad, dtype=torch.float32, device=dev)
@@ -200,7 +204,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
             b["dxr16"].copy_(b["dxr32"][:, :C])
             _lib.check(lib.dic_add_rows(_p(b["dx16"]), _p(b["dxr16"]), Nt, L, Tk, C, st), "add_rows")
             _lib.check(lib.dic_add_rows(_p(b["dx16"]) + off, _p(b["dxr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "add_rows")
-        prob = b["out"][6]
+        prob = out[6]
     else:
         prob = torch.zeros((), dtype=torch.float32, device=dev)
         if want_grad:
@@ -218,7 +222,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
             _lib.check(lib.dic_cfg_mix_bwd(_p(ws["dx_out"]), _p(ws["dx_out"]) + Nt * Tk * 768 * 4, _p(gi), Ng, Tk * 768, w, st), "cfg_mix_bwd")
         model._te_pending = dict(b=b, N=N, L=L, Tk=Tk, S=S, B=B, ids=idx.to(dev, torch.int64), gi=gi, Ng=Ng)
     model._pending = want_grad
-    return b["out"][0], b["out"][1], prob
+    return out[0], out[1], prob
 
 
 def backward_tail(model, t, t_next=None):

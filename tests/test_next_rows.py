@@ -25,7 +25,7 @@ def brute_bleu(cands, refs):
     c = r = 0
     for cand, rs in zip(cands, refs):
         c += len(cand)
-        r += sorted(rs, key=lambda x: (abs(len(x) - len(cand)), len(x)))[0].__len__()
+        r += len(rs[min(range(len(rs)), key=lambda i: abs(len(rs[i]) - len(cand)))])      # first closest reference in list order
         for n in range(1, 5):
             grams = [tuple(cand[i:i + n]) for i in range(len(cand) - n + 1)]
             cnt = Counter(grams)
@@ -54,6 +54,20 @@ def test_bleu_hand_cases():
     # strings and tensors are accepted
     assert bleu.corpus_bleu(["a b c d e"], [["a b c d e"]]) == pytest.approx(1.0)
     assert bleu.corpus_bleu([torch.tensor([1, 2, 3, 4, 5])], [[torch.tensor([1, 2, 3, 4, 5])]]) == pytest.approx(1.0)
+
+
+def test_bleu_length_tie_break_is_first_in_list_order():
+    """torchmetrics `_bleu_score_update`: target_len_list[target_len_diff.index(min(target_len_diff))] -- the FIRST reference among
+    those equally close in length, not the shorter one (NLTK's rule).  Candidate of 6 tokens, references of 7 and 5 tokens."""
+    cand = "a b c d e f".split()
+    longer, shorter = "a b c d e f g".split(), "a b c d e".split()
+    # every candidate n-gram occurs in `longer`, so all four precisions are 1 and BLEU = brevity penalty alone
+    first_longer = bleu.corpus_bleu([cand], [[longer, shorter]])
+    first_shorter = bleu.corpus_bleu([cand], [[shorter, longer]])
+    assert first_longer == pytest.approx(math.exp(1 - 7 / 6))      # r = 7 (first in list) > c = 6
+    assert first_shorter == pytest.approx(1.0)                     # r = 5 < c = 6: no penalty
+    assert first_longer != pytest.approx(first_shorter)            # the two rules are distinguishable on this case
+    assert brute_bleu([cand], [[longer, shorter]]) == pytest.approx(first_longer)
 
 
 def test_bleu_matches_bruteforce_on_random_corpora():
@@ -105,6 +119,64 @@ def test_loader_schema_and_drop_last():
         assert b["image_clip"].shape == (8, 512) and b["input_ids"].shape == (8, 16) and b["input_ids"].dtype == torch.int64
         seen += b["input_ids"][:, 0].tolist()
     assert len(seen) == 8 * len(ld)
+
+
+# ------------------------------------------------------------------ epoch driver branches (ref :520-522, 535-536, 547-553) with stub step functions
+class _StubModel:
+    training = True
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+
+def _run_fit(train_losses, val_losses, **cfg_kw):
+    """harness.fit over a 2-batch loader whose step returns the scripted losses (x_t, x_1, prob) per call."""
+    saved = {k: getattr(dic.cfg, k) for k in ("EARLY_STOP_RATIO", "DYNAMIC_ROUNDING_WEIGHT", "ROUNDING_WEIGHT", "LEARNING_RATE", "END_LEARNING_RATE", "DEBUG")}
+    dic.cfg.update(DEBUG=False, **cfg_kw)
+    calls, rw_seen, lr_seen = iter(train_losses), [], []
+    trainer = type("T", (), {"param_groups": [{"lr": None}]})()
+
+    def step(model, trainer_, x):
+        a, b, c = (torch.tensor(float(v)) for v in next(calls))
+        rw_seen.append(dic.cfg.ROUNDING_WEIGHT)
+        lr_seen.append(trainer_.param_groups[0]["lr"])
+        return a + b + c, a, b, c
+    vals = iter(val_losses)
+    out = io.StringIO()
+    try:
+        hist = harness.fit(_StubModel(), trainer, [0, 1], None, epochs=len(val_losses), summary=out, train_func=step,
+                           validate=lambda m, vl: tuple(torch.tensor(float(v)) for v in next(vals)))
+        return hist, out.getvalue(), rw_seen, lr_seen, dic.cfg.ROUNDING_WEIGHT
+    finally:
+        dic.cfg.update(**saved)
+
+
+def test_fit_early_stop_branch_fires_once_and_training_continues():
+    # epoch 0: val 9 <= 1.05 * mean(l) = 1.05 * 10 -> no stop; epoch 1: val 12 > 1.05 * 10 -> "early stop!"; epoch 2: again above, not repeated
+    tr = [(4, 3, 3)] * 6
+    hist, text, _, lr, _ = _run_fit(tr, [(3, 3, 3), (4, 4, 4), (5, 5, 5)], EARLY_STOP_RATIO=1.05, DYNAMIC_ROUNDING_WEIGHT=-1,
+                                    LEARNING_RATE=1e-4, END_LEARNING_RATE=5e-5)
+    lines = text.splitlines()
+    assert lines[0].startswith("epoch 0 ") and lines[1] == "early stop! " and lines[2].startswith("epoch 1 ") and lines[3].startswith("epoch 2 ")
+    assert text.count("early stop!") == 1 and len(hist) == 3          # written once (ref :549-552), all epochs still run
+    # per-epoch learning rates from the linspace table (ref :520-522): 1e-4, 7.5e-5, 5e-5, two steps each
+    np.testing.assert_allclose(lr, [1e-4, 1e-4, 7.5e-5, 7.5e-5, 5e-5, 5e-5], rtol=1e-6)
+    # the threshold is strict: val == ratio * train does not stop
+    _, text2, *_ = _run_fit([(4, 3, 3)] * 2, [(3.5, 3.5, 3.5)], EARLY_STOP_RATIO=1.05)
+    assert "early stop" not in text2
+
+
+def test_fit_dynamic_rounding_weight_follows_the_running_ratio():
+    # ref :535-536: after every step ROUNDING_WEIGHT = (acc_x_t + acc_x_1) / acc_prob * DYNAMIC_ROUNDING_WEIGHT, accumulators reset per epoch
+    tr = [(4, 2, 3), (2, 2, 2), (1, 1, 8), (3, 3, 2)]
+    _, _, rw, _, rw_end = _run_fit(tr, [(0, 0, 0), (0, 0, 0)], DYNAMIC_ROUNDING_WEIGHT=0.5, ROUNDING_WEIGHT=0.3, EARLY_STOP_RATIO=1e9)
+    # the weight each step SAW is the one set after the previous step (0.3 before the first)
+    assert rw == pytest.approx([0.3, (4 + 2) / 3 * 0.5, (6 + 4) / 5 * 0.5, (1 + 1) / 8 * 0.5])
+    assert rw_end == pytest.approx((4 + 4) / 10 * 0.5)
+    # switched off (the default -1): untouched
+    _, _, rw2, _, rw2_end = _run_fit(tr[:2], [(0, 0, 0)], DYNAMIC_ROUNDING_WEIGHT=-1, ROUNDING_WEIGHT=0.3, EARLY_STOP_RATIO=1e9)
+    assert rw2 == [0.3, 0.3] and rw2_end == 0.3
 
 
 # ------------------------------------------------------------------ GPU: epoch driver + checkpoint round trip
