@@ -56,7 +56,7 @@ def build(verbose: bool = False) -> str:
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
         if s.endswith("misc.hip"):
             # q_sample must round a*x, eps*b and their sum separately to be bit-exact with the reference (ref :360-362);
             # everything in misc.hip is HBM-bound, so no FMA contraction in this file costs nothing

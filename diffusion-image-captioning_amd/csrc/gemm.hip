@@ -25,6 +25,13 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef DIC_GEMM_PF
+#define DIC_GEMM_PF 3            // A fragments read ahead of their MFMAs in the bf16 kernel
+#endif
+#ifndef DIC_GEMM_ISSUE_AT
+#define DIC_GEMM_ISSUE_AT -1     // fragment step after whose MFMAs the next K-step's LDS-DMA is issued; < 0: before the fragment reads
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, NT = 256;
@@ -338,13 +345,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {   // v1:
     epilogue<T, EPI>(acc, p, m0, n0, wm, wn, lane, bn, nbn);
 }
 
-// ---- LDS-staged epilogue of the bf16 kernel -------------------------------------------------------------------------
-// The MFMA accumulator layout gives a lane 4 consecutive n of ONE row, so direct stores are 16 rows x 32-byte fragments
-// per wave-instruction -- store-ISSUE-bound: a K=64 GEMM of 510 tiles took 13 us, almost all of it this tail.  Instead the
-// fp32 tile is parked in the (now idle) LDS stages -- 128 rows at a time --, XOR-swizzled so both the scattered 16-byte writes
-// and the row-wise 16-byte reads are bank-conflict-free, and written out row-contiguously: each thread handles 8 consecutive
-// n, BN/8 threads cover an output row, a wave-instruction writes whole 128-byte lines.  Residual / pre-activation side inputs
-// are read with the same fully coalesced pattern, and each thread's 8 columns are fixed, so its bias slice is loaded once.
+// ---- bf16 kernel: output mapping and epilogue -------------------------------------------------------------------------------------
+// The MFMA is issued with the operands swapped (D = Bfrag x Afrag), so a lane holds 4 values of ONE output row for 4 of the B
+// fragment's rows (= output columns).  Which LDS rows feed a B fragment is free, so fragment pair (2p, 2p+1) of a wave's 64 columns is
+// loaded with the rows   n = 32 p + 8 (idx>>2) + 4 q + (idx&3)   (q = fragment parity, idx = 0..15 the fragment row): lane group
+// g = lane>>4 then owns the 8 CONSECUTIVE columns 32 p + 8 g .. + 7 of its row across the pair, i.e. 16 bytes of bf16 output.  The
+// accumulators go to HBM straight from registers as 16-byte stores (a wave-instruction covers 16 rows x 64 contiguous bytes) and the
+// side inputs (residual, GELU' pre-activation) come in with the same shape.  Round 1 parked the fp32 tile in LDS to get row-contiguous
+// stores (32 ds_write_b128 + 2 barriers + 16 ds_read_b128 per wave on the critical path of every tile, and the LDS was not free for
+// the next tile's operands meanwhile); with 16 bytes per lane straight from the accumulators that detour is gone and the next tile's
+// first K-step is already in flight while this one is written out.
 __device__ __forceinline__ void unpack8(i32x4 r, f32x4& a, f32x4& b) {
     a[0] = __uint_as_float((unsigned)r[0] << 16); a[1] = __uint_as_float((unsigned)r[0] & 0xffff0000u);
     a[2] = __uint_as_float((unsigned)r[1] << 16); a[3] = __uint_as_float((unsigned)r[1] & 0xffff0000u);
@@ -361,17 +371,22 @@ __device__ __forceinline__ i32x4 pack8f(const f32x4& a, const f32x4& b) {
 // Tile geometries of the bf16 kernel.  T128: 128x128, 4 waves (2x2, 64x64 each), 64 KB LDS, two workgroups per CU.
 // T256: 256x256, 8 waves (2x4, 128x64 each), 128 KB LDS, one workgroup per CU -- twice the flop per byte pulled from L2
 // (128 vs 64 flop/B: the 128x128 kernel saturates near 0.9 PFLOP/s on L2->LDS bandwidth) and 25 % fewer LDS reads per MFMA.
+// BM is the MAXIMUM tile height: the launch picks the height actually used (a multiple of 16 rows) so that the tiles fill whole
+// rounds of resident workgroups (pick_tile_rows below).
 struct T128 { static constexpr int BM = 128, BN = 128, WM = 2, WN = 2; };
 struct T256 { static constexpr int BM = 256, BN = 256, WM = 2, WN = 4; };
 template <class C> struct Geo {
     static constexpr int BM = C::BM, BN = C::BN, WM = C::WM, WN = C::WN;
+    static_assert(WM == 2, "tile rows are split over two wave rows");
     static constexpr int NW = WM * WN, NTH = 64 * NW;
-    static constexpr int FM = BM / WM / 16, FN = BN / WN / 16;           // MFMA fragments per wave
+    static constexpr int FM = BM / WM / 16, FN = BN / WN / 16;           // MFMA fragments per wave (FM: at most)
+    static constexpr int NP = FN / 2;                                    // fragment pairs = 8-column groups per lane
+    static constexpr int WCOLS = BN / WN;                                // columns per wave
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
     static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;             // 1 KiB DMA pieces per wave per operand
-    static constexpr int C_ROWS = LDS / (BN * 4) < BM ? LDS / (BN * 4) : BM;   // output rows parked in LDS per epilogue pass
-    static constexpr int C_PASSES = BM / C_ROWS;
 };
+// output column (relative to the wave's first) of accumulator element r of fragment j held by lane group g
+__device__ __forceinline__ int frag_col(int j, int g, int r) { return 32 * (j >> 1) + 8 * g + 4 * (j & 1) + r; }
 
 // workgroup barrier that waits for this wave's LDS traffic only: outstanding global STORES (epilogue output) keep draining across
 // it.  (__syncthreads() carries vmcnt(0), i.e. a full round trip of every store issued so far.)
@@ -380,187 +395,211 @@ __device__ __forceinline__ void barrier_lds_only() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <class C, int EPI, bool PF>
-__device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN], const DicGemmParams& p, int m0, int n0, int wm, int wn,
-                                             int lane, int tid, char* smem) {
+// One wave's accumulators -> HBM.  m_first: global row of the wave's fragment 0 (CNT fragments of 16 rows); n_first: global column of
+// the wave's first column.
+// gfx950 has ONE counter (vmcnt) for loads and stores, and they complete out of order with respect to each other: any wait for a
+// load drains every store issued before it (measured in round 1: 12 us to write a 28 MB output that a fill kernel writes in 4 when a
+// side input was loaded per row).  So all side inputs of the wave's tile are loaded first, one vmcnt(0) covers them, and the rest is
+// math + stores with nothing to wait on.  (The bias is added to the accumulators before the side tile is requested: its registers
+// are free again by then.)
+template <class C, int EPI, bool PF, int CNT>
+__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first, int lane) {
     using G = Geo<C>;
     using T = bf16_t;
-    constexpr int ROWB = G::BN * 4;                       // bytes per parked row
-    constexpr int CPR = G::BN / 8;                        // 8-column items per row
-    constexpr int RPI = G::NTH / CPR;                     // rows covered per iteration
-    constexpr int NIT = G::C_ROWS / RPI;
     const int g = lane >> 4, t = lane & 15;
-    const int c8 = tid % CPR;                             // this thread's 8 columns are the same for every row it handles
-    const int n = n0 + c8 * 8;
-    const bool v0ok = n < p.N, v1ok = n + 4 < p.N;
-    f32x4 b0{0.f, 0.f, 0.f, 0.f}, b1{0.f, 0.f, 0.f, 0.f};
+    auto put = [&](int i, int q, T* c, bool ok, const f32x4& x0, const f32x4& x1) { if (ok) *(i32x4*)c = pack8f(x0, x1); };
+    int nc[G::NP];
+    bool v0[G::NP], v1[G::NP];
+#pragma unroll
+    for (int q = 0; q < G::NP; ++q) { nc[q] = n_first + 32 * q + 8 * g; v0[q] = nc[q] < p.N; v1[q] = nc[q] + 4 < p.N; }
     if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU) {
-        if (p.bias) { if (v0ok) b0 = *(const f32x4*)(p.bias + n); if (v1ok) b1 = *(const f32x4*)(p.bias + n + 4); }
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 b0{0.f, 0.f, 0.f, 0.f}, b1{0.f, 0.f, 0.f, 0.f};
+                if (v0[q]) b0 = *(const f32x4*)(p.bias + nc[q]);
+                if (v1[q]) b1 = *(const f32x4*)(p.bias + nc[q] + 4);
+#pragma unroll
+                for (int i = 0; i < CNT; ++i) { acc[i][2 * q] += b0; acc[i][2 * q + 1] += b1; }
+            }
+        }
     }
-    const float inv_keep = drop_inv_keep(p.p_drop);
-    // gfx950 has ONE counter (vmcnt) for loads and stores, and they complete out of order with respect to each other: any wait for a
-    // load drains every store issued before it.  A row loop that reads a side input per row (residual, GELU' pre-activation, lse /
-    // target of the rounding head) therefore serialises on the round trip of each row's STORE (measured: 12 us to write a 28 MB
-    // output that a fill kernel writes in 4).  So the row loop below contains no global load at all: a group of GRP rows gets its side
-    // inputs into registers first (the first group's under the parking traffic, ahead of the barrier), one explicit vmcnt(0) covers
-    // them, and then the rows are LDS read -> math -> store with nothing to wait on.  128-tiles take the whole pass as one group;
-    // 256-tiles have 16 spare VGPRs, i.e. groups of 4.  The two combinations that need loads inside the loop (accumulating into an
-    // fp32 C, a residual with N % 8 != 0) are rare and take the `general` instantiation of the loop.
-    constexpr bool SIDE = PF && (EPI == DIC_EPI_GELU_BWD || EPI == DIC_EPI_AFFINE);     // a [M][N] side matrix in the compute dtype
-    constexpr bool ROWSIDE = EPI == DIC_EPI_CE_DLOGITS;                                  // per-row scalars
-    constexpr int GRP = G::BM == 128 ? NIT : ((SIDE || ROWSIDE) ? 4 : 2);
-    const T* side = EPI == DIC_EPI_GELU_BWD ? (const T*)p.aux : (const T*)p.R;
-    const int side_ld = EPI == DIC_EPI_GELU_BWD ? p.ldaux : p.ldr;
-    auto rows = [&](auto general_c, int pass) {
-        constexpr bool GENERAL = decltype(general_c)::value;
-#pragma unroll 1
-        for (int g0 = 0; g0 < NIT; g0 += GRP) {
-            i32x4 pre[SIDE ? GRP : 1];
-            float r_lse[ROWSIDE ? GRP : 1], r_sc[ROWSIDE ? GRP : 1];
-            long long r_tg[ROWSIDE ? GRP : 1];
-            bool issued = false;
-            if constexpr (SIDE && !GENERAL) {
-                if (side) {
-                    issued = true;
+    if constexpr (EPI == DIC_EPI_AFFINE) {
+        const float inv_keep = drop_inv_keep(p.p_drop);
+        const bool general = p.accumulate || (p.R != nullptr && (!PF || (p.N & 7) != 0));
+        if (!general) {
+            i32x4 pre[PF ? CNT : 1][PF ? G::NP : 1];
+            const T* R = (const T*)p.R;
+            if constexpr (PF) {
+                if (R) {
 #pragma unroll
-                    for (int kk = 0; kk < GRP; ++kk) {
-                        const int m = m0 + pass * G::C_ROWS + tid / CPR + RPI * (g0 + kk);
-                        pre[kk] = i32x4{0, 0, 0, 0};
-                        if (m < p.M && v1ok) pre[kk] = *(const i32x4*)(side + (size_t)m * side_ld + n);
+                    for (int i = 0; i < CNT; ++i) {
+                        const int m = m_first + 16 * i + t;
+#pragma unroll
+                        for (int q = 0; q < G::NP; ++q) {
+                            pre[i][q] = i32x4{0, 0, 0, 0};
+                            if (m < p.M && v1[q]) pre[i][q] = *(const i32x4*)(R + (size_t)m * p.ldr + nc[q]);
+                        }
                     }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the residual tile is in registers
                 }
             }
-            if constexpr (ROWSIDE) {
-                issued = true;
 #pragma unroll
-                for (int kk = 0; kk < GRP; ++kk) {
-                    const int m = m0 + pass * G::C_ROWS + tid / CPR + RPI * (g0 + kk);
-                    const bool ok = m < p.M;
-                    r_lse[kk] = ok ? p.lse[m] : 0.f;
-                    r_tg[kk] = ok ? p.tgt[m] : -1;
-                    r_sc[kk] = ok ? row_scale(p, m) : 0.f;
-                }
-            }
-            if (g0 == 0) barrier_lds_only();                     // the parked tile is complete
-            if (issued) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the group's side inputs are in registers
-#pragma unroll(GENERAL ? 1 : GRP)
-            for (int kk = 0; kk < GRP; ++kk) {
-                const int row = tid / CPR + RPI * (g0 + kk), m = m0 + pass * G::C_ROWS + row;
+            for (int i = 0; i < CNT; ++i) {
+                const int m = m_first + 16 * i + t;
                 const bool mok = m < p.M;
-                const char* rp_ = smem + row * ROWB;
-                f32x4 x0 = *(const f32x4*)(rp_ + (((2 * c8) ^ (row & 15)) << 4)), x1 = *(const f32x4*)(rp_ + (((2 * c8 + 1) ^ (row & 15)) << 4));
-                if constexpr (EPI == DIC_EPI_AFFINE) {
-                    x0 += b0; x1 += b1;
+#pragma unroll
+                for (int q = 0; q < G::NP; ++q) {
+                    f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
                     if (p.p_drop > 0.f) {
-                        x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + n, p.p_drop, inv_keep);
-                        x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + n + 4, p.p_drop, inv_keep);
+                        x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + nc[q], p.p_drop, inv_keep);
+                        x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + nc[q] + 4, p.p_drop, inv_keep);
                     }
-                    if constexpr (!GENERAL) {
-                        if constexpr (SIDE) {
-                            if (side) { f32x4 r0, r1; unpack8(pre[kk], r0, r1); x0 += r0; x1 += r1; }
-                        }
-                        if (p.out_f32) {
-                            float* c = (float*)p.C + (size_t)m * p.ldc + n;
-                            if (mok && v0ok) *(f32x4*)c = x0;
-                            if (mok && v1ok) *(f32x4*)(c + 4) = x1;
-                        } else {
-                            T* c = (T*)p.C + (size_t)m * p.ldc + n;
-                            if (mok && v1ok) *(i32x4*)c = pack8f(x0, x1);
-                            else if (mok && v0ok) Elem<T>::st4(c, x0);
-                        }
-                    } else if (mok && v0ok) {
-                        if (p.R) {
-                            const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
-                            if (v1ok) { f32x4 r0, r1; unpack8(*(const i32x4*)rp, r0, r1); x0 += r0; x1 += r1; }
-                            else x0 += Elem<T>::ld4(rp);
-                        }
-                        if (p.out_f32) {
-                            float* c = (float*)p.C + (size_t)m * p.ldc + n;
-                            if (p.accumulate) { x0 += *(const f32x4*)c; if (v1ok) x1 += *(const f32x4*)(c + 4); }
-                            *(f32x4*)c = x0;
-                            if (v1ok) *(f32x4*)(c + 4) = x1;
-                        } else {
-                            T* c = (T*)p.C + (size_t)m * p.ldc + n;
-                            if (v1ok) *(i32x4*)c = pack8f(x0, x1); else Elem<T>::st4(c, x0);
-                        }
+                    if constexpr (PF) {
+                        if (R) { f32x4 r0, r1; unpack8(pre[i][q], r0, r1); x0 += r0; x1 += r1; }
                     }
-                } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {            // N % 8 == 0 is required for this epilogue
-                    x0 += b0; x1 += b1;
-                    if (mok && v1ok) *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + n) = pack8f(x0, x1);     // pre-activation u (for GELU')
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
-                    if (mok && v1ok) *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-                } else if constexpr (EPI == DIC_EPI_GELU_BWD) {
-                    f32x4 u0, u1;
-                    if constexpr (SIDE) unpack8(pre[kk], u0, u1);
-                    else unpack8((mok && v1ok) ? *(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + n) : i32x4{0, 0, 0, 0}, u0, u1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
-                    if (mok && v1ok) *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
-                } else {   // DIC_EPI_CE_DLOGITS: (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
-                    const float lse = r_lse[kk], sc = r_sc[kk];
-                    const long long tg = r_tg[kk];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
-                        if ((long long)(n + r) == tg) q0 -= 1.0f;
-                        if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
-                        x0[r] = q0 * sc; x1[r] = q1 * sc;
+                    if (p.out_f32) {
+                        float* c = (float*)p.C + (size_t)m * p.ldc + nc[q];
+                        if (mok && v0[q]) *(f32x4*)c = x0;
+                        if (mok && v1[q]) *(f32x4*)(c + 4) = x1;
+                    } else {
+                        T* c = (T*)p.C + (size_t)m * p.ldc + nc[q];
+                        if (v1[q]) put(i, q, c, mok, x0, x1);
+                        else if (mok && v0[q]) Elem<T>::st4(c, x0);
                     }
-                    if (mok && n < p.ldc) *(i32x4*)((T*)p.C + (size_t)m * p.ldc + n) = pack8f(x0, x1);
+                }
+            }
+        } else {
+            // rare combinations (accumulating into an fp32 C; a residual with N % 8 != 0): loads inside the loop.  Still fully unrolled:
+            // a run-time index into the accumulator array would move it to scratch memory.
+#pragma unroll
+            for (int i = 0; i < CNT; ++i) {
+                const int m = m_first + 16 * i + t;
+#pragma unroll
+                for (int q = 0; q < G::NP; ++q) {
+                    if (m >= p.M || !v0[q]) continue;
+                    f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
+                    if (p.p_drop > 0.f) {
+                        x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + nc[q], p.p_drop, inv_keep);
+                        x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + nc[q] + 4, p.p_drop, inv_keep);
+                    }
+                    if (p.R) {
+                        const T* rp = (const T*)p.R + (size_t)m * p.ldr + nc[q];
+                        x0 += Elem<T>::ld4(rp);
+                        if (v1[q]) x1 += Elem<T>::ld4(rp + 4);
+                    }
+                    if (p.out_f32) {
+                        float* c = (float*)p.C + (size_t)m * p.ldc + nc[q];
+                        if (p.accumulate) { x0 += *(const f32x4*)c; if (v1[q]) x1 += *(const f32x4*)(c + 4); }
+                        *(f32x4*)c = x0;
+                        if (v1[q]) *(f32x4*)(c + 4) = x1;
+                    } else {
+                        T* c = (T*)p.C + (size_t)m * p.ldc + nc[q];
+                        Elem<T>::st4(c, x0);
+                        if (v1[q]) Elem<T>::st4(c + 4, x1);
+                    }
                 }
             }
         }
-    };
-    const bool general = EPI == DIC_EPI_AFFINE && (p.accumulate || (p.R != nullptr && (!SIDE || (p.N & 7) != 0)));
+    } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {                 // N % 8 == 0 is required for this epilogue
 #pragma unroll
-    for (int pass = 0; pass < G::C_PASSES; ++pass) {
-        if (pass > 0) barrier_lds_only();                                // every wave has read its rows of the previous pass
-        const int wrow0 = wm * (G::BM / G::WM) - pass * G::C_ROWS;       // this wave's first row relative to the parked block
-        if (wrow0 >= 0 && wrow0 < G::C_ROWS) {
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+            const bool mok = m < p.M;
 #pragma unroll
-            for (int i = 0; i < G::FM; ++i)
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
+                if (mok && v1[q]) *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + nc[q]) = pack8f(x0, x1);     // pre-activation u (for GELU')
 #pragma unroll
-                for (int j = 0; j < G::FN; ++j) {
-                    const int row = wrow0 + i * 16 + t, chunk = wn * (G::BN / G::WN / 4) + j * 4 + g;
-                    *(f32x4*)(smem + row * ROWB + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
-                }
+                for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
+                put(i, q, (T*)p.C + (size_t)m * p.ldc + nc[q], mok && v1[q], x0, x1);
+            }
         }
-        if constexpr (EPI == DIC_EPI_AFFINE) {
-            if (general) rows(std::true_type{}, pass); else rows(std::false_type{}, pass);
-        } else {
-            rows(std::false_type{}, pass);
+    } else if constexpr (EPI == DIC_EPI_GELU_BWD) {                  // dU = acc * gelu'(U)
+        i32x4 pre[CNT][G::NP];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                pre[i][q] = i32x4{0, 0, 0, 0};
+                if (m < p.M && v1[q]) pre[i][q] = *(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + nc[q]);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1], u0, u1;
+                unpack8(pre[i][q], u0, u1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
+                put(i, q, (T*)p.C + (size_t)m * p.ldc + nc[q], m < p.M && v1[q], x0, x1);
+            }
+        }
+    } else if constexpr (EPI == DIC_EPI_CE_DLOGITS) {                // (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
+        float r_lse[CNT], r_sc[CNT];
+        long long r_tg[CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+            const bool ok = m < p.M;
+            r_lse[i] = ok ? p.lse[m] : 0.f;
+            r_tg[i] = ok ? p.tgt[m] : -1;
+            r_sc[i] = ok ? row_scale(p, m) : 0.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+            const float lse = r_lse[i], sc = r_sc[i];
+            const long long tg = r_tg[i];
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
+                const int n = nc[q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float q0 = (n + r < p.N) ? __expf(x0[r] - lse) : 0.f, q1 = (n + 4 + r < p.N) ? __expf(x1[r] - lse) : 0.f;
+                    if ((long long)(n + r) == tg) q0 -= 1.0f;
+                    if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
+                    x0[r] = q0 * sc; x1[r] = q1 * sc;
+                }
+                put(i, q, (T*)p.C + (size_t)m * p.ldc + n, m < p.M && n < p.ldc, x0, x1);
+            }
         }
     }
 }
 
-// CE_PARTIAL for the bf16 geometries: every wave owns (BM/WM) rows x (BN/WN) = 64 columns of the tile and emits one
-// (max, sum exp, first argmax) record per row; record slot = bn * WN + wn, so a row has nbn * WN records for ce_combine.
-template <class C>
-__device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[Geo<C>::FM][Geo<C>::FN], const DicGemmParams& p, int m0, int n0, int wm,
+// CE_PARTIAL for the bf16 geometries: every wave owns its rows x 64 columns of the tile and emits one (max, sum exp, first argmax)
+// record per row; record slot = bn * WN + wn, so a row has nbn * WN records for ce_combine.
+template <class C, int CNT>
+__device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first,
                                                     int wn, int lane, int bn, int nbn) {
     using G = Geo<C>;
-    static_assert(G::BN / G::WN == 64 && G::FN == 4, "one 64-column record per wave");
+    static_assert(G::WCOLS == 64 && G::FN == 4, "one 64-column record per wave");
     const int g = lane >> 4, t = lane & 15;
     const int np = G::WN * nbn;
     // all target ids first: a load inside the row loop would wait on vmcnt, which also counts the stores of the rows before it
-    long long tgs[G::FM];
+    long long tgs[CNT];
 #pragma unroll
-    for (int i = 0; i < G::FM; ++i) {
-        const int m = m0 + wm * (G::BM / G::WM) + i * 16 + t;
+    for (int i = 0; i < CNT; ++i) {
+        const int m = m_first + i * 16 + t;
         tgs[i] = (m < p.M && p.tgt) ? p.tgt[m] : -1;
     }
 #pragma unroll
-    for (int i = 0; i < G::FM; ++i) {
-        const int m = m0 + wm * (G::BM / G::WM) + i * 16 + t;
+    for (int i = 0; i < CNT; ++i) {
+        const int m = m_first + i * 16 + t;
         const long long tg = tgs[i];
         float mx = -INFINITY;
         int ix = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)            // (j, r) ascending = column ascending within a lane: the first maximum keeps the lowest index
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + j * 16 + g * 4 + r;
+                const int n = n_first + frag_col(j, g, r);
                 const float x = acc[i][j][r];
                 if (n < p.N) {
                     if (x > mx) { mx = x; ix = n; }
@@ -572,7 +611,7 @@ __device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[Geo<C>::FM][Geo
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + j * 16 + g * 4 + r;
+                const int n = n_first + frag_col(j, g, r);
                 if (n < p.N) sm += __expf(acc[i][j][r] - mx);
             }
 #pragma unroll
@@ -594,18 +633,22 @@ __device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[Geo<C>::FM][Geo
 // no ds_write pass (the register-staged v1 spent ~830 of every ~1340 LDS cycles per K-step on ds_write_b128); the next
 // tile's DMA is in flight while the MFMAs of the current tile run.  The DMA destination is lane-linear (wave base +
 // lane*16), so the bank-conflict-free LDS image is produced by permuting the per-lane SOURCE address and applying the
-// same XOR on the fragment reads (both verified against the bank model of MI355X_MICROARCH.md):
-//   KC tile [rows][128 B]:       16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7); fragment = ONE ds_read_b128
-//                                (8 consecutive k), conflict-free and not mergeable into the half-rate ds_read2 forms
+// same XOR on the fragment reads (scripts/experiments/lds_bank_check.py replays every fragment read against the bank model of
+// MI355X_MICROARCH.md):
+//   KC tile [rows][128 B]:       16-byte chunk c of row r lives at chunk c ^ key(r); fragment = ONE ds_read_b128 (8 consecutive k),
+//                                conflict-free.  A fragments read 16 consecutive rows (key_a); B fragments read the rows of the
+//                                output mapping above, 8 (t>>2) + (t&3) (+ 4q + 32p), which needs a key of its own (key_b).
 //   KM tile [64 k][rows x 2 B]:  chunk c of row k lives at c ^ km_key(k); fragment = two ds_read_b64_tr_b16 on rows
-//                                8g+{0..3} and 8g+4+{0..3}  => lane group g = lane>>4 holds k = 8g..8g+7 in BOTH layouts.
+//                                8g+{0..3} and 8g+4+{0..3}  => lane group g = lane>>4 holds k = 8g..8g+7 in BOTH layouts.  An A
+//                                fragment reads 16 consecutive columns (conflict-free); a B fragment reads the 4-column groups
+//                                8c + 4q of the output mapping: one half of four 16-byte chunks, 2-way (the minimum for that shape).
 // Everything lane-dependent (DMA source offsets, fragment addresses) is computed once per workgroup; the K loop is DMA
-// issues, LDS reads, MFMAs, a few integer adds and one barrier per 64-deep step, unrolled over the two LDS stages so
-// that stage offsets are instruction immediates.
-__device__ __forceinline__ int kc_key(int row) { return (row >> 1) & 7; }
+// issues, LDS reads, MFMAs, a few integer adds and one barrier per 64-deep step.
+__device__ __forceinline__ int key_a(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int key_b(int row) { return ((((row >> 3) & 3) << 1) | ((row >> 1) & 1)) & 7; }
 __device__ __forceinline__ int km_key(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
-template <class C, bool AKM, bool BKM, int EPI>
+template <class C, bool AKM, bool BKM, int EPI, int CNT>
 __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<C>;
@@ -616,22 +659,37 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / G::WN, wn = wave % G::WN;
     const int g = lane >> 4, t = lane & 15;
+    // tile height: CNT 16-row fragments for each of the two wave rows (a per-launch choice, see pick_tile_rows; k-major A always takes BM).
+    // CNT is a template parameter: with a run-time count the K loop needs either a branch between fragment reads and MFMAs or a switch
+    // over unrolled bodies, and the latter made the register allocator spill hundreds of VGPRs.
+    static_assert(CNT >= 1 && CNT <= G::FM && (!AKM || CNT == G::FM), "fragments per wave");
+    constexpr int tile_rows = 32 * CNT, cnt = CNT;
+    const int row0_w = wm * CNT * 16;
 
     // ---- per-lane fragment addresses inside an operand tile for the first 32-deep half-step (same for every tile this
     // workgroup processes); the second half-step is `^ 64` (KC: chunk index bit 2) or `+ 32 rows` (KM: same swizzle key)
-    int ofA[G::FM], ofB[G::FN];
+    // k-contiguous tiles: the swizzle key is the same for every fragment of an operand (A fragments are 16 rows apart, B fragments
+    // 4 / 32 rows), so fragment i is a compile-time byte offset from fragment 0 -- one address register per operand, the rest are
+    // instruction immediates.  k-major tiles XOR the key into the column chunk, which differs per fragment: one register each.
+    int ofA[AKM ? CNT : 1], ofB[BKM ? G::FN : 1];
+    if constexpr (!AKM) { const int row = row0_w + t; ofA[0] = row * 128 + ((g ^ key_a(row)) << 4); }
+    else {
 #pragma unroll
-    for (int i = 0; i < G::FM; ++i) {
-        const int base = wm * (G::BM / G::WM) + i * 16;
-        if (!AKM) { const int row = base + t; ofA[i] = row * 128 + ((g ^ kc_key(row)) << 4); }
-        else { const int rho = 8 * g + (t >> 2), c = (base >> 3) + ((t & 3) >> 1); ofA[i] = rho * ROWB_A + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
+        for (int i = 0; i < CNT; ++i) {
+            const int base = row0_w + i * 16, rho = 8 * g + (t >> 2), c = (base >> 3) + ((t & 3) >> 1);
+            ofA[i] = rho * ROWB_A + ((c ^ km_key(rho)) << 4) + (t & 1) * 8;
+        }
     }
+    if constexpr (!BKM) { const int row = wn * G::WCOLS + 8 * (t >> 2) + (t & 3); ofB[0] = row * 128 + ((g ^ key_b(row)) << 4); }
+    else {
 #pragma unroll
-    for (int j = 0; j < G::FN; ++j) {
-        const int base = wn * (G::BN / G::WN) + j * 16;
-        if (!BKM) { const int row = base + t; ofB[j] = row * 128 + ((g ^ kc_key(row)) << 4); }
-        else { const int rho = 8 * g + (t >> 2), c = (base >> 3) + ((t & 3) >> 1); ofB[j] = rho * ROWB_B + ((c ^ km_key(rho)) << 4) + (t & 1) * 8; }
+        for (int j = 0; j < G::FN; ++j) {           // fragment pair's first column; fragment parity picks the 4-column half
+            const int base = wn * G::WCOLS + 32 * (j >> 1), rho = 8 * g + (t >> 2), c = (base >> 3) + (t & 3);
+            ofB[j] = rho * ROWB_B + ((c ^ km_key(rho)) << 4) + (j & 1) * 8;
+        }
     }
+    auto offA = [&](int i, int kk) { return AKM ? ofA[AKM ? i : 0] + kk * 32 * ROWB_A : (ofA[0] ^ (kk * 64)) + i * (16 * 128); };
+    auto offB = [&](int j, int kk) { return BKM ? ofB[BKM ? j : 0] + kk * 32 * ROWB_B : (ofB[0] ^ (kk * 64)) + (32 * (j >> 1) + 4 * (j & 1)) * 128; };
     // ---- per-lane DMA source offsets of the 1 KiB pieces this wave stages per operand advance by a uniform step.  (Kept in
     // VGPRs rather than the scalar offset operand: the descriptor's bounds check covers only the vector offset, and it is
     // that check which zero-fills ragged M/N/K.)
@@ -658,9 +716,15 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
     };
     // every wave's DMA pieces of the stage being published have landed, and every wave is done reading the stage being recycled
     auto dma_barrier = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // A pieces (8 rows of a k-contiguous tile) are dealt round-robin over the waves so that a short tile still spreads its DMA issue;
+    // pieces beyond the tile height are not issued at all
+    constexpr int n_pieces_a = AKM ? G::BM / 8 : tile_rows >> 3;
+    // per-lane source offsets of the wave's pieces, swizzle term included, advanced by one K-step per issue.  (Recomputing them from one
+    // base per operand saved six registers and cost ~40 VALU instructions at the head of every K-step, in front of the first MFMA of
+    // both waves of a SIMD: 25 % slower on the K = 768 GEMMs.)
     unsigned voA[G::PA], voB[G::PB];
     auto setup = [&](const TileId& tl) {          // descriptors anchored at the tile origin: OOB rows/k read as zero
-        const int m0 = tl.bm * G::BM, n0 = tl.bn * G::BN;
+        const int m0 = tl.bm * tile_rows, n0 = tl.bn * G::BN;
         const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
         const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
         long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
@@ -672,24 +736,23 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         const unsigned ka = (unsigned)tl.kt0 * stepA, kb = (unsigned)tl.kt0 * stepB;
 #pragma unroll
         for (int j = 0; j < G::PA; ++j) {
-            const int q = wave * G::PA + j;
-            if (!AKM) { const int row = 8 * q + (lane >> 3); voA[j] = ka + (unsigned)row * (unsigned)p.lda * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
-            else { constexpr int CPRW = G::BM / 8; const int row = q * (64 / CPRW) + lane / CPRW; voA[j] = ka + (unsigned)row * (unsigned)p.lda * 2u + (((lane % CPRW) ^ km_key(row)) << 4); }
+            if (!AKM) { const int q = j * G::NW + wave, row = 8 * q + (lane >> 3); voA[j] = ka + (unsigned)row * (unsigned)p.lda * 2u + (((lane & 7) ^ key_a(row)) << 4); }
+            else { constexpr int CPRW = G::BM / 8; const int q = wave * G::PA + j, row = q * (64 / CPRW) + lane / CPRW; voA[j] = ka + (unsigned)row * (unsigned)p.lda * 2u + (((lane % CPRW) ^ km_key(row)) << 4); }
         }
 #pragma unroll
         for (int j = 0; j < G::PB; ++j) {
             const int q = wave * G::PB + j;
-            if (!BKM) { const int row = 8 * q + (lane >> 3); voB[j] = kb + (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 7) ^ kc_key(row)) << 4); }
+            if (!BKM) { const int row = 8 * q + (lane >> 3); voB[j] = kb + (unsigned)row * (unsigned)p.ldb * 2u + (((lane & 7) ^ key_b(row)) << 4); }
             else { constexpr int CPRW = G::BN / 8; const int row = q * (64 / CPRW) + lane / CPRW; voB[j] = kb + (unsigned)row * (unsigned)p.ldb * 2u + (((lane % CPRW) ^ km_key(row)) << 4); }
         }
     };
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_PTR(char))smem;
     auto issue = [&](int stage) {
-        const unsigned dstA = __builtin_amdgcn_readfirstlane(lds_base + stage * G::STAGE + wave * (G::PA * 1024));
+        const unsigned dstA = __builtin_amdgcn_readfirstlane(lds_base + stage * G::STAGE + (AKM ? wave * (G::PA * 1024) : wave * 1024));
         const unsigned dstB = __builtin_amdgcn_readfirstlane(lds_base + stage * G::STAGE + G::A_BYTES + wave * (G::PB * 1024));
 #pragma unroll
         for (int j = 0; j < G::PA; ++j) {
-            dma16(voA[j], rsA, dstA + j * 1024);
+            if (AKM || j * G::NW + wave < n_pieces_a) dma16(voA[j], rsA, dstA + j * (AKM ? 1024 : G::NW * 1024));
             voA[j] += stepA;
         }
 #pragma unroll
@@ -705,14 +768,14 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     };
-    f32x4 acc[G::FM][G::FN];
+    f32x4 acc[CNT][G::FN];
     // fused bias gradient (weight-gradient GEMMs only): db[m] = sum_k A[k][m] is a column sum of the A tile that is already
     // in LDS; the workgroups of the first tile column (bn == 0) add it up on the side (4 x ds_read_b128 + 32 adds per thread
     // per K-step) instead of a separate pass that re-reads dY from HBM.
     bool do_cs = false;
     f32x4 cs0{0.f, 0.f, 0.f, 0.f}, cs1{0.f, 0.f, 0.f, 0.f};
     constexpr int CS_CPR = G::BM / 8, CS_GROUPS = G::NTH / CS_CPR;        // 16-byte chunks per A row; thread groups over k
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage, bool more_k) {
         const int sb = stage * G::STAGE;
         const char* la = smem + sb;
         const char* lb = la + G::A_BYTES;
@@ -727,36 +790,128 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
                 }
             }
         }
+#ifndef DIC_GEMM_PLAIN_READS
+        // Fragment reads run DIC_GEMM_PF A fragments ahead of the MFMAs that consume them, with counted waits.  Left to the compiler every A
+        // fragment is `ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs`: a wave alone keeps the matrix pipe below 50 % busy and the K-step ends
+        // with the younger wave of each SIMD finishing on its own (s_memtime stamps: the older wave waits ~25 % of every K-step at the barrier).
+        // Issue order: B(kk=0) x FN, A0, A1, | A2 ... A(CNT-1), B(kk=1) x FN, A(CNT) ... ; LDS returns in order, so before the MFMAs of
+        // A_s everything but the reads issued after A_s may be outstanding.  The reads are inline asm so that neither the order nor the
+        // counts are the compiler's to change (it tracks none of them); every wait names the registers it validates.
+        constexpr int RA = AKM ? 2 : 1, RB = BKM ? 2 : 1, NS = 2 * CNT;
+        constexpr int PFD_MAX = (15 - G::FN * RB) / RA, PFD = DIC_GEMM_PF < PFD_MAX ? DIC_GEMM_PF : PFD_MAX, RING = PFD + 1;      // lgkmcnt counts to 15
+        const unsigned sbA = lds_base + sb, sbB = sbA + G::A_BYTES;
+        unsigned aA[2] = {0, 0}, aB[2] = {0, 0};
+        if constexpr (!AKM) { aA[0] = sbA + (unsigned)ofA[0]; aA[1] = sbA + ((unsigned)ofA[0] ^ 64u); }
+        if constexpr (!BKM) { aB[0] = sbB + (unsigned)ofB[0]; aB[1] = sbB + ((unsigned)ofB[0] ^ 64u); }
+        auto read_frag = [&](bf16x8& dst, bool km, unsigned addr, auto imm_c, auto rowb4_c) {
+            constexpr int imm = decltype(imm_c)::value, hi = decltype(rowb4_c)::value;
+            if (!km) {
+                i32x4 v;
+                asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(v) : "v"(addr), "i"(imm));
+                dst = __builtin_bit_cast(bf16x8, v);
+            } else {
+                s16x4 lo, hi4;
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4" : "=&v"(lo), "=v"(hi4) : "v"(addr), "i"(imm), "i"(imm + hi));
+                dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        };
+        bf16x8 fb[2][G::FN], fa[RING];
+        auto issue_b = [&](auto kk_c) {
+            constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+            for (int j = 0; j < G::FN; ++j) {
+                if constexpr (!BKM) {
+                    auto rd = [&](auto j_c) { constexpr int jj = decltype(j_c)::value;
+                        read_frag(fb[kk][jj], false, aB[kk], std::integral_constant<int, (32 * (jj >> 1) + 4 * (jj & 1)) * 128>{}, std::integral_constant<int, 0>{}); };
+                    if (j == 0) rd(std::integral_constant<int, 0>{});
+                    if (j == 1) rd(std::integral_constant<int, 1>{});
+                    if (j == 2) rd(std::integral_constant<int, 2>{});
+                    if (j == 3) rd(std::integral_constant<int, 3>{});
+                } else {
+                    read_frag(fb[kk][j], true, sbB + (unsigned)ofB[j], std::integral_constant<int, kk * 32 * ROWB_B>{}, std::integral_constant<int, 4 * ROWB_B>{});
+                }
+            }
+        };
+        auto issue_a = [&](auto s_c) {          // A fragment number sidx of the K-step; the B set of the second half-step goes out right before its first A fragment
+            constexpr int sidx = decltype(s_c)::value, kk = sidx / CNT, i = sidx % CNT;
+            if constexpr (sidx == CNT) issue_b(std::integral_constant<int, 1>{});
+            if constexpr (!AKM) read_frag(fa[sidx % RING], false, aA[kk], std::integral_constant<int, i * 2048>{}, std::integral_constant<int, 0>{});
+            else read_frag(fa[sidx % RING], true, sbA + (unsigned)ofA[i], std::integral_constant<int, kk * 32 * ROWB_A>{}, std::integral_constant<int, 4 * ROWB_A>{});
+        };
+        auto step = [&](auto s_c) {
+            constexpr int sidx = decltype(s_c)::value, kk = sidx / CNT, i = sidx % CNT;
+            if constexpr (sidx + PFD < NS) issue_a(std::integral_constant<int, sidx + PFD>{});
+            // reads issued after A_s: A_{s+1} .. A_{s+PFD} and, when it lies among them, the B set of the second half-step
+            constexpr int last = (sidx + PFD < NS - 1) ? sidx + PFD : NS - 1;
+            constexpr int after = (last - sidx) * RA + ((sidx < CNT && last >= CNT) ? G::FN * RB : 0);
+            static_assert(after <= 15, "lgkmcnt is a 4-bit counter");
+            if constexpr (i == 0) {
+                asm volatile("s_waitcnt lgkmcnt(%c5)" : "+v"(fa[sidx % RING]), "+v"(fb[kk][0]), "+v"(fb[kk][1]), "+v"(fb[kk][2]), "+v"(fb[kk][3]) : "i"(after));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fa[sidx % RING]) : "i"(after));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < G::FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[sidx % RING], acc[i][j], 0, 0, 0);
+            // Where in the K-step the next stage's DMA is issued (DIC_GEMM_ISSUE_AT).  With operands resident in L2 / the infinity cache, issuing
+            // behind the first few MFMA groups is 2-5 % faster (at the head of the K-step the ~8 x 60-180 issue cycles per wave sit in front of
+            // the first MFMA of both waves of a SIMD); with operands coming from HBM -- the training step: every operand was just written by
+            // another kernel or is streamed once -- the K-step is bound by the DMA's arrival and issuing FIRST wins by 5-10 % (weight
+            // gradients: +10 % slower when issued after fragment 3).  Default: first.  Also measured: staggering the two waves of a SIMD (one
+            // half issuing in the first half-step, the other in the second) 5-8 % slower; static s_setprio for the younger half: noise.
+            if constexpr (DIC_GEMM_ISSUE_AT >= 0 && sidx == (DIC_GEMM_ISSUE_AT < NS ? DIC_GEMM_ISSUE_AT : NS - 1)) { if (more_k) issue(stage ^ 1); }
+        };
+        static_assert(G::FN == 4, "issue_b / the first wait of a half-step name four B fragments");
+        if constexpr (DIC_GEMM_ISSUE_AT < 0) { if (more_k) issue(stage ^ 1); }
+        issue_b(std::integral_constant<int, 0>{});
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (issue_a(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, (PFD < NS ? PFD : NS)>{});
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (step(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, NS>{});
+#else
+        if (more_k) issue(stage ^ 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fb[G::FN];
 #pragma unroll
-            for (int j = 0; j < G::FN; ++j) fb[j] = frag(lb, BKM ? ofB[j] + kk * 32 * ROWB_B : ofB[j] ^ (kk * 64), BKM, ROWB_B);
+            for (int j = 0; j < G::FN; ++j) fb[j] = frag(lb, offB(j, kk), BKM, ROWB_B);
 #pragma unroll
-            for (int ih = 0; ih < G::FM; ih += 4) {          // A fragments four at a time: bounded register footprint at FM = 8
+            for (int ih = 0; ih < CNT; ih += 4) {            // A fragments four at a time: bounded register footprint at 8 fragments
                 bf16x8 fa[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag(la, AKM ? ofA[ih + i] + kk * 32 * ROWB_A : ofA[ih + i] ^ (kk * 64), AKM, ROWB_A);
+                for (int i = 0; i < 4; ++i)
+                    if (ih + i < CNT) fa[i] = frag(la, offA(ih + i, kk), AKM, ROWB_A);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
+                    if (ih + i < CNT) {
 #pragma unroll
-                    for (int j = 0; j < G::FN; ++j)
-                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih + i][j], 0, 0, 0);
+                        for (int j = 0; j < G::FN; ++j)
+                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih + i][j], 0, 0, 0);
+                    }
             }
         }
+#endif
     };
 
     // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
     // addressing set-up is paid once per workgroup and the tail of the launch is balanced by unit order, not dispatch order.
-    const int total = total_units(p, G::BM, G::BN);
+    const int total = total_units(p, tile_rows, G::BN);
     int unit = blockIdx.x;
-    TileId tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
+#ifdef DIC_GEMM_TRACE      // measurement build only (scripts/experiments/gemm_trace.py): s_memtime stamps of wave 0 at the phase boundaries of every tile
+    unsigned long long* trace = (unsigned long long*)p.tgt_logit + (size_t)blockIdx.x * 64;
+    int trace_n = 0;
+#define DIC_STAMP() do { if (trace && tid == 0 && trace_n < 64) trace[trace_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DIC_STAMP() do { } while (0)
+#endif
+    DIC_STAMP();
+    TileId tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
-    dma_barrier();
     for (;;) {
+        dma_barrier();                       // the tile's first K-step has landed (and the previous tile's output stores have drained)
+        DIC_STAMP();
 #pragma unroll
-        for (int i = 0; i < G::FM; ++i)
+        for (int i = 0; i < CNT; ++i)
 #pragma unroll
             for (int j = 0; j < G::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
@@ -766,46 +921,63 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         const int nk = tl.kt1;
         int cur = 0;
         // (A software-pipelined variant -- barrier before the last MFMA group, first fragments of the next stage prefetched across it,
-        // DMA re-armed 1.75 K-steps ahead -- was measured: +2-5 % on isolated GEMMs, -2 % on the training step; not kept.)
+        // DMA re-armed 1.75 K-steps ahead -- was measured in round 1: +2-5 % on isolated GEMMs, -2 % on the training step; not kept.)
         for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
-            if (kt + 1 < nk) issue(cur ^ 1);           //  register allocator keep two copies of the accumulator tile)
-            compute(cur);                              // next K-step's DMA flies under this step's MFMAs
+            compute(cur, kt + 1 < nk);                 //  register allocator keep two copies of the accumulator tile); issues the next K-step's DMA
+#ifdef DIC_GEMM_TRACE
+            if (p.partial && (kt - tl.kt0) < 16 && unit == (int)blockIdx.x && (wave == 0 || wave == G::NW - 1)) {
+                unsigned long long* kst = (unsigned long long*)p.partial + (((size_t)blockIdx.x * 2 + (wave != 0)) * 16 + (kt - tl.kt0)) * 4;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                if (lane == 0) { kst[0] = t0; kst[1] = t1; kst[2] = t2; }
+            } else
+#endif
             dma_barrier();
             cur ^= 1;
         }
+        DIC_STAMP();
+        // Both LDS stages are free now.  The next tile's first K-step goes out BEFORE this tile is written: its latency hides under the
+        // epilogue, which touches no LDS (except the bias-gradient fold of the weight-gradient GEMMs, which uses the second stage).
+        const TileId done = tl;
+        unit += gridDim.x;
+        const bool more = unit < total;
+        if (more) {
+            tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+            setup(tl);
+            if (tl.kt0 < tl.kt1) issue(0);
+        }
         DicGemmParams pe = p;
-        if (p.split_k > 1) redirect_to_slab(pe, tl.kz);
+        if (p.split_k > 1) redirect_to_slab(pe, done.kz);
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
-            if (do_cs) {       // fold the thread groups through LDS (free after the K loop's last barrier), fixed order
-                float* red = (float*)smem;
+            if (do_cs) {       // fold the thread groups through LDS, fixed order
+                float* red = (float*)(smem + G::STAGE);
                 *(f32x4*)(red + (tid / CS_CPR) * G::BM + (tid % CS_CPR) * 8) = cs0;
                 *(f32x4*)(red + (tid / CS_CPR) * G::BM + (tid % CS_CPR) * 8 + 4) = cs1;
-                __syncthreads();
+                barrier_lds_only();
                 if (tid < G::BM) {
                     float v = 0.f;
 #pragma unroll
                     for (int gq = 0; gq < CS_GROUPS; ++gq) v += red[gq * G::BM + tid];
-                    const int m = tl.bm * G::BM + tid;
+                    const int m = done.bm * G::BM + tid;
                     if (m < p.M) {
                         if (p.split_k > 1) ((float*)pe.C)[(size_t)p.M * p.ldc + m] = v;
                         else p.colsum_out[m] = p.accumulate ? p.colsum_out[m] + v : v;
                     }
                 }
-                __syncthreads();
+                barrier_lds_only();
             }
         }
+        const int m_first = done.bm * tile_rows + row0_w, n_first = done.bn * G::BN + wn * G::WCOLS;
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
-            epilogue_ce_partial<C>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tl.bn, tl.nbn);
+            epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn);
         } else {
-            epilogue_lds<C, EPI, !AKM>(acc, pe, tl.bm * G::BM, tl.bn * G::BN, wm, wn, lane, tid, smem);
+            epilogue_direct<C, EPI, !AKM, CNT>(acc, pe, m_first, n_first, lane);
         }
-        unit += gridDim.x;
-        if (unit >= total) break;
-        tl = tile_of_unit(p, BK, unit, G::BM, G::BN);
-        setup(tl);
-        barrier_lds_only();              // every wave is done with the LDS-staged output tile; its stores drain under the next DMA
-        if (tl.kt0 < tl.kt1) issue(0);
-        dma_barrier();
+        DIC_STAMP();
+        if (!more) break;
     }
 }
 
@@ -854,20 +1026,80 @@ bool persist_enabled() {
     return v == 1;
 }
 
+bool rows_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DIC_GEMM_ROWS"); v = (e && e[0] == '0') ? 0 : 1; }       // 0: always full-height tiles (A/B measurements)
+    return v == 1;
+}
+
+// Tile height for a k-contiguous A (the token dimension of the forward / input-gradient GEMMs).  With full-height tiles the tile count
+// rarely fills whole rounds of resident workgroups (17 408 tokens x 768 columns = 204 tiles of 256x256 on 256 CUs: one round at 80 %;
+// x 2304: 612 = 2.39 rounds run as 3), and a persistent grid cannot rebalance inside a round.  Tiles may be any multiple of 32 rows
+// (one 16-row fragment for each of the two wave rows) from BM/2 to BM, so the launch takes the height that minimises
+// rounds x (K-loop time of one tile + per-tile fixed cost): 224 rows at 17 408 tokens (234 / 702 / 936 tiles = 1 / 3 / 4 rounds at 91 %).
+int pick_tile_rows(int M, int nbn_split, int slots, int BM, int K) {
+    const int CMAX = BM / 32, CMIN = CMAX / 2;          // fragments per wave
+    if (!rows_enabled()) return BM;
+    if (M <= BM) { int c = (M + 31) / 32; return 32 * (c < CMIN ? CMIN : c); }
+    double fixed = 2.0 * 768.0 / (K > 0 ? K : 768);      // prologue + epilogue + one B tile, in units of one fragment pair's K loop (K = 768: ~1/4 tile)
+    fixed = fixed < 0.25 ? 0.25 : (fixed > 3.0 ? 3.0 : fixed);
+    double best = 1e30;
+    int best_c = CMAX;
+    for (int R = 1; R <= 4096; ++R) {
+        const long long nbm = (long long)R * slots / nbn_split;
+        if (nbm < 1) continue;
+        int c = (int)((((long long)M + nbm - 1) / nbm + 31) / 32);
+        if (c > CMAX) continue;
+        const bool last = c <= CMIN;
+        if (last) c = CMIN;
+        const long long tiles = ((long long)M + 32 * c - 1) / (32 * c) * nbn_split;
+        const double cost = (double)((tiles + slots - 1) / slots) * (c + fixed);
+        if (cost < best - 1e-9) { best = cost; best_c = c; }
+        if (last) break;
+    }
+    return 32 * best_c;
+}
+
+template <class C, bool AKM, bool BKM, int E, int CNT>
+void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
+    using G = Geo<C>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {           // per device: one process may drive several GPUs
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AKM, BKM, E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<C, AKM, BKM, E, CNT>), dim3(grid), dim3(G::NTH), G::LDS, st, q);
+}
+
 template <class C, bool AKM, bool BKM, int E>
 void launch_bf16(const DicGemmParams& q, hipStream_t st) {
     using G = Geo<C>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr_set = true;
-    }
-    const int units = ((q.N + G::BN - 1) / G::BN) * ((q.M + G::BM - 1) / G::BM) * (q.split_k > 1 ? q.split_k : 1);
     int cus = device_cus();
     if (q.cu_cap > 0 && q.cu_cap < cus) cus = q.cu_cap;             // spatial share of the chip (two streams interleaving two half-batches)
     const int resident = cus * (160 * 1024 / G::LDS);                // co-resident workgroups (LDS-limited): 2 per CU at 64 KB, 1 at 128 KB
+    const int nbn_split = ((q.N + G::BN - 1) / G::BN) * (q.split_k > 1 ? q.split_k : 1);
+    const int rows = AKM ? G::BM : pick_tile_rows(q.M, nbn_split, resident, G::BM, q.K);
+    const int units = nbn_split * ((q.M + rows - 1) / rows);
     const int grid = ((persist_enabled() || q.cu_cap > 0) && units > resident) ? resident : units;
-    hipLaunchKernelGGL((gemm_bf16_kernel<C, AKM, BKM, E>), dim3(grid), dim3(G::NTH), G::LDS, st, q);
+    if constexpr (AKM) {
+        launch_bf16_cnt<C, AKM, BKM, E, G::FM>(q, st, grid);
+    } else if constexpr (G::FM == 8) {
+        switch (rows / 32) {
+            case 8: launch_bf16_cnt<C, AKM, BKM, E, 8>(q, st, grid); break;
+            case 7: launch_bf16_cnt<C, AKM, BKM, E, 7>(q, st, grid); break;
+            case 6: launch_bf16_cnt<C, AKM, BKM, E, 6>(q, st, grid); break;
+            case 5: launch_bf16_cnt<C, AKM, BKM, E, 5>(q, st, grid); break;
+            default: launch_bf16_cnt<C, AKM, BKM, E, 4>(q, st, grid); break;
+        }
+    } else {
+        switch (rows / 32) {
+            case 4: launch_bf16_cnt<C, AKM, BKM, E, 4>(q, st, grid); break;
+            case 3: launch_bf16_cnt<C, AKM, BKM, E, 3>(q, st, grid); break;
+            default: launch_bf16_cnt<C, AKM, BKM, E, 2>(q, st, grid); break;
+        }
+    }
 }
 
 template <typename T, bool AKM, bool BKM, int E>
@@ -880,10 +1112,12 @@ void launch_one(hipStream_t st, const DicGemmParams& q) {
         }
     }
     constexpr size_t lds = 4 * TILE_BYTES;   // 72 KB: two stages x (A tile + B tile) -> 2 workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<T, AKM, BKM, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int nbn = (q.N + BN - 1) / BN, nbm = (q.M + BM - 1) / BM;
     hipLaunchKernelGGL((gemm_kernel<T, AKM, BKM, E>), dim3(nbm * nbn * (q.split_k > 1 ? q.split_k : 1)), dim3(NT), lds, st, q);
@@ -892,13 +1126,20 @@ void launch_one(hipStream_t st, const DicGemmParams& q) {
 template <typename T, bool AKM, bool BKM>
 int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
     const int split = p.split_k > 1 ? p.split_k : 1;
+    // built combinations: every epilogue for (k-contiguous, k-contiguous) = nn.Linear forward and the rounding head; the affine and GELU
+    // epilogues for a k-major B (input gradients); the affine one for (k-major, k-major) = weight gradients.  Nothing on the path
+    // asks for the others.
+    if (epi < DIC_EPI_AFFINE || epi > DIC_EPI_CE_DLOGITS) { dic_set_error("dic_gemm: unknown epilogue"); return 1002; }
+    if ((AKM && epi != DIC_EPI_AFFINE) || (BKM && (epi == DIC_EPI_CE_PARTIAL || epi == DIC_EPI_CE_DLOGITS))) {
+        dic_set_error("dic_gemm: this epilogue is not built for this operand layout (weight gradients: AFFINE only; k-major B: no rounding-head epilogues)");
+        return 1005;
+    }
     switch (epi) {
         case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(st, p); break;
-        case DIC_EPI_BIAS_GELU: launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(st, p); break;
-        case DIC_EPI_GELU_BWD: launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(st, p); break;
-        case DIC_EPI_CE_PARTIAL: launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(st, p); break;
-        case DIC_EPI_CE_DLOGITS: launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(st, p); break;
-        default: dic_set_error("dic_gemm: unknown epilogue"); return 1002;
+        case DIC_EPI_BIAS_GELU: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(st, p); break;
+        case DIC_EPI_GELU_BWD: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(st, p); break;
+        case DIC_EPI_CE_PARTIAL: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(st, p); break;
+        case DIC_EPI_CE_DLOGITS: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(st, p); break;
     }
     if (split > 1) {
         const long long n4 = (long long)p.M * p.ldc / 4, n4cs = p.colsum_out ? p.M / 4 : 0;

@@ -174,7 +174,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     if x_t.data_ptr() != xin.data_ptr():                  # (train_func lets q_sample write into the workspace directly)
         xin[:Nt].copy_(x_t)
     if x_1.data_ptr() != xin[Nt + Ng:].data_ptr():
-        xin[Nt + Ng:].copy_(x_1)
+        xin[Nt + Ng:N].copy_(x_1)
     img = image_clip.to(dev, torch.float32)
     txt = text_clip.to(dev, torch.float32)
     img_rep, txt_rep = img.repeat(S, 1), txt.repeat(S, 1)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dic = importlib.import_module("diffusion-image-captioning_amd")
 L = dic.lib()
 GP = dic._lib.GemmParams
-T, D, F, V = 18432, 768, 3072, 30592
+T, D, F, V = int(os.environ.get("TOKENS", "17408")), 768, 3072, 30592
 bf = torch.bfloat16
 
 
