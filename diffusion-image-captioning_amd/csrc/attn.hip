@@ -11,6 +11,7 @@
 //     only V (fwd) / K,Q,dO (bwd) are staged through LDS because they are consumed k-major.
 //   * backward recomputes P from Q,K (cheaper than storing 12x18x18 probabilities per sequence), runs the score / dP
 //     tiles in both orientations (query-major for dQ, key-major for dK,dV) and never leaves registers in between.
+//   * 33..64 tokens (seq_len 32 + CLIP rows): the same scheme on a 2 x 2 grid of 32-token tiles (attn_*_bf16_t64).
 // f32 path: exact-fp32 VALU kernel (one wave per (sequence, head), LDS-resident Q,K,V): the parity path.
 #include "common.h"
 #include "../../include/dic_hip.h"
@@ -314,6 +315,264 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16, 33..64 tokens (seq_len 32 + CLIP rows)
+// The same scheme on a 2 x 2 grid of 32-token tiles: ONE wave per (sequence, head), scores transposed so that a lane owns one query and
+// its keys are registers (two accumulator tiles = 32 keys per half-wave), softmax in registers + one __shfl_xor(32), P never stored,
+// P.V through ds_read_b64_tr_b16 fragments of the LDS-staged V.  Queries are processed one 32-token tile at a time; K fragments stay in
+// registers across both, Q (and in the backward dO) tiles are re-read per use (8 KB per operand per head: L1/L2 hits).
+// Dropout index: ((pair * 64 + query) * 32 + key/2) -- 32 bits up to 2^21 (sequence, head) pairs.
+__device__ __forceinline__ unsigned attn_drop_hash64(unsigned mix, unsigned pair, int q, int key) {
+    return hash32((((pair << 6) + (unsigned)q) << 5) + (unsigned)(key >> 1) ^ mix);
+}
+__device__ __forceinline__ RowFrags load_rows_at(const bf16_t* X, int ld, int row0, int Tk, int lane) {   // rows row0 .. row0+31 of X, zero beyond Tk
+    const int r = row0 + (lane & 31), hi = lane >> 5;
+    RowFrags o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o.f[s] = ld_frag_global(X + (size_t)r * ld + 16 * s + 8 * hi, r < Tk);
+    return o;
+}
+__device__ __forceinline__ void store_rows_at(char* tile, const RowFrags& x, int row0, int Tk, int lane) {   // rows <= Tk (row Tk = the zero row)
+    const int r = row0 + (lane & 31), hi = lane >> 5;
+    if (r <= Tk && r < 64) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *(i32x4*)(tile + r * VSTRIDE + 32 * s + 16 * hi) = __builtin_bit_cast(i32x4, x.f[s]);
+    }
+}
+// one 32-token output tile (rows row0 ..) through a wave-private LDS tile, as stage_out / store_out
+__device__ __forceinline__ void put_out(char* tile, const f32x16& o0, const f32x16& o1, bf16_t* dst, int ld, int row0, int Tk, int lane) {
+    __builtin_amdgcn_s_waitcnt(0);            // the previous contents of `tile` have been read (wave-private: program order + this wait)
+    __builtin_amdgcn_wave_barrier();
+    stage_out(tile, o0, o1, lane, Tk - row0 < 32 ? Tk - row0 : 32);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    store_out(tile, dst + (size_t)row0 * ld, ld, Tk - row0 < 32 ? Tk - row0 : 32, lane);
+}
+
+__global__ __launch_bounds__(128) void attn_fwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* ctx, int N, int Tk, int H,
+                                                         float scale, float p_drop, unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 2 + wave;
+    if (pair >= N * H) return;
+    const int n = pair / H, h = pair - n * H;
+    const int ld = 3 * H * DH, Dm = H * DH;
+    const bf16_t* Q = qkv + (size_t)n * Tk * ld + h * DH;
+    const bf16_t* K = Q + Dm;
+    const bf16_t* V = Q + 2 * Dm;
+    char* vt = smem + wave * (3 * TILE);          // [64][VSTRIDE] V tile + one 32-row output tile
+    char* ot = vt + 2 * TILE;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j, row = c >> 3, ch = c & 7;
+        *(i32x4*)(vt + row * VSTRIDE + ch * 16) = row < Tk ? *(const i32x4*)(V + (size_t)row * ld + ch * 8) : i32x4{0, 0, 0, 0};
+    }
+    const int ql = lane & 31, hi = lane >> 5;
+    const unsigned long long mbits = __ballot(lane < Tk && key_mask[(size_t)n * Tk + (lane < Tk ? lane : 0)] != 0);
+    const RowFrags fk0 = load_rows_at(K, ld, 0, Tk, lane), fk1 = load_rows_at(K, ld, 32, Tk, lane);
+    const float inv_keep = drop_inv_keep(p_drop);
+    const unsigned thr = drop_thr(p_drop), mix = attn_seed_mix(seed);
+    const int nqt = Tk > 32 ? 2 : 1;
+    for (int qt = 0; qt < nqt; ++qt) {
+        const RowFrags fq = load_rows_at(Q, ld, 32 * qt, Tk, lane);
+        f32x16 st[2] = {rowdot_reg(fk0, fq), rowdot_reg(fk1, fq)};       // S^T[key][query]: lane = query, register r of tile kt = key 32 kt + reg_tok(r, hi)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = (mbits >> (32 * kt + reg_tok(r, hi))) & 1ull;
+                st[kt][r] = ok ? st[kt][r] * scale : -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kt][r] = (mx == -INFINITY) ? 0.f : __expf(st[kt][r] - mx); sum += st[kt][r]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                st[kt][r] *= inv; st[kt][r + 1] *= inv;
+                if (p_drop > 0.f) {
+                    const unsigned hsh = attn_drop_hash64(mix, (unsigned)pair, 32 * qt + ql, 32 * kt + reg_tok(r, hi));
+                    st[kt][r] = (hsh & 0xffffu) >= thr ? st[kt][r] * inv_keep : 0.f;
+                    st[kt][r + 1] = (hsh >> 16) >= thr ? st[kt][r + 1] * inv_keep : 0.f;
+                }
+            }
+        __builtin_amdgcn_s_waitcnt(0);   // V tile stores by this wave are complete (wave-private LDS region, no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {                                 // O^T[d][query] = sum_key V[key][d] P[query][key], 4 steps of 16 keys
+            o[db] = zero16();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vt, s, db, lane), pack8(st[s >> 1], s & 1), o[db], 0, 0, 0);
+        }
+        put_out(ot, o[0], o[1], ctx + (size_t)n * Tk * Dm + h * DH, Dm, 32 * qt, Tk, lane);
+    }
+}
+
+// Backward, 33..64 tokens.  K, Q, dO are staged in LDS (Tk + 1 rows, the last one zero: the redirect target of token rows >= Tk) for the
+// k-major products; the score-shaped products take row fragments from HBM/L2.  Pass 1 per query tile (lane = query): P, delta, dS -> dQ.
+// Pass 2 per key tile (lane = key), accumulating over the query tiles: Pd -> dV, dS -> dK.
+__device__ __forceinline__ bf16x8 tr_frag_clamped64(const char* lds, int s, int db, int lane, int zero_row) {
+    const int hi = lane >> 5, half = (lane >> 4) & 1, t = lane & 15;
+    const int r0 = min(16 * s + 4 * hi + (t >> 2), zero_row), r1 = min(16 * s + 8 + 4 * hi + (t >> 2), zero_row);
+    const int col = (db * 32 + half * 16 + 4 * (t & 3)) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + r0 * VSTRIDE + col));
+    s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(lds + r1 * VSTRIDE + col));
+    s16x8 v = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
+                                                         int H, float scale, float p_drop, unsigned long long seed, int tile_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x;       // one wave per workgroup: LDS (27 KB at 34 tokens) is what bounds residency, five of these fit a CU
+    if (pair >= N * H) return;
+    const int n = pair / H, h = pair - n * H;
+    const int ld = 3 * H * DH, Dm = H * DH;
+    const bf16_t* Q = qkv + (size_t)n * Tk * ld + h * DH;
+    const bf16_t* K = Q + Dm;
+    const bf16_t* V = Q + 2 * Dm;
+    const bf16_t* dO = dctx + (size_t)n * Tk * Dm + h * DH;
+    bf16_t* dQ = dqkv + (size_t)n * Tk * ld + h * DH;
+    bf16_t* dK = dQ + Dm;
+    bf16_t* dV = dQ + 2 * Dm;
+    char* base = smem;
+    char* kt_ = base;
+    char* qt_ = base + tile_bytes;
+    char* dot = base + 2 * tile_bytes;
+    char* vt_ = base + 3 * tile_bytes;
+    char* ot = base + 4 * tile_bytes;                      // one 32-row output tile
+    float* stats = (float*)(base + 4 * tile_bytes + TILE);  // [0..63] row max, [64..127] 1/rowsum, [128..191] delta
+    const int zero_row = Tk < 64 ? Tk : 63;
+    const int c = lane & 31, hi = lane >> 5;
+    const float inv_keep = drop_inv_keep(p_drop);
+    const unsigned thr = drop_thr(p_drop), mix = attn_seed_mix(seed);
+    const unsigned long long mbits = __ballot(lane < Tk && key_mask[(size_t)n * Tk + (lane < Tk ? lane : 0)] != 0);
+    const int nt = Tk > 32 ? 2 : 1;
+    {   // stage K, Q, dO, V (rows 0 .. Tk, row Tk zero): the only HBM reads of the kernel, all in flight together.  Every later operand --
+        // row fragments for the score-shaped products, transpose-read fragments for the k-major ones -- comes from these tiles (a first
+        // version re-read row fragments from HBM/L2 in every phase: ~26 dependent load phases per head, 1.3 TB/s).
+        const RowFrags a0 = load_rows_at(K, ld, 0, Tk, lane), a1 = load_rows_at(K, ld, 32, Tk, lane), b0 = load_rows_at(Q, ld, 0, Tk, lane),
+                       b1 = load_rows_at(Q, ld, 32, Tk, lane), c0 = load_rows_at(dO, Dm, 0, Tk, lane), c1 = load_rows_at(dO, Dm, 32, Tk, lane),
+                       d0 = load_rows_at(V, ld, 0, Tk, lane), d1 = load_rows_at(V, ld, 32, Tk, lane);
+        store_rows_at(kt_, a0, 0, Tk, lane); store_rows_at(kt_, a1, 32, Tk, lane);
+        store_rows_at(qt_, b0, 0, Tk, lane); store_rows_at(qt_, b1, 32, Tk, lane);
+        store_rows_at(dot, c0, 0, Tk, lane); store_rows_at(dot, c1, 32, Tk, lane);
+        store_rows_at(vt_, d0, 0, Tk, lane); store_rows_at(vt_, d1, 32, Tk, lane);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto rows_lds = [&](const char* tile, int row0) {       // row fragments of rows row0 .. row0+31 (rows >= Tk: the zero row)
+        const int r = min(row0 + (lane & 31), zero_row);
+        RowFrags o;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) o.f[s2] = __builtin_bit_cast(bf16x8, *(const i32x4*)(tile + r * VSTRIDE + 32 * s2 + 16 * hi));
+        return o;
+    };
+    // ---- pass 1 (query-major), one query tile at a time
+    {
+        const RowFrags fk0 = rows_lds(kt_, 0), fk1 = rows_lds(kt_, 32);
+        const RowFrags fv0 = rows_lds(vt_, 0), fv1 = rows_lds(vt_, 32);
+        for (int qt = 0; qt < nt; ++qt) {
+            const RowFrags fq = rows_lds(qt_, 32 * qt), fo = rows_lds(dot, 32 * qt);
+            f32x16 st[2] = {rowdot_reg(fk0, fq), rowdot_reg(fk1, fq)};
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = (mbits >> (32 * kt + reg_tok(r, hi))) & 1ull;
+                    st[kt][r] = ok ? st[kt][r] * scale : -INFINITY;
+                    mx = fmaxf(mx, st[kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[kt][r] = (mx == -INFINITY) ? 0.f : __expf(st[kt][r] - mx); sum += st[kt][r]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+            f32x16 dpt[2] = {rowdot_reg(fv0, fo), rowdot_reg(fv1, fo)};                 // dPd^T[key][query]
+            float delta = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    st[kt][r] *= inv; st[kt][r + 1] *= inv;                             // P
+                    if (p_drop > 0.f) {
+                        const unsigned hsh = attn_drop_hash64(mix, (unsigned)pair, 32 * qt + c, 32 * kt + reg_tok(r, hi));
+                        dpt[kt][r] = (hsh & 0xffffu) >= thr ? dpt[kt][r] * inv_keep : 0.f;
+                        dpt[kt][r + 1] = (hsh >> 16) >= thr ? dpt[kt][r + 1] * inv_keep : 0.f;
+                    }
+                    delta += dpt[kt][r] * st[kt][r] + dpt[kt][r + 1] * st[kt][r + 1];
+                }
+            delta += __shfl_xor(delta, 32, 64);
+            if (hi == 0) { stats[32 * qt + c] = mx; stats[64 + 32 * qt + c] = inv; stats[128 + 32 * qt + c] = delta; }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] = st[kt][r] * (dpt[kt][r] - delta) * scale;      // dS[query][key]
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            f32x16 o[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {                                            // dQ^T[d][query] = sum_key K[key][d] dS[query][key]
+                o[db] = zero16();
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(kt_, s, db, lane, zero_row), pack8(st[s >> 1], s & 1), o[db], 0, 0, 0);
+            }
+            put_out(ot, o[0], o[1], dQ, ld, 32 * qt, Tk, lane);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 2 (key-major), one key tile at a time, accumulating over the query tiles
+    for (int kt = 0; kt < nt; ++kt) {
+        const RowFrags fk = rows_lds(kt_, 32 * kt), fv = rows_lds(vt_, 32 * kt);
+        const int key = 32 * kt + c;
+        const bool kok = (mbits >> key) & 1ull;
+        f32x16 ov[2] = {zero16(), zero16()}, ok_[2] = {zero16(), zero16()};
+        for (int qt = 0; qt < nt; ++qt) {
+            const RowFrags fq = rows_lds(qt_, 32 * qt), fo = rows_lds(dot, 32 * qt);
+            f32x16 s2 = rowdot_reg(fq, fk);                                             // S[query(reg)][key(lane)]
+            f32x16 dp2 = rowdot_reg(fo, fv);                                            // dPd[query][key]
+            f32x16 pd, ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = 32 * qt + reg_tok(r, hi);
+                const float m_ = stats[qi], inv = stats[64 + qi], delta = stats[128 + qi];
+                float pr = (kok && m_ > -INFINITY) ? __expf(s2[r] * scale - m_) * inv : 0.f;
+                float dpr = dp2[r], pdr = pr;
+                if (p_drop > 0.f) {
+                    const unsigned hsh = attn_drop_hash64(mix, (unsigned)pair, qi, key);
+                    dpr = attn_drop(dpr, hsh, key, thr, inv_keep);
+                    pdr = attn_drop(pr, hsh, key, thr, inv_keep);
+                }
+                pd[r] = pdr;
+                ds[r] = pr * (dpr - delta) * scale;
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {       // queries 32 qt + 16 s ..: dV^T[d][key] += dO[q][d] Pd[q][key];  dK^T[d][key] += Q[q][d] dS[q][key]
+                    ov[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(dot, 2 * qt + s, db, lane, zero_row), pack8(pd, s), ov[db], 0, 0, 0);
+                    ok_[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(qt_, 2 * qt + s, db, lane, zero_row), pack8(ds, s), ok_[db], 0, 0, 0);
+                }
+        }
+        put_out(ot, ov[0], ov[1], dV, ld, 32 * kt, Tk, lane);
+        put_out(ot, ok_[0], ok_[1], dK, ld, 32 * kt, Tk, lane);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ f32 VALU path
 constexpr int TMAX = 64, PADW = 65;
 template <typename T>
@@ -439,9 +698,11 @@ extern "C" int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask,
     hipStream_t st = (hipStream_t)stream;
     DIC_REQUIRE(Tk <= TMAX, "dic_attn: at most 64 tokens per sequence");
     DIC_REQUIRE((long long)N * H < (1ll << 23), "dic_attn: at most 2^23 (sequence, head) pairs per launch (32-bit dropout index)");
-    if (dtype == DIC_BF16 && Tk > 32) {      // beyond one 32x32 MFMA tile (seq_len 32 + CLIP rows): exact-fp32-math kernel on bf16 I/O
-        size_t lds = (size_t)(3 * Tk * PADW + Tk * (Tk + 1)) * sizeof(float);
-        hipLaunchKernelGGL(attn_fwd_f32<bf16_t>, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+    if (dtype == DIC_BF16 && Tk > 32) {      // seq_len 32 + CLIP rows: the 2 x 2-tile MFMA kernel, two (sequence, head) pairs per workgroup
+        DIC_REQUIRE((long long)N * H < (1ll << 21), "dic_attn: at most 2^21 (sequence, head) pairs per launch beyond 32 tokens (32-bit dropout index)");
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_t64, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * TILE); attr = true; }
+        hipLaunchKernelGGL(attn_fwd_bf16_t64, dim3((N * H + 1) / 2), dim3(128), 2 * 3 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
     } else if (dtype == DIC_BF16) {
         hipLaunchKernelGGL(attn_fwd_bf16, dim3((N * H + 3) / 4), dim3(256), 4 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
     } else {
@@ -460,10 +721,11 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
     DIC_REQUIRE(Tk <= TMAX, "dic_attn: at most 64 tokens per sequence");
     DIC_REQUIRE((long long)N * H < (1ll << 23), "dic_attn: at most 2^23 (sequence, head) pairs per launch (32-bit dropout index)");
     if (dtype == DIC_BF16 && Tk > 32) {
-        size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)attn_bwd_f32<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * TMAX * PADW + 2 * TMAX * (TMAX + 1))); attr2 = true; }
-        hipLaunchKernelGGL(attn_bwd_f32<bf16_t>, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        DIC_REQUIRE((long long)N * H < (1ll << 21), "dic_attn: at most 2^21 (sequence, head) pairs per launch beyond 32 tokens (32-bit dropout index)");
+        const int rows = Tk < 64 ? ((Tk + 1 + 3) & ~3) : 64;          // valid rows + one zero row
+        const int tile_bytes = rows * VSTRIDE;
+        const size_t lds = (size_t)(4 * tile_bytes + TILE + 768);
+        hipLaunchKernelGGL(attn_bwd_bf16_t64, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
     } else if (dtype == DIC_BF16) {
         const int rows = Tk < 32 ? ((Tk + 1 + 3) & ~3) : 32;          // valid rows + one zero row
         const int tile_bytes = rows * VSTRIDE;

@@ -428,8 +428,10 @@ def test_fuse_ln_fwd_bwd(L, dtype, mode):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("dtype,Tk", [(F32, 18), (F32, 34), (F32, 16), (BF16, 18), (BF16, 17), (BF16, 16), (BF16, 32), (BF16, 34)])
+@pytest.mark.parametrize("dtype,Tk", [(F32, 18), (F32, 34), (F32, 16), (BF16, 18), (BF16, 17), (BF16, 16), (BF16, 32), (BF16, 33), (BF16, 34),
+                                      (BF16, 47), (BF16, 63), (BF16, 64)])
 def test_attention_fwd_bwd(L, dtype, Tk):
+    """bf16: one 32-token MFMA tile up to 32 tokens, the 2 x 2-tile MFMA kernel for 33..64 (seq_len 32 + CLIP rows = 34); fp32: VALU kernel."""
     N, H, D = 3, 12, 768
     g = torch.Generator().manual_seed(Tk + dtype)
     qkv = torch.randn(N, Tk, 3 * D, generator=g)
@@ -455,9 +457,9 @@ def test_attention_fwd_bwd(L, dtype, Tk):
         assert e < (2e-5 if dtype == F32 else 3e-2), f"{name} relerr {e}"
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16])
-def test_attention_dropout_mask_is_shared_by_forward_and_backward(L, dtype):
-    N, H, D, Tk, pd, seed = 2, 12, 768, 18, 0.3, 777
+@pytest.mark.parametrize("dtype,Tk", [(F32, 18), (BF16, 18), (BF16, 34), (BF16, 64)])
+def test_attention_dropout_mask_is_shared_by_forward_and_backward(L, dtype, Tk):
+    N, H, D, pd, seed = 2, 12, 768, 0.3, 777
     g = torch.Generator().manual_seed(4)
     qkv = torch.randn(N, Tk, 3 * D, generator=g)
     # V = identity block per head -> ctx[i][d=j] = P_dropped[i][j]
