@@ -24,7 +24,7 @@ EXPORTS = [
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
-    "dic_te_dx0", "dic_embed_scatter",
+    "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad",
 ]
 
 
@@ -100,10 +100,11 @@ def lib():
         L.dic_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmParams), C.c_void_p]
         P, I, F, U64, I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
         L.dic_ce_combine.argtypes = [P, P, I, I, P, P, P, P]
-        L.dic_embed_gather.argtypes = [P, P, P, I, I, I, P]
+        L.dic_embed_gather.argtypes = [P, P, P, I, I, I, P, P]
         L.dic_qsample.argtypes = [P, P, P, P, P, P, P, I, I, I, I, U64, P]
-        L.dic_fuse_ln_fwd.argtypes = [I, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, P]
-        L.dic_fuse_ln_bwd.argtypes = [I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64, P]
+        L.dic_fuse_ln_fwd.argtypes = [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, P]
+        L.dic_fuse_ln_bwd.argtypes = [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64, P]
+        L.dic_temb_grad.argtypes = [P, P, I, I, I, I, P, P]
         L.dic_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]
         L.dic_ln_bwd.argtypes = [I, P, P, P, P, P, P, P, F, U64, P, I, I, I, P]
         L.dic_gelu_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]

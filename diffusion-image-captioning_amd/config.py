@@ -42,6 +42,9 @@ class Config:
     VOCAB_SIZE: int = 30522
     # build-side switch (not a reference constant): skip the provably-unused text row when no sequence is guided
     DROP_UNUSED_TEXT_ROW: bool = True
+    # build-side switch: learned timestep embedding added before the embeddings LayerNorm (BASELINE north_star names it; the reference's
+    # denoiser is not time-conditioned, ref :271, so the parity value is False)
+    TIMESTEP_EMBEDDING: bool = False
 
     def update(self, **kw):
         for k, v in kw.items():

@@ -19,20 +19,26 @@ static inline int grid_for(long long work_items, int per_block, int cap = 4096) 
 
 // ------------------------------------------------------------------------------------------------ K1 embedding gather
 // ref CLIP-DDPM.py:459  x_0 = model.embedding(ids).  One wave per token row, 16 B per lane.
-__global__ void embed_gather_kernel(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V) {
+// nn.Embedding raises on an id outside [0, V); a kernel cannot raise, so it REPORTS: the row is zero-filled and `err` (optional, two
+// ints the caller zeroed: device memory or device-visible pinned host memory) gets err[0] += 1 and err[1] = max(err[1], position + 1).
+// The caller turns a non-zero err[0] into its IndexError at its next synchronisation point.  Nothing is clamped.
+__global__ void embed_gather_kernel(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, int* err) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n_tokens; row += gridDim.x * wpb) {
-        long long id = ids[row];
-        if (id < 0) id = 0;
-        if (id >= V) id = V - 1;
-        const f32x4* src = (const f32x4*)(E + (size_t)id * D);
+        const long long id = ids[row];
+        const bool bad = id < 0 || id >= V;
+        if (bad && err && lane == 0) {
+            __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_max(err + 1, row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const f32x4* src = (const f32x4*)(E + (size_t)(bad ? 0 : id) * D);
         f32x4* dst = (f32x4*)(out + (size_t)row * D);
-        for (int c = lane; c < D / 4; c += 64) dst[c] = src[c];
+        for (int c = lane; c < D / 4; c += 64) dst[c] = bad ? f32x4{0.f, 0.f, 0.f, 0.f} : src[c];
     }
 }
-extern "C" int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, void* stream) {
+extern "C" int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, int* err, void* stream) {
     DIC_REQUIRE(D % 4 == 0 && n_tokens > 0, "dic_embed_gather: D must be a multiple of 4");
-    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, ids, E, out, n_tokens, D, V);
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for(n_tokens, 4)), dim3(256), 0, (hipStream_t)stream, ids, E, out, n_tokens, D, V, err);
     DIC_CHECK_LAUNCH();
     return 0;
 }

@@ -60,10 +60,23 @@ constexpr int LNB_WAVES = 8;
 // mode 2 concat without the text row (Tk = L+1): when no row of the batch is classifier-free-guided the text row is masked
 //        as a key for every query and its own outputs are never read (ref :297, :323, :418), so it can be left out of the
 //        sequence without changing any loss or any gradient (text_linear's gradient is exactly zero either way).
+// Optional timestep embedding (BASELINE north_star names the operand; the reference has none -- its forward takes no t, ref :271 -- so it
+// is off, temb == NULL, in every parity configuration): row temb[tidx[n]] of a learned [steps][D] table is added to every token row of
+// sequence n before the LayerNorm (tidx[n] < 0: none for that sequence).
 __device__ __forceinline__ void fused_row(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                                          const float* seg, const float* pos, int n, int t, int L, int lane, f32x4 (&v)[NCH]) {
+                                          const float* seg, const float* pos, const float* temb, const int* tidx, int n, int t, int L, int lane,
+                                          f32x4 (&v)[NCH]) {
     f32x4 p[NCH];
     load_row<float>(pos + (size_t)t * D, lane, p);
+    if (temb) {
+        const int ts = tidx[n];
+        if (ts >= 0) {
+            f32x4 e[NCH];
+            load_row<float>(temb + (size_t)ts * D, lane, e);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) p[c] = p[c] + e[c];
+        }
+    }
     if (mode != 1) {
         const float* src = t < L ? x + ((size_t)n * L + t) * D : (t == L ? img + (size_t)n * D : txt + (size_t)n * D);
         f32x4 s[NCH];
@@ -89,7 +102,8 @@ __device__ __forceinline__ void fused_row(int mode, const float* x, const float*
 
 template <typename T>
 __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                                                           const float* seg, const float* pos, const float* gamma, const float* beta, T* h,
+                                                           const float* seg, const float* pos, const float* temb, const int* tidx,
+                                                           const float* gamma, const float* beta, T* h,
                                                            float* mean, float* rstd, int N, int L, int Tk, float eps, float p_drop,
                                                            unsigned long long seed) {
     const int lane = threadIdx.x & 63;
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float*
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH];
-        fused_row(mode, x, img, txt, add_txt, seg, pos, n, t, L, lane, v);
+        fused_row(mode, x, img, txt, add_txt, seg, pos, temb, tidx, n, t, L, lane, v);
         float mu, rs;
         row_stats(v, eps, mu, rs);
 #pragma unroll
@@ -117,7 +131,8 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float*
 
 template <typename T>
 __global__ __launch_bounds__(64 * LNB_WAVES) void fuse_ln_bwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                                                           const float* seg, const float* pos, const float* gamma, const T* dh,
+                                                           const float* seg, const float* pos, const float* temb, const int* tidx,
+                                                           const float* gamma, const T* dh,
                                                            const float* mean, const float* rstd, float* dy, float* partial, int N, int L, int Tk,
                                                            float p_drop, unsigned long long seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void fuse_ln_bwd_kernel(int mode, c
     for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH], d[NCH];
-        fused_row(mode, x, img, txt, add_txt, seg, pos, n, t, L, lane, v);
+        fused_row(mode, x, img, txt, add_txt, seg, pos, temb, tidx, n, t, L, lane, v);
         load_row<T>(dh + (size_t)row * D, lane, d);
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
@@ -305,30 +320,50 @@ inline int rows_grid(int rows, int cap) { int g = (rows + 3) / 4; return g < 1 ?
 #define DISPATCH_T(dtype, CALL_BF, CALL_F32) do { if ((dtype) == DIC_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
 
 extern "C" int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                               const float* seg, const float* pos, const float* gamma, const float* beta, void* h, float* mean,
-                               float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
+                               const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
+                               void* h, float* mean, float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
+    DIC_REQUIRE(temb == nullptr || tidx != nullptr, "dic_fuse_ln_fwd: a timestep-embedding table needs the per-sequence indices");
     DIC_REQUIRE(Dd == D, "dic_fuse_ln_fwd: D must be 768");
     const int Tk = mode == 0 ? L + 2 : (mode == 2 ? L + 1 : L);
     dim3 grid(rows_grid(N * Tk, 2048)), block(256);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed),
-               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed));
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed),
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed));
     DIC_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                               const float* seg, const float* pos, const float* gamma, const void* dh, const float* mean,
-                               const float* rstd, float* dy, float* partial, int n_partial_blocks, int N, int L, int Dd, float p_drop,
-                               uint64_t seed, void* stream) {
+                               const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const void* dh,
+                               const float* mean, const float* rstd, float* dy, float* partial, int n_partial_blocks, int N, int L, int Dd,
+                               float p_drop, uint64_t seed, void* stream) {
     DIC_REQUIRE(Dd == D && n_partial_blocks > 0, "dic_fuse_ln_bwd: D must be 768");
     const int Tk = mode == 0 ? L + 2 : (mode == 2 ? L + 1 : L);
     dim3 grid(n_partial_blocks), block(64 * LNB_WAVES);
     const size_t lds = LNB_WAVES * 2 * D * sizeof(float);            // 48 KB
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(fuse_ln_bwd_kernel<bf16_t>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, gamma, (const bf16_t*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed),
-               hipLaunchKernelGGL(fuse_ln_bwd_kernel<float>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, gamma, (const float*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed));
+               hipLaunchKernelGGL(fuse_ln_bwd_kernel<bf16_t>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, (const bf16_t*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed),
+               hipLaunchKernelGGL(fuse_ln_bwd_kernel<float>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, (const float*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+// d temb[s] = sum over the sequences n with tidx[n] == s, and over their Tk token rows, of dy (the gradient wrt the pre-LayerNorm rows that
+// dic_fuse_ln_bwd wrote).  One block per (timestep, 256-column chunk), sequences visited in index order: deterministic, no atomics; a step
+// uses at most S + 1 distinct timesteps, every other block finds no match and writes zeros.
+__global__ __launch_bounds__(64) void temb_grad_kernel(const float* dy, const int* tidx, int N, int Tk, float* dtemb) {
+    const int ts = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x * 4;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        if (tidx[n] != ts) continue;
+        const float* src = dy + (size_t)n * Tk * D + col;
+        for (int t = 0; t < Tk; ++t) acc += *(const f32x4*)(src + (size_t)t * D);
+    }
+    *(f32x4*)(dtemb + (size_t)ts * D + col) = acc;
+}
+extern "C" int dic_temb_grad(const float* dy, const int32_t* tidx, int N, int Tk, int Dd, int steps, float* dtemb, void* stream) {
+    DIC_REQUIRE(Dd == D && steps > 0 && N > 0, "dic_temb_grad: D must be 768");
+    hipLaunchKernelGGL(temb_grad_kernel, dim3(steps, D / 256), dim3(64), 0, (hipStream_t)stream, dy, tidx, N, Tk, dtemb);
     DIC_CHECK_LAUNCH();
     return 0;
 }

@@ -196,7 +196,13 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         add_txt[Nt:Nt + Ng] = 1
     else:
         ic, tc, km = torch.cat([img_rep, img]), torch.cat([txt_rep, txt]), torch.cat([plain_t, plain_b])
-    x_out = model.encode(xin[:N], ic, tc, km, add_txt, drop_txt=drop_txt, cap=cap)
+    tidx = None
+    if model.temb:          # optional timestep embedding: row s*B+b carries t[s], a guided copy its source row's, the x_1 rows t = 1
+        tv = getattr(model, "_step_t", None)
+        assert tv is not None and tv.numel() == S, "cfg.TIMESTEP_EMBEDDING needs the step's t-vector (train_func passes it)"
+        tt = tv.reshape(S, 1).to(dev, torch.int32).repeat(1, B).reshape(Nt)
+        tidx = torch.cat([tt] + ([tt[gi]] if Ng else []) + [torch.ones(B, dtype=torch.int32, device=dev)])
+    x_out = model.encode(xin[:N], ic, tc, km, add_txt, drop_txt=drop_txt, cap=cap, tidx=tidx)
     st = model.ops.stream
     row = Tk * 768
     if Ng:
@@ -372,6 +378,7 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
         t_next = torch.max(t - cfg.X_T_STEP_INTERVAL, torch.zeros_like(t))
         x_t, x_tgt = generate_diffuse_pair(x_0, t, t_next, noises=(nz.pop(0), nz.pop(0)))
     x_1 = diffuse_t(x_0, torch.ones(1, dtype=torch.int64, device=dev), noise=nz.pop(0), out=out_1)
+    model._step_t = t
     if train:
         trainer.zero_grad()
         if not isinstance(trainer, AdamW):

@@ -126,6 +126,9 @@ class Denoiser:
         # TRAIN_EMBEDDING ablation (ref :98-102, 238-243): learned 16-d embedding / head + projections, see train_embedding.py
         self.te = bool(cfg.TRAIN_EMBEDDING)
         te_kw = dict(train_embedding_vocab=int(cfg.VOCAB_SIZE), in_channel=int(cfg.IN_CHANNEL)) if self.te else {}
+        self.temb = bool(cfg.TIMESTEP_EMBEDDING)
+        if self.temb:
+            te_kw["timestep_embedding"] = int(cfg.STEP_TOT)
         self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16, **te_kw)
         self.params.init_like_reference(seed)
         if self.te:
@@ -145,6 +148,7 @@ class Denoiser:
         self._saved = None
         self._pending = False
         self._side = None
+        self._id_err = None
         self.wgrad_stream_enabled = True
         self.rank_rows_forced = True     # CFG forces rows 0/1 to unguided/guided (ref :408-409); DP: rank 0 only
 
@@ -214,14 +218,31 @@ class Denoiser:
     def to(self, *a, **k):
         return self
 
+    def check_ids(self, sync=False):
+        """Raise IndexError if an embedding() call met a token id outside [0, vocab) (nn.Embedding's behaviour; the kernel zero-fills the
+        row and reports through a device-visible pinned word).  Without `sync` this looks at what has reached the host so far --
+        embedding() calls it before every lookup, so a bad batch surfaces at the next step at the latest; sync=True waits for the stream."""
+        if self._id_err is None:
+            return
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        n = int(self._id_err[0])
+        if n:
+            pos = int(self._id_err[1]) - 1
+            self._id_err.zero_()
+            raise IndexError(f"embedding: {n} token id(s) outside [0, {self.vocab}) (last at flat position {pos})")
+
     def embedding(self, ids):
         """ref :459 -- nn.Embedding lookup -> fp32 [..., IN_CHANNEL] (frozen 768-d table, or the learned 16-d one)."""
+        if self._id_err is None:
+            self._id_err = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.check_ids()
         ids = ids.to(self.device, torch.int64).contiguous()
         d = self.params.in_channel if self.te else 768
         table = self.params.slot_view(self.params.P, "E16") if self.te else self.E
         out = torch.empty(*ids.shape, d, dtype=torch.float32, device=self.device)
         self.ops.begin()
-        _lib.check(self.ops.L.dic_embed_gather(_p(ids), _p(table), _p(out), ids.numel(), d, self.vocab, self.ops.stream), "embed")
+        _lib.check(self.ops.L.dic_embed_gather(_p(ids), _p(table), _p(out), ids.numel(), d, self.vocab, self._id_err.data_ptr(), self.ops.stream), "embed")
         return out
 
     def lm_head(self, h):
@@ -265,6 +286,7 @@ class Denoiser:
         ws["xin"] = f(N, L, D)
         ws["kmask"] = torch.empty(N, Tk, dtype=torch.uint8, device=dev)
         ws["addtxt"] = torch.zeros(N, dtype=torch.uint8, device=dev)
+        ws["tidx"] = torch.full((N,), -1, dtype=torch.int32, device=dev) if self.temb else None
         ws["h"] = [e(T, D) for _ in range(self.n_layers + 1)]
         ws["mean0"], ws["rstd0"] = f(T), f(T)
         ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=e(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
@@ -305,7 +327,7 @@ class Denoiser:
         return ws
 
     # ------------------------------------------------------------------ encoder forward (hf:92-118, 150-259, 501-513)
-    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None):
+    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None, tidx=None):
         """x [N,L,768] fp32; image_clip/text_clip [N,512]; key_mask [N,Tk] uint8 -> x_out [N,Tk,768] fp32.
         Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training.
         drop_txt (concat fusion, no guided row in the batch): run with Tk = L+1, leaving the never-read text row out."""
@@ -331,6 +353,12 @@ class Denoiser:
                 ws["addtxt"][:N].copy_(add_txt)
             else:
                 ws["addtxt"][:N].zero_()               # a reused workspace must not keep an earlier batch's guided-row flags
+        if self.temb:                                  # per-sequence timestep for the optional timestep embedding (None: no injection)
+            if tidx is not None:
+                ws["tidx"][:N].copy_(tidx.reshape(N))
+            else:
+                ws["tidx"][:N].fill_(-1)
+        temb_p, tidx_p = (P.ptr("temb"), _p(ws["tidx"])) if self.temb else (0, 0)
         mode = ws["mode"]
         # K3: CLIP projections, exact fp32 MFMA (tiny)
         o.gemm(_p(ws["img_in"]), P.ptr("Wimg"), _p(ws["img_p"]), N, D, 512, 512, 512, D, bias=P.ptr("bimg"), out_f32=1, dtype=DIC_F32)
@@ -338,7 +366,7 @@ class Denoiser:
             o.gemm(_p(ws["txt_in"]), P.ptr("Wtxt"), _p(ws["txt_p"]), N, D, 512, 512, 512, D, bias=P.ptr("btxt"), out_f32=1, dtype=DIC_F32)
         # K4: concat/add fusion + segment + position + LayerNorm (+ dropout)
         _lib.check(lib.dic_fuse_ln_fwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
-                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), P.ptr("eln_b"),
+                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
                                        _p(ws["h"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
         for i in range(self.n_layers):
             Lw, h = ws["layers"][i], ws["h"][i]
@@ -504,9 +532,12 @@ class Denoiser:
         # embeddings LayerNorm + fusion backward (touches none of the side stream's buffers: runs under layer 0's weight gradients)
         mode = ws["mode"]
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
-                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
+                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("temb") if self.temb else 0,
+                                       _p(ws["tidx"]) if self.temb else 0, P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
                                        _p(ws["dy0"]), parts[4], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
         dy0 = _p(ws["dy0"])
+        if self.temb:
+            _lib.check(lib.dic_temb_grad(dy0, _p(ws["tidx"]), N, Tk, D, P.temb_steps, P.ptr("temb", "G"), st), "temb_grad")
         small_rows = N <= 1024                   # dic_colsum's single-launch path needs no workspace (the two-stage path shares `csw`)
 
         def embedding_grads():                   # feed only G: under the CLIP-projection GEMMs below, on the side stream

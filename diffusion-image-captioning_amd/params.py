@@ -24,7 +24,7 @@ ALIGN = 64  # floats (256 B)
 class ParamStore:
     def __init__(self, n_layers: int, device, concat: bool = True, dim: int = 768, hidden: int = 3072,
                  max_pos: int = 512, clip_dim: int = 512, bf16_shadow: bool = True, train_embedding_vocab: int | None = None,
-                 in_channel: int = 16):
+                 in_channel: int = 16, timestep_embedding: int | None = None):
         self.n_layers, self.dim, self.hidden, self.concat = n_layers, dim, hidden, concat
         self.te_vocab, self.in_channel = train_embedding_vocab, in_channel
         self.device = torch.device(device)
@@ -50,6 +50,9 @@ class ParamStore:
         add("Wtxt", (dim, clip_dim)); add("btxt", (dim,))
         if concat:
             add("seg", (2, dim))
+        self.temb_steps = timestep_embedding
+        if timestep_embedding:
+            add("temb", (int(timestep_embedding), dim))       # optional timestep embedding (cfg.TIMESTEP_EMBEDDING), absent from the reference
         if train_embedding_vocab is not None:
             # TRAIN_EMBEDDING ablation (ref :238-243): learned token embedding / rounding head in a 16-d space and the two
             # projections to and from the encoder width.  The head is stored with its rows padded to a tile multiple
@@ -69,6 +72,8 @@ class ParamStore:
         self.names = [n for n, _, _, _ in synth.denoiser_param_specs(n_layers, **te)]
         if not concat:
             self.names = [n for n in self.names if n != "segment_embedding.weight"]
+        if timestep_embedding:
+            self.names = self.names + ["timestep_embedding.weight"]
         self._views = {n: self._view(self.P, n) for n in self.names}
         self._gviews = {n: self._view(self.G, n) for n in self.names}
         for n in self.names:
@@ -96,6 +101,7 @@ class ParamStore:
             "model.vocab_transform.bias": "bvt", "model.vocab_layer_norm.weight": "vln_g",
             "model.vocab_layer_norm.bias": "vln_b", "image_linear.weight": "Wimg", "image_linear.bias": "bimg",
             "text_linear.weight": "Wtxt", "text_linear.bias": "btxt", "segment_embedding.weight": "seg",
+            "timestep_embedding.weight": "temb",
         }
         if ref_name in simple:
             return self.slot_view(buf, simple[ref_name])
@@ -145,6 +151,8 @@ class ParamStore:
     def load_state(self, state: dict):
         """`state`: reference-named tensors/arrays (e.g. synth.denoiser_state or a checkpoint)."""
         for n in self.names:
+            if n == "timestep_embedding.weight" and n not in state:
+                continue                                    # a reference-shaped state has none: keep the current table
             v = state[n]
             v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
             self._views[n].copy_(v.to(self.device, torch.float32))

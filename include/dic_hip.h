@@ -97,7 +97,9 @@ int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_pa
                    float* lse, int64_t* argmax, float* nll, void* stream);
 
 /* ---------------------------------------------------------------- embedding + q_sample (ref:459, 347-362) */
-int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, void* stream);
+/* out[i] = E[ids[i]].  An id outside [0, V) (where nn.Embedding raises) zero-fills its row and is REPORTED through `err` (optional;
+ * two ints zeroed by the caller, device memory or device-visible pinned host memory): err[0] += 1, err[1] = max(err[1], i + 1).      */
+int dic_embed_gather(const int64_t* ids, const float* E, float* out, int n_tokens, int D, int V, int* err, void* stream);
 /* out[(s*B+b)*LD + i] = sqrt_ac[t[s]]*x0[b*LD+i] + eps[b*LD+i]*sqrt_1mac[t[s]] (un-fused mul/mul/add: bit-exact with
  * ref:360-362); sqrt_ac = sqrt(alpha_cumprod), sqrt_1mac = sqrt(1-alpha_cumprod), tables of length step_tot;
  * eps = `noise` when non-NULL, else N(0,1) from Philox4x32-10 keyed by (seed, b*LD+i) -- ONE draw per element shared
@@ -110,17 +112,23 @@ int dic_qsample(const float* x0, const float* noise, const int64_t* t, const flo
  * mode 1 "add":    row t = x[n][t] + img[n] (+ txt[n] when add_txt[n]) + pos[t]; LayerNorm.   Tk = L+2 / L.
  * mode 2 "concat, text row dropped" (Tk = L+1): legal when no sequence is guided -- the text row is then masked as a key
  *        and its outputs are unused, so losses and gradients are unchanged.
+ * Optional timestep embedding (named by BASELINE.json's north_star; the reference's forward takes no t, ref:271, so every parity
+ * configuration passes temb = NULL): temb [steps][D] f32, tidx [N] int32 -- row temb[tidx[n]] is added to every token row of sequence n
+ * before the LayerNorm (tidx[n] < 0: none).
  * Writes h [N][Tk][D] (dtype T, dropout p applied) and mean/rstd [N*Tk].                                          */
 int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                    const float* seg, const float* pos, const float* gamma, const float* beta,
+                    const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
                     void* h, float* mean, float* rstd, int N, int L, int D, float eps,
                     float p_drop, uint64_t seed, void* stream);
 /* Backward: dh (T) -> dy [N][Tk][D] f32 (gradient wrt the pre-LN fused rows) and per-block partial sums of
  * dgamma/dbeta in `partial` [nblocks][2*D] (reduce with dic_colsum).                                              */
 int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                    const float* seg, const float* pos, const float* gamma,
+                    const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma,
                     const void* dh, const float* mean, const float* rstd, float* dy, float* partial, int n_partial_blocks,
                     int N, int L, int D, float p_drop, uint64_t seed, void* stream);
+/* Gradient of the timestep-embedding table: dtemb[s] = sum of dy over every token row of the sequences with tidx[n] == s (all `steps`
+ * rows of dtemb are written, zeros where no sequence carries that timestep).                                        */
+int dic_temb_grad(const float* dy, const int32_t* tidx, int N, int Tk, int D, int steps, float* dtemb, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (hf:236,239,253,257; eps 1e-12) */
 int dic_ln_fwd(int dtype, const void* y, const float* gamma, const float* beta, void* h, float* mean, float* rstd,

@@ -296,13 +296,39 @@ def test_rounding_ce_partial_combine_and_backward(L, dtype, V, tile):
 
 
 # ------------------------------------------------------------------------------------------------ embedding + q_sample
+def test_embed_gather_reports_out_of_range_ids(L):
+    """nn.Embedding raises for ids outside [0, V); the kernel reports them (count + last position) and zero-fills the row -- no clamping."""
+    V = 500
+    E = torch.randn(V, 768, generator=torch.Generator().manual_seed(1))
+    ids = torch.tensor([[3, V, 7, -1], [V - 1, 0, 12345, 9]])
+    out = torch.full((2, 4, 768), float("nan"), device="cuda")
+    err = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ok(L.dic_embed_gather(p(dev(ids)), p(dev(E)), p(out), 8, 768, V, p(err), stream()), L)
+    torch.cuda.synchronize()
+    assert err.tolist() == [3, 7]                                 # three bad ids, the last one at flat position 6
+    good = (ids >= 0) & (ids < V)
+    assert torch.equal(out.cpu()[good], E[ids[good]]) and bool((out.cpu()[~good] == 0).all())
+    # through the drop-in: model.embedding() surfaces it as IndexError (at the next lookup, or at once with check_ids(sync=True))
+    dic.cfg.update(VOCAB_SIZE=V, TRAIN_EMBEDDING=False, IN_CHANNEL=768)
+    model = dic.DistilBertModel(E.numpy(), E.numpy(), config=dict(n_layers=1, dropout=0.0, attention_dropout=0.0), dtype="fp32")
+    model.embedding(ids.clamp(0, V - 1))
+    model.check_ids(sync=True)                                    # clean batch: nothing raised
+    model.embedding(ids)
+    with pytest.raises(IndexError):
+        model.check_ids(sync=True)
+    model.embedding(ids)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        model.embedding(ids.clamp(0, V - 1))                      # the next lookup reports the previous batch
+
+
 def test_embed_gather_and_qsample_bit_exact(L):
     V, B, Lq, S = 500, 3, 16, 5
     g = torch.Generator().manual_seed(3)
     E = torch.randn(V, 768, generator=g)
     ids = torch.randint(0, V, (B, Lq), generator=g)
     out = torch.zeros(B, Lq, 768, device="cuda")
-    ok(L.dic_embed_gather(p(dev(ids)), p(dev(E)), p(out), B * Lq, 768, V, stream()), L)
+    ok(L.dic_embed_gather(p(dev(ids)), p(dev(E)), p(out), B * Lq, 768, V, 0, stream()), L)
     assert torch.equal(out.cpu(), E[ids])
     for cosine, T in ((True, 1000), (False, 100)):
         cfg = R.Config(COSIN_SCHEDULE=cosine, STEP_TOT=T)
@@ -393,7 +419,9 @@ def test_gelu_ln_fwd_bwd(L, dtype):
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_fuse_ln_fwd_bwd(L, dtype, mode):
+@pytest.mark.parametrize("with_temb", [False, True])
+def test_fuse_ln_fwd_bwd(L, dtype, mode, with_temb):
+    """with_temb: the optional timestep-embedding operand (off = NULL = the reference's arithmetic, ref :271 takes no t)."""
     N, Lq = 5, 16
     Tk = Lq + 2 if mode == 0 else Lq
     g = torch.Generator().manual_seed(11 + mode)
@@ -403,18 +431,25 @@ def test_fuse_ln_fwd_bwd(L, dtype, mode):
     gamma, beta = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
     add_txt = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8)
     dh = torch.randn(N, Tk, 768, generator=g)
-    leaves = [t.double().requires_grad_(True) for t in (img, txt, seg, pos, gamma, beta)]
-    im, tx, sg, ps, gm, bt = leaves
+    steps = 7
+    temb = 0.5 * torch.randn(steps, 768, generator=g)
+    tidx = torch.tensor([3, -1, 3, 0, 6], dtype=torch.int32)            # sequence 1 carries none; timestep 3 occurs twice
+    leaves = [t.double().requires_grad_(True) for t in (img, txt, seg, pos, gamma, beta, temb)]
+    im, tx, sg, ps, gm, bt, te = leaves
     if mode == 0:
         rows = torch.cat([x.double(), im[:, None], tx[:, None]], 1) + sg[torch.tensor([0] * Lq + [1] * 2)]
     else:
         rows = x.double() + im[:, None] + tx[:, None] * add_txt.double()[:, None, None]
     rows = rows + ps[:Tk]
+    if with_temb:
+        rows = rows + (te[tidx.clamp(min=0).long()] * (tidx >= 0).double()[:, None])[:, None, :]
     rows.retain_grad()
     ref = R.layer_norm(rows, gm, bt)
     h = torch.zeros(N, Tk, 768, dtype=DT[dtype], device="cuda")
     mean, rstd = torch.zeros(N * Tk, device="cuda"), torch.zeros(N * Tk, device="cuda")
-    args = (p(dev(x)), p(dev(img)), p(dev(txt)), p(dev(add_txt)), p(dev(seg)), p(dev(pos)), p(dev(gamma)))
+    tidx_d = dev(tidx)
+    args = (p(dev(x)), p(dev(img)), p(dev(txt)), p(dev(add_txt)), p(dev(seg)), p(dev(pos)), p(dev(temb)) if with_temb else 0,
+            p(tidx_d) if with_temb else 0, p(dev(gamma)))
     ok(L.dic_fuse_ln_fwd(dtype, mode, *args, p(dev(beta)), p(h), p(mean), p(rstd), N, Lq, 768, 1e-12, 0.0, 0, stream()), L)
     assert relerr(h.float(), ref) < (3e-6 if dtype == F32 else 8e-3)
     dhd = dev(dh, DT[dtype])
@@ -425,6 +460,10 @@ def test_fuse_ln_fwd_bwd(L, dtype, mode):
     s = _colsum(L, part, 2 * 768)
     assert relerr(dy, rows.grad) < 1e-5
     assert relerr(s[:768], gm.grad) < 1e-5 and relerr(s[768:], bt.grad) < 1e-5
+    if with_temb:
+        dte = torch.full((steps, 768), float("nan"), device="cuda")
+        ok(L.dic_temb_grad(p(dy), p(tidx_d), N, Tk, 768, steps, p(dte), stream()), L)
+        assert relerr(dte, te.grad) < 1e-5 and bool((dte[[1, 2, 4, 5]] == 0).all())
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -263,3 +263,33 @@ def test_data_parallel_gradients_equal_full_batch_gloo_world2():
     assert abs(l_dp - float(l)) < 1e-4 * abs(float(l))
     err = float((g_dp - store.G).abs().max() / store.G.abs().max())
     assert err < 1e-5, err
+
+
+# ------------------------------------------------------------------ the PRODUCT's schedule tables (ref :337-346)
+def test_product_alpha_cumprod_tables_match_the_reference_host():
+    """diffusion.alpha_cumprod_table() itself (not the oracle's, not an injected table) against the tables the reference produced
+    (tests/golden: cosine T=1000 and linear T=100).  torch.cos is not correctly rounded on every CPU, so the cosine table may differ
+    from another host's by an ulp -- no more; the linear one is exact.  The sqrt tables q_sample uses must be the correctly rounded
+    square roots of whatever table is in force."""
+    diffusion = importlib.import_module("diffusion-image-captioning_amd.diffusion")
+    saved = {k: getattr(dic.cfg, k) for k in ("COSIN_SCHEDULE", "STEP_TOT", "BETA_MIN", "BETA_MAX")}
+    try:
+        for name, cosine, T in (("base_b4s3l16", True, 1000), ("deep6_b2s2l16", False, 100)):
+            z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+            dic.cfg.update(COSIN_SCHEDULE=cosine, STEP_TOT=T, BETA_MIN=0.0001, BETA_MAX=0.02)
+            diffusion.set_alpha_cumprod(None)
+            ac = diffusion.alpha_cumprod_table("cpu").numpy()
+            ref = z["alpha_cumprod"]
+            assert ac.dtype == np.float32 and ac.shape == ref.shape == (T,)
+            ulp = np.abs(ac.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+            assert ulp.max() <= (1 if cosine else 0), f"{name}: alpha_cumprod differs by {ulp.max()} ulp"
+            assert ac[0] == 1.0
+            np.testing.assert_array_equal(diffusion._state["sqrt_ac"].numpy(), np.sqrt(ac.astype(np.float64)).astype(np.float32))
+            np.testing.assert_array_equal(diffusion._state["sqrt_1mac"].numpy(), np.sqrt((1 - ac).astype(np.float64)).astype(np.float32))
+            # and with the reference host's table injected (what the golden tests do) the coefficient tables follow it exactly
+            diffusion.set_alpha_cumprod(torch.from_numpy(ref))
+            diffusion.alpha_cumprod_table("cpu")
+            np.testing.assert_array_equal(diffusion._state["sqrt_ac"].numpy(), np.sqrt(ref.astype(np.float64)).astype(np.float32))
+    finally:
+        dic.cfg.update(**saved)
+        diffusion.set_alpha_cumprod(None)

@@ -81,6 +81,30 @@ def test_eval_forward_and_losses(name):
     np.testing.assert_allclose(got, z["eval_losses"], rtol=2e-6)
 
 
+def test_reference_default_shape_eval():
+    """The reference's own default shape (ref :57-114: B=8, S=100 -> 808 sequences, 6 layers, cosine T=1000, L1 loss), eval forward +
+    validate()-style losses; the fixture holds checksums and sub-sampled hidden states (oracle/gen_golden.py refdefault)."""
+    z, m = load_golden("refdefault_b8s100l16")
+    cfg, model, x = build_case(m)
+    t, noises, u = draws(m, 123)
+    np.testing.assert_array_equal(t.numpy(), z["t"])
+    ac = R.alpha_cumprod(cfg)
+    S, B = m["S"], m["B"]
+    with torch.no_grad():
+        x_0 = model.embedding(x["input_ids"])
+        x_t = R.diffuse_t(x_0, t, noises[0], ac)
+        np.testing.assert_array_equal(x_t[:, :2, :8].numpy(), z["x_t_head"])
+        lt, ht = model(x_t, x["image_clip"].unsqueeze(1).repeat(S, 1, 1), x["text_clip"].unsqueeze(1).repeat(S, 1, 1),
+                       x["attention_mask"].repeat(S, 1), torch.tensor([1, 0]).repeat(S * B, 1))
+        np.testing.assert_allclose(ht[::50, :, ::64].numpy(), z["hid_t"], rtol=0, atol=2e-5)
+        assert abs(ht.double().sum().item() - float(z["hid_t_sum"])) < 2e-6 * ht.numel() ** 0.5 * 10
+        np.testing.assert_array_equal(lt.argmax(-1).numpy(), z["argmax_t"])
+        np.testing.assert_allclose(torch.logsumexp(lt, -1).numpy(), z["lse_t"], rtol=1e-6, atol=1e-5)
+        del lt
+        l, a, b, c = R.train_func(model, None, x, train=False, t=t, noises=noises, cfg_uniform=u, ac=ac)
+    np.testing.assert_allclose(np.array([float(l), float(a), float(b), float(c)]), z["eval_losses"], rtol=2e-6)
+
+
 @pytest.mark.parametrize("name", TRAIN_CASES)
 def test_two_adamw_steps(name):
     z, m = load_golden(name)
