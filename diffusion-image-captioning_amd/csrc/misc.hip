@@ -155,7 +155,7 @@ extern "C" int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int T
 }
 
 // out[0] = scale_a * sum in[0:n_a], out[1] = scale_b * sum in[n_a:n], out[2] = out[0]+out[1]  (one workgroup, fixed order)
-__global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, int n_a, float sa, float sb, float* out2) {
+__global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, int n_a, float sa, float sb, float* out2, const float* carry) {
     __shared__ double red[2][4];
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) { float v = in[i]; if (i < n_a) a += v; else b += v; }
@@ -166,10 +166,76 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, in
         float a_ = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) * sa);
         float b_ = (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) * sb);
         out2[0] = a_; out2[1] = b_; out2[2] = a_ + b_;
+        out2[3] = (a_ + b_) + (carry ? *carry : 0.f);        // running total over several calls (the step's l = x_t + x_1 + prob, ref :481)
     }
 }
-extern "C" int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out2, void* stream) {
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, n_a, scale_a, scale_b, out2);
+extern "C" int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out2, const float* carry, void* stream) {
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, n_a, scale_a, scale_b, out2, carry);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ step inputs of the stacked encoder batch
+// What `loss` (ref :406-415, 426, 434-437) assembles with repeat / hstack / cat every step -- the CLIP rows repeated over the S timesteps,
+// the key-padding masks with their constant CLIP columns, the repeated target ids, the per-sequence loss scales -- written by ONE launch
+// straight into the encoder's and the rounding head's input buffers.  Batch layout: rows [0, S*B) = x_t (s-major: row s*B + b), then B rows x_1.
+__global__ __launch_bounds__(256) void step_prep_kernel(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, int S, int B, int L,
+                                                        int Tk, float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt, int64_t* tgt,
+                                                        float* gscale, float sa, float sb) {
+    const int N = S * B + B, Nt = S * B;
+    const long long n_clip = (long long)N * 128;                 // float4 items per CLIP buffer
+    const long long total = n_clip + (long long)N * Tk + (long long)N * L + N;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n_clip) {
+            const int n = (int)(i >> 7), c = (int)(i & 127), b = n < Nt ? n % B : n - Nt;
+            ((f32x4*)img_in)[i] = ((const f32x4*)img)[(size_t)b * 128 + c];
+            if (txt_in) ((f32x4*)txt_in)[i] = ((const f32x4*)txt)[(size_t)b * 128 + c];
+            continue;
+        }
+        long long j = i - n_clip;
+        if (j < (long long)N * Tk) {
+            const int n = (int)(j / Tk), c = (int)(j - (long long)n * Tk), b = n < Nt ? n % B : n - Nt;
+            kmask[j] = c < L ? (mask[(size_t)b * L + c] != 0) : (c == L ? 1 : 0);      // token keys | image row visible | text row masked
+            continue;
+        }
+        j -= (long long)N * Tk;
+        if (j < (long long)N * L) {
+            if (tgt) { const int n = (int)(j / L), c = (int)(j - (long long)n * L), b = n < Nt ? n % B : n - Nt; tgt[j] = ids[(size_t)b * L + c]; }
+            continue;
+        }
+        j -= (long long)N * L;
+        addtxt[j] = 0;
+        if (gscale) gscale[j] = j < Nt ? sa : sb;
+    }
+}
+extern "C" int dic_step_prep(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, int S, int B, int L, int Tk,
+                             float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt, int64_t* tgt, float* gscale, float scale_a,
+                             float scale_b, void* stream) {
+    DIC_REQUIRE(S > 0 && B > 0 && L > 0 && Tk >= L && Tk <= L + 2, "dic_step_prep: Tk must be L, L+1 or L+2");
+    const long long total = (long long)(S * B + B) * (128 + Tk + L + 1);
+    hipLaunchKernelGGL(step_prep_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, img, txt, mask, ids, S, B, L, Tk, img_in,
+                       txt_in, kmask, addtxt, tgt, gscale, scale_a, scale_b);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+// out[i] = uniform integer in [0, hi) from Philox4x32-10 keyed by (seed, i): the step's timestep vector (ref :460-461 torch.randint)
+__global__ void randint_kernel(int64_t* out, int n, unsigned hi, unsigned long long seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)(((unsigned long long)rng4(seed, (unsigned long long)i).x * hi) >> 32);
+}
+extern "C" int dic_randint(int64_t* out, int n, int hi, uint64_t seed, void* stream) {
+    DIC_REQUIRE(n > 0 && hi > 0, "dic_randint: empty range");
+    hipLaunchKernelGGL(randint_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned)hi, (unsigned long long)seed);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+__global__ void zero_kernel(f32x4* p4, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) p4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+extern "C" int dic_zero(void* p, int64_t nbytes, void* stream) {
+    DIC_REQUIRE(((uintptr_t)p % 16) == 0 && nbytes % 16 == 0 && nbytes >= 0, "dic_zero: 16-byte aligned ranges only");
+    if (nbytes == 0) return 0;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(nbytes / 16, 256, 2048)), dim3(256), 0, (hipStream_t)stream, (f32x4*)p, (long long)(nbytes / 16));
     DIC_CHECK_LAUNCH();
     return 0;
 }

@@ -89,6 +89,30 @@ def _guidance_uniform(n, dev):
     return torch.rand((n, 1), device=dev, generator=g)
 
 
+T_SEED_BASE = 0x7157E9        # timestep draws: the SAME stream on every rank (one t-vector per step for the whole global batch, ref :461)
+
+
+def _draw_t(S, dev):
+    """torch.randint(0, STEP_TOT, (S,1,1)) of ref :460-461 from a Philox kernel.  The seed is a per-process step counter that starts from
+    the same value on every rank, so data-parallel ranks agree on t without a collective (and without a torch generator)."""
+    _state["t_seed"] = _state.get("t_seed", T_SEED_BASE) + 1
+    t = torch.empty((S, 1, 1), dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().dic_randint(_p(t), S, int(cfg.STEP_TOT), _state["t_seed"], torch.cuda.current_stream().cuda_stream), "randint")
+    return t
+
+
+def seed_timesteps(seed: int):
+    _state["t_seed"] = int(seed)
+
+
+def _t_one(dev):
+    """The constant t = 1 of the x_1 pass (ref :468), kept on the device."""
+    key = ("t_one", str(dev))
+    if key not in _state:
+        _state[key] = torch.ones(1, dtype=torch.int64, device=dev)
+    return _state[key]
+
+
 def _next_seed():
     _state["noise_seed"] += 0x9E3779B1
     return _state["noise_seed"] & 0xFFFFFFFFFFFFFFFF
@@ -169,46 +193,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     ws = model._workspace(N, L, drop_txt, cap)
     Tk = ws["Tk"]
 
-    # ---- one stacked encoder batch: [x_t rows | guided copies | x_1 rows]
-    xin = ws["xin"]
-    if x_t.data_ptr() != xin.data_ptr():                  # (train_func lets q_sample write into the workspace directly)
-        xin[:Nt].copy_(x_t)
-    if x_1.data_ptr() != xin[Nt + Ng:].data_ptr():
-        xin[Nt + Ng:N].copy_(x_1)
-    img = image_clip.to(dev, torch.float32)
-    txt = text_clip.to(dev, torch.float32)
-    img_rep, txt_rep = img.repeat(S, 1), txt.repeat(S, 1)
-    m = (mask.to(dev) != 0).to(torch.uint8)
-    m_rep = m.repeat(S, 1)
-    if model.concat:
-        one_t, one_b = torch.ones(Nt, 1, dtype=torch.uint8, device=dev), torch.ones(B, 1, dtype=torch.uint8, device=dev)
-        plain_t = torch.cat([m_rep, one_t] if drop_txt else [m_rep, one_t, 0 * one_t], 1)
-        plain_b = torch.cat([m, one_b] if drop_txt else [m, one_b, 0 * one_b], 1)
-    else:
-        plain_t, plain_b = m_rep, m
-    add_txt = torch.zeros(N, dtype=torch.uint8, device=dev)
-    if Ng:
-        xin[Nt:Nt + Ng].copy_(x_t[gi])
-        g_mask = torch.cat([m_rep[gi], one_t[:Ng], one_t[:Ng]], 1) if model.concat else m_rep[gi]
-        ic = torch.cat([img_rep, img_rep[gi], img])
-        tc = torch.cat([txt_rep, txt_rep[gi], txt])
-        km = torch.cat([plain_t, g_mask, plain_b])
-        add_txt[Nt:Nt + Ng] = 1
-    else:
-        ic, tc, km = torch.cat([img_rep, img]), torch.cat([txt_rep, txt]), torch.cat([plain_t, plain_b])
-    tidx = None
-    if model.temb:          # optional timestep embedding: row s*B+b carries t[s], a guided copy its source row's, the x_1 rows t = 1
-        tv = getattr(model, "_step_t", None)
-        assert tv is not None and tv.numel() == S, "cfg.TIMESTEP_EMBEDDING needs the step's t-vector (train_func passes it)"
-        tt = tv.reshape(S, 1).to(dev, torch.int32).repeat(1, B).reshape(Nt)
-        tidx = torch.cat([tt] + ([tt[gi]] if Ng else []) + [torch.ones(B, dtype=torch.int32, device=dev)])
-    x_out = model.encode(xin[:N], ic, tc, km, add_txt, drop_txt=drop_txt, cap=cap, tidx=tidx)
-    st = model.ops.stream
-    row = Tk * 768
-    if Ng:
-        _lib.check(lib.dic_cfg_mix_fwd(_p(x_out), _p(x_out) + Nt * row * 4, _p(gi), Ng, row, w, st), "cfg_mix_fwd")
-
-    # ---- embedding losses (ref :77-87, 418, 428) + compact rows for the rounding head
+    # ---- loss scales (ref :77-87) and scratch
     sc = ws.get("loss_sc")
     if sc is None:
         sc = ws["loss_sc"] = dict(per_seq=torch.zeros(ws["cap"], dtype=torch.float32, device=dev),
@@ -234,9 +219,65 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     M = (Nt + B) * L
     cw = model._ce_workspace(M)
     dx = ws["dx_out"]
+
+    # ---- one stacked encoder batch: [x_t rows | guided copies | x_1 rows]
+    xin = ws["xin"]
+    if x_t.data_ptr() != xin.data_ptr():                  # (train_func lets q_sample write into the workspace directly)
+        xin[:Nt].copy_(x_t)
+    if x_1.data_ptr() != xin[Nt + Ng:].data_ptr():
+        xin[Nt + Ng:N].copy_(x_1)
+
+    def resident(t_, dtype):
+        return t_.device == dev and t_.dtype == dtype and t_.is_contiguous()
+    fast = (w <= 0 and not model.temb and resident(image_clip, torch.float32) and resident(text_clip, torch.float32)
+            and resident(mask, torch.int64) and resident(idx, torch.int64))
+    if fast:
+        # no guidance: the repeats / hstacks / cats of ref :406-415, 426 and the target ids of :434-437 are ONE kernel writing the
+        # encoder's and the rounding head's input buffers (no ATen kernel on the step)
+        st0 = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.dic_step_prep(_p(image_clip), _p(text_clip), _p(mask), _p(idx), S, B, L, Tk, _p(ws["img_in"]),
+                                     0 if ws["mode"] == 2 else _p(ws["txt_in"]), _p(ws["kmask"]), _p(ws["addtxt"]),
+                                     _p(cw["tgt"]) if cfg.USE_PROB_LOSS else 0, _p(sc["gscale"]) if want_grad else 0, sa, sb, st0), "step_prep")
+        x_out = model.encode(xin[:N], None, None, None, drop_txt=drop_txt, cap=cap)
+    else:
+        img = image_clip.to(dev, torch.float32)
+        txt = text_clip.to(dev, torch.float32)
+        img_rep, txt_rep = img.repeat(S, 1), txt.repeat(S, 1)
+        m = (mask.to(dev) != 0).to(torch.uint8)
+        m_rep = m.repeat(S, 1)
+        if model.concat:
+            one_t, one_b = torch.ones(Nt, 1, dtype=torch.uint8, device=dev), torch.ones(B, 1, dtype=torch.uint8, device=dev)
+            plain_t = torch.cat([m_rep, one_t] if drop_txt else [m_rep, one_t, 0 * one_t], 1)
+            plain_b = torch.cat([m, one_b] if drop_txt else [m, one_b, 0 * one_b], 1)
+        else:
+            plain_t, plain_b = m_rep, m
+        add_txt = torch.zeros(N, dtype=torch.uint8, device=dev)
+        if Ng:
+            xin[Nt:Nt + Ng].copy_(x_t[gi])
+            g_mask = torch.cat([m_rep[gi], one_t[:Ng], one_t[:Ng]], 1) if model.concat else m_rep[gi]
+            ic = torch.cat([img_rep, img_rep[gi], img])
+            tc = torch.cat([txt_rep, txt_rep[gi], txt])
+            km = torch.cat([plain_t, g_mask, plain_b])
+            add_txt[Nt:Nt + Ng] = 1
+        else:
+            ic, tc, km = torch.cat([img_rep, img]), torch.cat([txt_rep, txt]), torch.cat([plain_t, plain_b])
+        tidx = None
+        if model.temb:          # optional timestep embedding: row s*B+b carries t[s], a guided copy its source row's, the x_1 rows t = 1
+            tv = getattr(model, "_step_t", None)
+            assert tv is not None and tv.numel() == S, "cfg.TIMESTEP_EMBEDDING needs the step's t-vector (train_func passes it)"
+            tt = tv.reshape(S, 1).to(dev, torch.int32).repeat(1, B).reshape(Nt)
+            tidx = torch.cat([tt] + ([tt[gi]] if Ng else []) + [torch.ones(B, dtype=torch.int32, device=dev)])
+        x_out = model.encode(xin[:N], ic, tc, km, add_txt, drop_txt=drop_txt, cap=cap, tidx=tidx)
+    st = model.ops.stream
+    row = Tk * 768
+    if Ng:
+        _lib.check(lib.dic_cfg_mix_fwd(_p(x_out), _p(x_out) + Nt * row * 4, _p(gi), Ng, row, w, st), "cfg_mix_fwd")
+
+    # ---- embedding losses (ref :77-87, 418, 428) + compact rows for the rounding head
     if want_grad:
-        sc["gscale"][:Nt].fill_(sa)
-        sc["gscale"][Nt:Nt + B].fill_(sb)
+        if not fast:
+            sc["gscale"][:Nt].fill_(sa)
+            sc["gscale"][Nt:Nt + B].fill_(sb)
         if Ng:
             dx[Nt:Nt + Ng].zero_()
     tgt_t, tgt_rows = (x_0, B) if cfg.X_0_PREDICTION else (x_tgt, Nt)
@@ -250,18 +291,21 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     off = (Nt + Ng) * row * 4
     _lib.check(lib.dic_emb_loss(model.dt, kind, _p(x_out) + off, _p(x_0c), B, _p(sc["per_seq"]) + Nt * 4, (_p(dx) + off) if want_grad else 0,
                                 _p(sc["gscale"]) + Nt * 4, _p(cw["xr"]) + Nt * L * 768 * es, B, L, Tk, 768, st), "emb_loss")
-    _lib.check(lib.dic_seg_sum(_p(sc["per_seq"]), Nt + B, Nt, sa, sb, _p(out), st), "seg_sum")
+    _lib.check(lib.dic_seg_sum(_p(sc["per_seq"]), Nt + B, Nt, sa, sb, _p(out), 0, st), "seg_sum")
+    model._last_total = out[3]
 
     # ---- rounding loss (ref :432-445): streaming GEMM + logsumexp + gather, logits never materialised
     if cfg.USE_PROB_LOSS:
-        ids = idx.to(dev, torch.int64)
-        cw["tgt"][:Nt * L].copy_(ids.repeat(S, 1).reshape(-1))
-        cw["tgt"][Nt * L:].copy_(ids.reshape(-1))
+        if not fast:
+            ids = idx.to(dev, torch.int64)
+            cw["tgt"][:Nt * L].copy_(ids.repeat(S, 1).reshape(-1))
+            cw["tgt"][Nt * L:].copy_(ids.reshape(-1))
         model.rounding(cw["xr"], M, cw["tgt"], cw)
         ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         rw = float(cfg.ROUNDING_WEIGHT)
-        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(out) + 4 * 4, st), "seg_sum")
+        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(out) + 4 * 4, _p(out) + 2 * 4, st), "seg_sum")
+        model._last_total = out[7]                       # x_t_loss + x_1_loss + prob_loss, summed by the kernel (ref :481)
         if want_grad:
             dxr = model.rounding_backward(cw, M, Nt * L, rw * ca, rw * cb)
             _lib.check(lib.dic_add_rows(_p(dx), _p(dxr), Nt, L, Tk, 768, st), "add_rows")
@@ -361,7 +405,7 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
     x_0 = model.embedding(x["input_ids"].to(dev))
     S = cfg.SAMPLE_SIZE
     if t is None:
-        t = parallel.shared_randint(0, cfg.STEP_TOT, (S, 1, 1), dev)     # one t-vector per step shared by the batch (ref :461)
+        t = _draw_t(S, dev)                               # one t-vector per step shared by the (global) batch (ref :461)
     t = t.to(dev)
     nz = list(noises) if noises is not None else [None, None, None]
     # without classifier-free guidance the stacked encoder batch is [x_t rows | x_1 rows]: q_sample writes straight into it
@@ -377,7 +421,7 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
     else:
         t_next = torch.max(t - cfg.X_T_STEP_INTERVAL, torch.zeros_like(t))
         x_t, x_tgt = generate_diffuse_pair(x_0, t, t_next, noises=(nz.pop(0), nz.pop(0)))
-    x_1 = diffuse_t(x_0, torch.ones(1, dtype=torch.int64, device=dev), noise=nz.pop(0), out=out_1)
+    x_1 = diffuse_t(x_0, _t_one(dev), noise=nz.pop(0), out=out_1)
     model._step_t = t
     if train:
         trainer.zero_grad()
@@ -385,9 +429,11 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
             # a torch optimizer's zero_grad() only drops the .grad views: the slots this backward will not write (position rows
             # beyond the sequence, text_linear when the text row is skipped) must still be cleared in the flat buffer
             model.params.zero_pending = True
+    model._last_total = None
     x_t_loss, x_1_loss, prob_loss = loss(model, x_t, x_1, x_tgt, x_0, x["image_clip"], x["text_clip"], x["attention_mask"],
                                          x["input_ids"], cfg.LOSS_FUNC, cfg_uniform=cfg_uniform)
-    l = x_t_loss + x_1_loss + prob_loss
+    # l = x_t_loss + x_1_loss + prob_loss (ref :481): the loss kernels already wrote that sum next to the three terms
+    l = model._last_total if model._last_total is not None else x_t_loss + x_1_loss + prob_loss
     if train:
         if not model._pending:
             raise RuntimeError("train_func(train=True) called under torch.no_grad()")

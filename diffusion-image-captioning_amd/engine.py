@@ -414,10 +414,11 @@ class Denoiser:
         # LayerNorm / attention kernels and store-heavy epilogues: letting the two streams share the CUs overlaps those phases.
         if P.zero_pending:          # zero_grad(): clear what this backward will not overwrite
             P.zero_pending = False
-            P.slot_view(P.G, "pos")[Tk:].zero_()
+            pos_rows = P._slots["pos"][1][0]
+            _lib.check(lib.dic_zero(P.ptr("pos", "G") + Tk * D * 4, (pos_rows - Tk) * D * 4, st), "zero")
             if ws["mode"] == 2:
-                P.slot_view(P.G, "Wtxt").zero_()
-                P.slot_view(P.G, "btxt").zero_()
+                _lib.check(lib.dic_zero(P.ptr("Wtxt", "G"), D * 512 * 4, st), "zero")
+                _lib.check(lib.dic_zero(P.ptr("btxt", "G"), D * 4, st), "zero")
         main = torch.cuda.current_stream()
         use_side = self.bf16 and _os.environ.get("DIC_WGRAD_STREAM", "1") == "1" and self.wgrad_stream_enabled
         side = self._side_stream() if use_side else None

@@ -172,7 +172,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
                                 _p(b["gscale"]) + Nt * 4, _p(b["xr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "emb_loss")
     b["slot"] = (b["slot"] + 1) % 256           # ring of result slots, as diffusion.loss (returned losses stay valid for 256 calls)
     out = b["ring"][b["slot"]]
-    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), Nt + B, Nt, sa, sb, _p(out), st), "seg_sum")
+    _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), Nt + B, Nt, sa, sb, _p(out), 0, st), "seg_sum")
     if want_grad:
         b["g16"].copy_(b["dx16"])                  # the loss gradient alone: its negative flows into the targets
 
@@ -191,7 +191,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
         ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         rw = float(cfg.ROUNDING_WEIGHT)
-        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(out) + 4 * 4, st), "seg_sum")
+        _lib.check(lib.dic_seg_sum(_p(cw["nll"]), M, Nt * L, rw * ca, rw * cb, _p(out) + 4 * 4, 0, st), "seg_sum")
         if want_grad:
             if b["dlogits"] is None:
                 b["dlogits"] = torch.empty(M, model.vpad, dtype=torch.float32, device=dev)

@@ -172,8 +172,21 @@ int dic_emb_loss(int dtype, int kind, const float* x_out, const float* target, i
                  float* dx_out, const float* grad_scale, void* xr, int N, int L, int Tk, int D, void* stream);
 /* dx_out[n][t<L][:] += dxr[n*L+t][:]   (adds the rounding-loss gradient)                                           */
 int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int Tk, int D, void* stream);
-/* out3[0] = scale_a*sum in[0:n_a), out3[1] = scale_b*sum in[n_a:n), out3[2] = out3[0]+out3[1] (fp64 accumulate)      */
-int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out3, void* stream);
+/* out4[0] = scale_a*sum in[0:n_a), out4[1] = scale_b*sum in[n_a:n), out4[2] = out4[0]+out4[1] (fp64 accumulate)      */
+int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out4, const float* carry, void* stream);
+/* (out4[0..2] as above; out4[3] = out4[2] + *carry (carry optional): the step's total l = x_t_loss + x_1_loss + prob_loss, ref:481) */
+
+/* Step inputs of the stacked encoder batch [S*B x_t rows (s-major) | B x_1 rows] without classifier-free guidance, in one launch:
+ * img_in/txt_in [N][512] = the CLIP rows repeated over S (ref:415 `.repeat((SAMPLE_SIZE,1,1))`; txt_in optional), kmask [N][Tk] =
+ * [mask != 0 | 1 | 0] (ref:296-297 hstack([mask, [1,0]]); Tk = L+1 drops the text column, Tk = L is "add" fusion), addtxt [N] = 0,
+ * tgt [(N)*L] = ids repeated (ref:434-437; optional), gscale [N] = scale_a for the x_t rows, scale_b for the x_1 rows (optional).      */
+int dic_step_prep(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, int S, int B, int L, int Tk,
+                  float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt, int64_t* tgt, float* gscale, float scale_a, float scale_b,
+                  void* stream);
+/* out[i] ~ U{0..hi-1}, Philox4x32-10 keyed by (seed, i) -- the step's shared timestep vector (ref:460-461).                          */
+int dic_randint(int64_t* out, int n, int hi, uint64_t seed, void* stream);
+/* zero a 16-byte aligned device range (gradient slots a backward does not write)                                                      */
+int dic_zero(void* p, int64_t nbytes, void* stream);
 
 /* ---------------------------------------------------------------- classifier-free-guidance mix (ref:313-317)
  * x_out[idx[i]] = (1+w)*g_out[i] - w*x_out[idx[i]]  (rows of Tk*D floats); backward splits the gradient.          */

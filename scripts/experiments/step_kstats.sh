@@ -15,6 +15,6 @@ for r in rows[:16]:
     print(f"{n:70s} calls {int(r['Calls'])//13:4d}/step avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['TotalDurationNs'])/13e6:7.3f} ms/step")
 PY
 }
-run new DIC_WGRAD_STREAM=${WGS:-1}
+run new DIC_WGRAD_STREAM=${WGS:-1}; grep -c "at::native\|rocclr" $O/new_kernel_stats.csv; grep "at::native\|rocclr" $O/new_kernel_stats.csv | cut -c1-120
 grep -h '"metric"' $O/new.log | cut -c1-160
 if [ -n "$1" ]; then run $1 DIC_WGRAD_STREAM=${WGS:-1} DIC_HIP_LIB=$R/ab/libdic_$1.so; grep -h '"metric"' $O/$1.log | cut -c1-160; fi

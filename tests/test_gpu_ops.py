@@ -538,9 +538,9 @@ def test_emb_loss_kinds(L, kind, name):
     dx = torch.full((N, Tk, 768), float("nan"), device="cuda")
     gs = torch.full((N,), scale, device="cuda")
     xr = torch.zeros(N * Lq, 768, device="cuda")
-    out = torch.zeros(3, device="cuda")
+    out = torch.zeros(4, device="cuda")
     ok(L.dic_emb_loss(F32, kind, p(dev(xo)), p(dev(x0)), B, p(per), p(dx), p(gs), p(xr), N, Lq, Tk, 768, stream()), L)
-    ok(L.dic_seg_sum(p(per), N, N, scale, 0.0, p(out), stream()), L)
+    ok(L.dic_seg_sum(p(per), N, N, scale, 0.0, p(out), 0, stream()), L)
     torch.cuda.synchronize()
     assert abs(float(out[0]) - float(ref)) < 2e-6 * abs(float(ref))
     assert relerr(dx, xx.grad) < 1e-5
@@ -607,3 +607,40 @@ def test_adamw_matches_oracle_and_writes_bf16_shadow(L):
         torch.cuda.synchronize()
         np.testing.assert_allclose(P.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=1e-6)
     assert torch.equal(sh.cpu(), P.cpu().to(torch.bfloat16))
+
+
+def test_step_prep_randint_zero(L):
+    """The step-input kernel against the repeat / hstack / cat statements of ref :406-415, 426, 434-437; the timestep draw; the range fill."""
+    S, B, Lq = 3, 4, 16
+    g = torch.Generator().manual_seed(2)
+    img, txt = torch.randn(B, 512, generator=g), torch.randn(B, 512, generator=g)
+    mask = (torch.rand(B, Lq, generator=g) > 0.3).long()
+    ids = torch.randint(0, 30522, (B, Lq), generator=g)
+    N = S * B + B
+    for Tk in (Lq + 2, Lq + 1, Lq):
+        img_in, txt_in = torch.full((N, 512), float("nan"), device="cuda"), torch.full((N, 512), float("nan"), device="cuda")
+        km = torch.full((N, Tk), 9, dtype=torch.uint8, device="cuda")
+        at = torch.full((N,), 9, dtype=torch.uint8, device="cuda")
+        tgt = torch.full((N * Lq,), -5, dtype=torch.int64, device="cuda")
+        gs = torch.full((N,), float("nan"), device="cuda")
+        ok(L.dic_step_prep(p(dev(img)), p(dev(txt)), p(dev(mask)), p(dev(ids)), S, B, Lq, Tk, p(img_in), p(txt_in), p(km), p(at), p(tgt), p(gs),
+                           0.25, 0.5, stream()), L)
+        torch.cuda.synchronize()
+        assert torch.equal(img_in.cpu(), torch.cat([img.repeat(S, 1), img])) and torch.equal(txt_in.cpu(), torch.cat([txt.repeat(S, 1), txt]))
+        m = (mask != 0).to(torch.uint8)
+        one = torch.ones(B, 1, dtype=torch.uint8)
+        row = torch.cat([m, one, 0 * one][: 1 + (Tk - Lq)], 1)
+        assert torch.equal(km.cpu(), torch.cat([row.repeat(S, 1), row]))
+        assert bool((at == 0).all()) and torch.equal(tgt.cpu(), torch.cat([ids.repeat(S, 1), ids]).reshape(-1))
+        assert torch.equal(gs.cpu(), torch.tensor([0.25] * (S * B) + [0.5] * B))
+    t = torch.full((4096,), -1, dtype=torch.int64, device="cuda")
+    ok(L.dic_randint(p(t), 4096, 100, 77, stream()), L)
+    t2 = torch.empty_like(t)
+    ok(L.dic_randint(p(t2), 4096, 100, 77, stream()), L)
+    tc = t.cpu()
+    assert torch.equal(tc, t2.cpu()) and int(tc.min()) == 0 and int(tc.max()) == 99 and abs(float(tc.float().mean()) - 49.5) < 2.0
+    assert torch.bincount(tc, minlength=100).min() > 15
+    z = torch.full((1000,), 3.0, device="cuda")
+    ok(L.dic_zero(p(z) + 16, 16 * 50, stream()), L)
+    torch.cuda.synchronize()
+    assert bool((z[4:204] == 0).all()) and bool((z[:4] == 3).all()) and bool((z[204:] == 3).all())
