@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: training captions/sec of the CLIP-DDPM hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: bench.py starts its own N ranks)
+    python bench.py --mode sample                        (BASELINE.json config 4 as the headline line instead)
 
 One "step" = one `train_func` call: embed -> q_sample -> ONE stacked encoder pass over the x_t and x_1 rows ->
 embedding + rounding losses -> backward -> (RCCL all-reduce) -> AdamW, on a synthetic batch already resident in HBM.
@@ -11,21 +11,32 @@ denoiser ("bert-base" of the north_star; the reference's own depth is 6 -- `--la
 beta schedule T=100, bf16 operands with fp32 accumulation/statistics/optimizer, dropout 0.1 as the reference trains,
 SAMPLE_SIZE S=1 timestep per caption per step (the reference default S=100 is `--sample-size 100 --batch 8`).
 Weak scaling: per-GPU work is fixed; value = N * 512 * K / max-over-ranks time.
+
+Besides the contract's keys the line carries (rank 0, N = 1): `roofline` (GEMM launches bracketed by hipEvents), `cpu_baseline` (the CPU
+port on a bounded sample of the same workload, median of 3) and `cpu_baseline_config1` (the BASELINE.json configs[0] shape: B=8, S=100,
+6 layers), `bf16_vs_fp32_loss_rel` (the same eval step in both dtypes at the bench shape), `sampling` (configs[3]: 2048 images, 100
+passes, captions/s + BLEU-4 of the bf16 ids against the fp32 ids) and `seq32_cfg` (configs[4] on one GPU: seq_len 32 + guidance).
+`--quick` skips those extras.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
 # algorithmic GFLOP per denoiser sequence, forward+backward (SURVEY.md section 8d; lm_head backward = dX only)
-def gflop_per_seq(L, layers):
-    T, D, F, V = L + 2, 768, 3072, 30522
+def gflop_per_seq(L, layers, T=None):
+    """T: tokens per sequence (default L + 2 = the reference's concat sequence; L + 1 when the unguided text row is skipped)."""
+    T, D, F, V = (L + 2 if T is None else T), 768, 3072, 30522
     per_layer = 2 * T * D * (3 * D + D + 2 * F) + 2 * 2 * T * T * D
     fwd = layers * per_layer + 2 * T * D * D + 2 * 2 * T * D * 512 + 2 * L * D * V
     bwd = 2 * (fwd - 2 * L * D * V) + 2 * L * D * V
@@ -53,18 +64,98 @@ def relaunch(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def csrc_sha():
+    """Identity of the kernel sources a PMC traffic file must have been collected on to be quoted."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed PMC collection -- only if it was taken on exactly these kernel sources."""
+    sha = csrc_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if pj.get("csrc_sha") == sha:
+            return round(pj["gemm_fetch_bytes_per_launch_x2"] + pj["gemm_write_bytes_per_launch"]), \
+                f"bytes/launch averaged over the step's GEMM launches, FETCH_SIZE(x2)+WRITE_SIZE, profiles/{os.path.basename(f)} (csrc {sha})"
+    return None, f"no PMC collection for csrc {sha} under profiles/ (rocprofv3 --pmc needs its own passes: scripts/pmc_traffic.sh)"
+
+
+def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_batch=256):
+    """BASELINE.json configs[3]: x0-prediction sampling loop (ref :611-621), logits/argmax only after the last pass."""
+    dic.cfg.update(MAX_LENGTH=16, CLASSIFIER_FREE_WEIGHT=0.0, CLIP_ADDING_METHOD="concat", VOCAB_SIZE=30522)
+    model = dic.DistilBertModel(E, E, config=dict(n_layers=layers), dtype=dtype, device=dev)
+    model.eval()
+    img = torch.from_numpy(dic.synth.batch(batch, 16, 30522, 2)["image_clip"]).to(dev)
+    dic.sample(model, img, steps=2)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dic.sample(model, img, steps=passes)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    out = {"metric": "sampling captions/sec", "value": round(batch / best, 1), "unit": "captions/s", "batch": batch, "denoising_passes": passes,
+           "n_layers": layers, "dtype": dtype, "ms_per_pass": round(best / passes * 1e3, 3)}
+    if dtype == "bf16" and bleu_batch > 0:
+        # BLEU-4 of the bf16 loop's ids against the fp32 loop's ids from the SAME start noise (the fp32 path is the one the -m gpu tests
+        # pin bit-exactly to the reference's ids on the golden fixture): how far the bf16 passes drift in token space
+        m32 = dic.DistilBertModel(E, E, config=dict(n_layers=layers), dtype="fp32", device=dev)
+        m32.load_state_dict(model.state_dict())
+        m32.eval()
+        start = torch.randn(bleu_batch, 18, 768, generator=torch.Generator().manual_seed(11)).to(dev)
+        ids16 = dic.sample(model, img[:bleu_batch], steps=passes, start=start).cpu()
+        ids32 = dic.sample(m32, img[:bleu_batch], steps=passes, start=start).cpu()
+        out["bleu4_bf16_vs_fp32_ids"] = round(dic.bleu.corpus_bleu([r.tolist() for r in ids16], [[r.tolist()] for r in ids32]), 4)
+        out["token_agreement"] = round(float((ids16 == ids32).float().mean()), 4)
+        out["bleu_captions"] = bleu_batch
+        del m32
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_leg(dic, torch, E, cb, S, L, layers, steps=3):
+    """The CPU port of the reference step (oracle/ref_model.py) on this host's cores: median of `steps` after one warm-up."""
+    from oracle import ref_model as R
+    rcfg = R.Config(BATCH_SIZE=cb, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=layers, vocab=30522)
+    om = R.build(rcfg, dic.synth.denoiser_state(layers, 0), E)
+    otr = R.AdamW(om.parameters(), lr=1e-4)
+    xb = {k: torch.from_numpy(v) for k, v in dic.synth.batch(cb, L, 30522, 1).items()}
+    times = []
+    for i in range(steps + 1):
+        t = torch.from_numpy(dic.synth.timesteps(S, 100, i))
+        nz = [torch.randn(cb, L, 768) for _ in range(2)]
+        c0 = time.perf_counter()
+        R.train_func(om, otr, xb, t=t, noises=nz)
+        times.append(time.perf_counter() - c0)
+    med = statistics.median(times[1:])
+    return {"value": round(cb / med, 3), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ref_model.py train_func, {cb} captions/step (S={S}, L={L}, {layers} layers, fp32, linear T=100), median of {steps} steps "
+                      f"after 1 warm-up ({med:.2f} s/step)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="captions per GPU per step")
+    ap.add_argument("--mode", default="train", choices=["train", "sample"])
+    ap.add_argument("--batch", type=int, default=None, help="captions per GPU per step (train: 512, sample: 2048)")
     ap.add_argument("--sample-size", type=int, default=1, help="SAMPLE_SIZE S: noised copies per caption per step")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--seq-len", type=int, default=16)
+    ap.add_argument("--cfg-weight", type=float, default=0.0, help="classifier-free guidance weight (configs[4]: 0.3 with --seq-len 32)")
+    ap.add_argument("--passes", type=int, default=100, help="denoising passes of --mode sample")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="headline + roofline only (no CPU legs, no sampling / seq32 / dtype-delta extras)")
     args = ap.parse_args()
 
     # --gpus N without a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI) exactly as the driver would
@@ -77,11 +168,26 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}: refusing to report a line for a different GPU count")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B, S, L = args.batch, args.sample_size, args.seq_len
-    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=30522,
-                   CLASSIFIER_FREE_WEIGHT=0.0, CLIP_ADDING_METHOD="concat", LOSS_FUNC="series_sum_sample_mean",
-                   X_0_PREDICTION=True, ROUNDING_WEIGHT=0.5)
     E = dic.synth.vocab_embedding(30522, 768, 0)
+
+    if args.mode == "sample":
+        line = sampling_leg(dic, torch, E, dev, args.batch or 2048, args.passes, args.layers, args.dtype, reps=3)
+        line.update({"n_gpus": world, "steps": args.passes, "warmup": 2, "ms_per_step": line["ms_per_pass"], "higher_is_better": True, "scaling": "weak",
+                     "vs_baseline": None, "data": "synthetic",
+                     "config": {"workload": f"sample(): {line['batch']} images, {args.passes} x0-prediction passes of the {args.layers}-layer denoiser, "
+                                            f"rounding (argmax over 30522) after the last pass"}})
+        if rank == 0:
+            print(json.dumps(line))
+        return
+
+    B, S, L = args.batch or 512, args.sample_size, args.seq_len
+    w = args.cfg_weight
+
+    def configure(L_, w_):
+        dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L_, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=30522,
+                       CLASSIFIER_FREE_WEIGHT=w_, CLASSIFIER_FREE_PROB=0.2, CLIP_ADDING_METHOD="concat", LOSS_FUNC="series_sum_sample_mean",
+                       X_0_PREDICTION=True, ROUNDING_WEIGHT=0.5)
+    configure(L, w)
     model = dic.DistilBertModel(E, E, config=dict(n_layers=args.layers, dropout=0.1, attention_dropout=0.1), dtype=args.dtype,
                                 device=dev, seed=0)            # same random init on every rank (DDP invariant)
     dic.parallel.configure_model_for_rank(model)
@@ -124,52 +230,85 @@ def main():
         model.wgrad_stream_enabled = True
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        # HBM traffic of the same kernels comes from PMC passes (rocprofv3 --pmc cannot run inside this process): the committed
-        # summary of the last collection, valid for the default workload only
-        traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v7_pmc_gemm_traffic.json")
-        if os.path.exists(pmc) and (B, S, L, args.layers, args.dtype) == (512, 1, 16, 12, "bf16"):
-            with open(pmc) as fh:
-                pj = json.load(fh)
-            traffic = round(pj["gemm_fetch_bytes_per_launch_x2"] + pj["gemm_write_bytes_per_launch"])
-            traffic_src = "bytes/launch averaged over the step's GEMM launches, FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_v7_pmc_gemm_traffic.json"
-        roof = {"bound": "mfma", "kernel": "gemm_kernel (all layouts/epilogues)", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_src, "launches_per_step": n.value // max(args.steps, 1),
-                "gemm_ms_per_step": round(ms.value / args.steps, 3), "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
+        traffic, traffic_src = (None, "PMC traffic is collected for the default workload only")
+        if (B, S, L, args.layers, args.dtype, w) == (512, 1, 16, 12, "bf16", 0.0):
+            traffic, traffic_src = pmc_traffic()
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)" if args.dtype == "bf16" else "gemm_kernel<float>", "achieved": round(ach, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_src,
+                "launches_per_step": n.value // max(args.steps, 1), "gemm_ms_per_step": round(ms.value / args.steps, 3),
+                "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
     barrier()
 
-    # ---- CPU baseline: the oracle (a port of the reference step) on this host's cores, bounded sample, rank 0 at N=1 only
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import ref_model as R
-        cb = 16
-        rcfg = R.Config(BATCH_SIZE=cb, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=args.layers, vocab=30522)
-        om = R.build(rcfg, dic.synth.denoiser_state(args.layers, 0), E)
-        otr = R.AdamW(om.parameters(), lr=1e-4)
-        xb = {k: torch.from_numpy(v) for k, v in dic.synth.batch(cb, L, 30522, 1).items()}
-        times = []
-        for i in range(3):
-            t = torch.from_numpy(dic.synth.timesteps(S, 100, i))
-            nz = [torch.randn(cb, L, 768) for _ in range(2)]
+    extras = rank == 0 and world == 1 and not args.quick
+    dtype_delta = sampling = seq32 = None
+    if extras and args.dtype == "bf16":
+        # the same eval step (same t, same noise) in fp32 and bf16 at the bench shape: how far the benchmarked dtype is from the parity dtype
+        from_t = torch.from_numpy(dic.synth.timesteps(S, 100, 0))
+        nz = [torch.from_numpy(dic.synth.noise((B, L, 768), 3, f"eps{i}")) for i in range(2)]
+        u = torch.from_numpy(dic.synth.uniform(dic.synth.stream_id("cfg", 3), (S * B, 1)))
+        vals = {}
+        state = model.state_dict()
+        for dt_ in ("fp32", "bf16"):
+            m2 = model if dt_ == "bf16" else dic.DistilBertModel(E, E, config=dict(n_layers=args.layers, dropout=0.1, attention_dropout=0.1), dtype="fp32", device=dev)
+            if dt_ == "fp32":
+                m2.load_state_dict(state)
+            m2.eval()
+            with torch.no_grad():
+                r = dic.train_func(m2, None, x, train=False, t=from_t, noises=nz, cfg_uniform=u)
+            vals[dt_] = [float(v) for v in r]
+            m2.train()
+            if dt_ == "fp32":
+                del m2
+                torch.cuda.empty_cache()
+        dtype_delta = {k: round(abs(a - b) / abs(b), 8) for k, a, b in zip(("total", "x_t", "x_1", "prob"), vals["bf16"], vals["fp32"])}
+    del trainer, model
+    torch.cuda.empty_cache()
+    if extras:
+        sampling = sampling_leg(dic, torch, E, dev, 2048, 100, args.layers, args.dtype)
+        if (L, w) == (16, 0.0):
+            # configs[4] on one GPU: seq_len 32 (+2 CLIP rows = 34 tokens: the 2x2-tile MFMA attention) with classifier-free guidance
+            configure(32, 0.3)
+            m5 = dic.DistilBertModel(E, E, config=dict(n_layers=args.layers, dropout=0.1, attention_dropout=0.1), dtype=args.dtype, device=dev, seed=0)
+            tr5 = dic.AdamW(m5.parameters(), lr=1e-4)
+            x5 = {k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, 32, 30522, seed=1).items()}
+            for _ in range(3):
+                dic.train_func(m5, tr5, x5)
+            torch.cuda.synchronize()
             c0 = time.perf_counter()
-            R.train_func(om, otr, xb, t=t, noises=nz)
-            times.append(time.perf_counter() - c0)
-        step = sorted(times[1:])[0] if len(times) > 1 else times[0]
-        cpu = {"value": round(cb / step, 3), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"oracle/ref_model.py train_func, {cb} captions/step (S={S}, {args.layers} layers, fp32), best of 2 steps after 1 warm-up"}
+            n5 = 8
+            for _ in range(n5):
+                o5 = dic.train_func(m5, tr5, x5)
+            torch.cuda.synchronize()
+            d5 = (time.perf_counter() - c0) / n5
+            seq32 = {"metric": "training captions/sec (seq32 + classifier-free guidance w=0.3, p=0.2)", "value": round(B / d5, 1), "unit": "captions/s",
+                     "ms_per_step": round(d5 * 1e3, 3), "steps": n5, "batch": B, "seq_len": 32, "n_layers": args.layers, "dtype": args.dtype,
+                     "sequences_per_step": f"{S * B} x_t + ~{0.8 * S * B:.0f} guided copies + {B} x_1, 34 tokens each", "loss": round(float(o5[0]), 4)}
+            del m5, tr5
+            torch.cuda.empty_cache()
+            configure(L, w)
+
+    # ---- CPU baseline: the oracle (a port of the reference step) on this host's cores, bounded sample, rank 0 at N=1 only
+    cpu = cpu1 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.quick:
+        cpu = cpu_leg(dic, torch, E, 16, S, L, args.layers)
+        cpu1 = cpu_leg(dic, torch, E, 8, 100, 16, 6)          # BASELINE.json configs[0] / BASELINE.md section 3: B=8, S=100, 6 layers
 
     if rank == 0:
         gf = gflop_per_seq(L, args.layers) * (S + 1)
+        guided = f", classifier-free guidance w={w} p=0.2" if w > 0 else ""
         line = {
-            "metric": "training captions/sec (seq16, bert-base)", "value": round(value, 2), "unit": "captions/s", "n_gpus": world,
+            "metric": "training captions/sec (seq16, bert-base)" if L == 16 else f"training captions/sec (seq{L}, bert-base)", "value": round(value, 2),
+            "unit": "captions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"train_func: B={B}/GPU x S={S} (+x_1 pass) = {(S + 1) * B} sequences x {L}+2 tokens (the unguided text row is "
-                                   f"skipped), {args.layers}-layer DistilBERT-width denoiser, concat fusion, linear beta T=100, dropout 0.1, AdamW",
+            "config": {"workload": f"train_func: B={B}/GPU x S={S} (+x_1 pass) = {(S + 1) * B} sequences x {L}+2 tokens (an unguided text row is "
+                                   f"skipped), {args.layers}-layer DistilBERT-width denoiser, concat fusion, linear beta T=100, dropout 0.1, AdamW{guided}",
                        "global_batch": world * B, "seq_len": L, "sample_size": S, "n_layers": args.layers,
                        "parallelism": f"dp{world}", "loss": round(loss_val, 4),
-                       "algorithmic_tflop_per_s": round(value * gf / 1e3, 2)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "algorithmic_tflop_per_s": round(value * gf / 1e3, 2),
+                       "executed_tflop_per_s": round(value * gflop_per_seq(L, args.layers, L + 1 if w <= 0 else L + 2) * (S + 1) / 1e3, 2)},
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, "bf16_vs_fp32_loss_rel": dtype_delta,
+            "sampling": sampling, "seq32_cfg": seq32,
         }
         print(json.dumps(line))
     if world > 1:

@@ -45,4 +45,6 @@ if len(sys.argv) > 4:
            "gemm_write_bytes_per_launch": 1e3 * g["write_kb"] / g["launches"],
            "step_fetch_gb_x2": 2 * tot_f / steps / 1e6, "step_write_gb": tot_w / steps / 1e6,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (each with --kernel-trace); KB units; gfx950 x2 correction on FETCH_SIZE"}
+    if len(sys.argv) > 5:
+        out["csrc_sha"] = sys.argv[5]          # bench.py quotes this file only for exactly these kernel sources
     json.dump(out, open(sys.argv[4], "w"), indent=1)
