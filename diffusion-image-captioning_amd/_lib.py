@@ -24,7 +24,7 @@ EXPORTS = [
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
-    "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero",
+    "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
 ]
 
 
@@ -42,6 +42,12 @@ class GemmParams(C.Structure):
         ("ce_rows_a", C.c_int), ("ce_scale_a", C.c_float), ("ce_scale_b", C.c_float),
         ("split_k", C.c_int), ("split_ws", C.c_void_p), ("tile", C.c_int), ("cu_cap", C.c_int), ("colsum_out", C.c_void_p),
     ]
+
+
+class WgradItem(C.Structure):
+    """Mirror of DicWgradItem (include/dic_hip.h)."""
+    _fields_ = [("dY", C.c_void_p), ("ldy", C.c_int), ("X", C.c_void_p), ("ldx", C.c_int), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int)]
 
 
 def build(verbose: bool = False) -> str:
@@ -117,6 +123,9 @@ def lib():
         L.dic_step_prep.argtypes = [P, P, P, P, I, I, I, I, P, P, P, P, P, P, F, F, P]
         L.dic_randint.argtypes = [P, I, I, U64, P]
         L.dic_zero.argtypes = [P, I64, P]
+        L.dic_wgrad_group.argtypes = [C.POINTER(WgradItem), I, I, P, C.c_size_t, I, P]
+        L.dic_wgrad_group_ws_bytes.argtypes = [C.POINTER(WgradItem), I, I, I]
+        L.dic_wgrad_group_ws_bytes.restype = C.c_size_t
         L.dic_cfg_mix_fwd.argtypes = [P, P, P, I, I, F, P]
         L.dic_cfg_mix_bwd.argtypes = [P, P, P, I, I, F, P]
         L.dic_seq_sum.argtypes = [P, P, P, P, I, I, I, P]

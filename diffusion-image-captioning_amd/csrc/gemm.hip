@@ -23,6 +23,7 @@
 #include "common.h"
 #include "../../include/dic_hip.h"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 #ifndef DIC_GEMM_PF
@@ -648,8 +649,30 @@ __device__ __forceinline__ int key_a(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_b(int row) { return ((((row >> 3) & 3) << 1) | ((row >> 1) & 1)) & 7; }
 __device__ __forceinline__ int km_key(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
-template <class C, bool AKM, bool BKM, int EPI, int CNT>
-__global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
+// ---- grouped weight gradients (dic_wgrad_group) ------------------------------------------------------------------------------------------
+// The weight gradients of one encoder layer -- dW = dY^T X for the qkv, out-proj and the two FFN Linears: 27 + 9 + 36 + 36 tiles of 256 x 256,
+// each with the whole token dimension (272 K-steps at 17 408 tokens) as its contraction -- are ONE launch: every tile of every problem is cut
+// into the same number S of K-slices, and the S x 108 (slice, tile) units are walked by a persistent grid slice-slowest, so the workgroups
+// resident together read the same token range of dY / X (L2 reuse across the tiles that share a panel) and S is chosen for the WHOLE group
+// (S = 7: 756 units = 2.95 rounds of 256) instead of per problem (9 / 28 / 7 / 7, four launches each rounded up to whole rounds, four folds).
+// (A stream-K cut -- equal consecutive K-step ranges of the tile-major sequence, ~1/3 of the partial tiles -- was tried first: 2.5 % slower on
+// the step, because neighbouring workgroups then sit at unrelated token positions and every operand panel is streamed from HBM once per tile.)
+constexpr int WG_MAX_PROBLEMS = 8;
+struct WgradGroupDev {
+    int n, nk, split, per;                     // problems, K-steps per tile, K-slices per tile, K-steps per slice
+    int tiles, pad_;
+    int tile0[WG_MAX_PROBLEMS + 1];            // first global tile of each problem
+    int nbn[WG_MAX_PROBLEMS];
+    const void* A[WG_MAX_PROBLEMS];            // dY [T][lda] (k-major)
+    const void* B[WG_MAX_PROBLEMS];            // X  [T][ldb] (k-major)
+    float* Cout[WG_MAX_PROBLEMS];
+    float* cs[WG_MAX_PROBLEMS];                // bias gradient (column sums of dY) or NULL
+    int M[WG_MAX_PROBLEMS], N[WG_MAX_PROBLEMS], lda[WG_MAX_PROBLEMS], ldb[WG_MAX_PROBLEMS];
+    float* ws;                                 // [split * tiles] slabs of BM*BN + BM floats, slab = slice * tiles + tile
+};
+
+template <class C, bool AKM, bool BKM, int EPI, int CNT, bool GROUP>
+__device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGroupDev* grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<C>;
     using T = bf16_t;
@@ -693,8 +716,8 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
     // ---- per-lane DMA source offsets of the 1 KiB pieces this wave stages per operand advance by a uniform step.  (Kept in
     // VGPRs rather than the scalar offset operand: the descriptor's bounds check covers only the vector offset, and it is
     // that check which zero-fills ragged M/N/K.)
-    const unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;
-    const unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
+    unsigned stepA = AKM ? (unsigned)BK * (unsigned)p.lda * 2u : BK * 2u;          // (re-derived per problem by the grouped launch)
+    unsigned stepB = BKM ? (unsigned)BK * (unsigned)p.ldb * 2u : BK * 2u;
 
     // The LDS-DMA is issued through inline asm on purpose.  With the builtin, the compiler's waitcnt pass cannot tell which LDS bytes a
     // pending `buffer_load ... lds` will write, so it puts `s_waitcnt vmcnt(0)` in front of EVERY later ds_read: the K loop then
@@ -894,8 +917,28 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
 
     // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
     // addressing set-up is paid once per workgroup and the tail of the launch is balanced by unit order, not dispatch order.
-    const int total = total_units(p, tile_rows, G::BN);
+    const int total = GROUP ? 0 : total_units(p, tile_rows, G::BN);
     int unit = blockIdx.x;
+    // grouped launch: unit u of split * tiles, slice-slowest after the XCD-aware remap (consecutive logical units share an XCD's L2)
+    int slab = 0;
+    auto group_unit = [&](int u) {             // sets p (operands, shapes) and returns the unit's tile / K range
+        const int nwg = grp->split * grp->tiles;
+        const int q_ = nwg >> 3, r_ = nwg & 7, xcd = u & 7, slot = u >> 3;
+        const int lu = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
+        const int kz = lu / grp->tiles, tg = lu - kz * grp->tiles;
+        int pi = 0;
+        while (pi + 1 < grp->n && tg >= grp->tile0[pi + 1]) ++pi;
+        p.A = grp->A[pi]; p.B = grp->B[pi]; p.M = grp->M[pi]; p.N = grp->N[pi]; p.lda = grp->lda[pi]; p.ldb = grp->ldb[pi];
+        p.colsum_out = grp->cs[pi];
+        stepA = (unsigned)BK * (unsigned)p.lda * 2u; stepB = (unsigned)BK * (unsigned)p.ldb * 2u;
+        const int lt = tg - grp->tile0[pi], nbn_ = grp->nbn[pi];
+        TileId t_;
+        t_.bm = lt / nbn_; t_.bn = lt - t_.bm * nbn_; t_.nbn = nbn_; t_.kz = kz;
+        t_.kt0 = kz * grp->per < grp->nk ? kz * grp->per : grp->nk;
+        t_.kt1 = t_.kt0 + grp->per < grp->nk ? t_.kt0 + grp->per : grp->nk;
+        slab = lu;
+        return t_;
+    };
 #ifdef DIC_GEMM_TRACE      // measurement build only (scripts/experiments/gemm_trace.py): s_memtime stamps of wave 0 at the phase boundaries of every tile
     unsigned long long* trace = (unsigned long long*)p.tgt_logit + (size_t)blockIdx.x * 64;
     int trace_n = 0;
@@ -904,7 +947,12 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
 #define DIC_STAMP() do { } while (0)
 #endif
     DIC_STAMP();
-    TileId tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+    TileId tl;
+    if constexpr (GROUP) {
+        tl = group_unit(unit);
+    } else {
+        tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+    }
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
     for (;;) {
@@ -942,15 +990,29 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         // Both LDS stages are free now.  The next tile's first K-step goes out BEFORE this tile is written: its latency hides under the
         // epilogue, which touches no LDS (except the bias-gradient fold of the weight-gradient GEMMs, which uses the second stage).
         const TileId done = tl;
-        unit += gridDim.x;
-        const bool more = unit < total;
-        if (more) {
-            tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
-            setup(tl);
-            if (tl.kt0 < tl.kt1) issue(0);
-        }
         DicGemmParams pe = p;
-        if (p.split_k > 1) redirect_to_slab(pe, done.kz);
+        bool more;
+        if constexpr (GROUP) {
+            // the unit's partial tile goes to its own slab, in tile-local coordinates (the fold kernel adds a tile's slices up)
+            pe.C = grp->ws + (size_t)slab * (G::BM * G::BN + G::BM);
+            pe.ldc = G::BN; pe.M = G::BM; pe.N = G::BN; pe.out_f32 = 1; pe.accumulate = 0; pe.bias = nullptr; pe.R = nullptr; pe.p_drop = 0.f;
+            unit += gridDim.x;
+            more = unit < grp->split * grp->tiles;
+            if (more) {
+                tl = group_unit(unit);
+                setup(tl);
+                if (tl.kt0 < tl.kt1) issue(0);
+            }
+        } else {
+            unit += gridDim.x;
+            more = unit < total;
+            if (more) {
+                tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+                setup(tl);
+                if (tl.kt0 < tl.kt1) issue(0);
+            }
+            if (p.split_k > 1) redirect_to_slab(pe, done.kz);
+        }
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
             if (do_cs) {       // fold the thread groups through LDS, fixed order
                 float* red = (float*)(smem + G::STAGE);
@@ -962,7 +1024,8 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
 #pragma unroll
                     for (int gq = 0; gq < CS_GROUPS; ++gq) v += red[gq * G::BM + tid];
                     const int m = done.bm * G::BM + tid;
-                    if (m < p.M) {
+                    if constexpr (GROUP) ((float*)pe.C)[G::BM * G::BN + tid] = v;
+                    else if (m < p.M) {
                         if (p.split_k > 1) ((float*)pe.C)[(size_t)p.M * p.ldc + m] = v;
                         else p.colsum_out[m] = p.accumulate ? p.colsum_out[m] + v : v;
                     }
@@ -970,7 +1033,7 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
                 barrier_lds_only();
             }
         }
-        const int m_first = done.bm * tile_rows + row0_w, n_first = done.bn * G::BN + wn * G::WCOLS;
+        const int m_first = (GROUP ? 0 : done.bm * tile_rows) + row0_w, n_first = (GROUP ? 0 : done.bn * G::BN) + wn * G::WCOLS;
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
             epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn);
         } else {
@@ -979,6 +1042,43 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
         DIC_STAMP();
         if (!more) break;
     }
+}
+
+template <class C, bool AKM, bool BKM, int EPI, int CNT>
+__global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
+    gemm_bf16_body<C, AKM, BKM, EPI, CNT, false>(p, nullptr);
+}
+__global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmParams p, WgradGroupDev grp) {
+    gemm_bf16_body<T256, true, true, DIC_EPI_AFFINE, Geo<T256>::FM, true>(p, &grp);
+}
+// Fold of a grouped launch: tile t = sum of its K-slices' slabs in slice order (deterministic).  Block = (tile, 16-row chunk); 256 threads x
+// (4 rows x 4 columns).  The bias gradient rides in each slab's tail.
+__global__ __launch_bounds__(256) void wgrad_group_fold_kernel(WgradGroupDev grp) {
+    using G = Geo<T256>;
+    const int tg = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    int pi = 0;
+    while (pi + 1 < grp.n && tg >= grp.tile0[pi + 1]) ++pi;
+    const int lt = tg - grp.tile0[pi], nbn_ = grp.nbn[pi], bm = lt / nbn_, bn = lt - bm * nbn_;
+    const size_t slab_f = (size_t)G::BM * G::BN + G::BM;
+    const int r0 = chunk * 16 + (tid >> 6) * 4, col = (tid & 63) * 4;
+    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 csum{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = grp.cs[pi] != nullptr && bn == 0 && chunk == 0 && tid < 64;
+    for (int kz = 0; kz < grp.split; ++kz) {
+        const float* sl = grp.ws + ((size_t)kz * grp.tiles + tg) * slab_f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += *(const f32x4*)(sl + (size_t)(r0 + r) * G::BN + col);
+        if (do_cs) csum += *(const f32x4*)(sl + (size_t)G::BM * G::BN + tid * 4);
+    }
+    float* Cp = grp.Cout[pi];
+    const int M = grp.M[pi], N = grp.N[pi];
+    const int n = bn * G::BN + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = bm * G::BM + r0 + r;
+        if (m < M && n < N) *(f32x4*)(Cp + (size_t)m * N + n) = acc[r];
+    }
+    if (do_cs) { const int m = bm * G::BM + tid * 4; if (m < M) *(f32x4*)(grp.cs[pi] + m) = csum; }
 }
 
 // fold split-K slabs: out[i] (+)= sum_s ws[s][i]   (fixed order => deterministic); the optional tail of each slab holds the
@@ -1163,6 +1263,84 @@ int launch_layout(const DicGemmParams& p, int a_km, int b_km, int epi, hipStream
 
 }  // namespace
 
+// claims the next timing record of the measurement hooks below (false when profiling is off); thread-safe
+static bool prof_slot(hipEvent_t* a, hipEvent_t* b, double flops);
+
+// ---- grouped weight gradients: host side ---------------------------------------------------------------------------------------------------
+namespace {
+struct WgradPlan { WgradGroupDev dev; int grid; size_t ws_bytes; };
+// Collects the problems' tiles into one sequence and picks the number of K-slices for the whole group.
+int plan_wgrad_group(const DicWgradItem* items, int n, int T, int cu_cap, WgradPlan& pl) {
+    using G = Geo<T256>;
+    DIC_REQUIRE(n >= 1 && n <= WG_MAX_PROBLEMS && T > 0, "dic_wgrad_group: 1..8 problems");
+    WgradGroupDev& d = pl.dev;
+    d.n = n; d.nk = (T + 63) / 64; d.pad_ = 0;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const DicWgradItem& it = items[i];
+        DIC_REQUIRE(it.M > 0 && it.N > 0 && it.M % 256 == 0 && it.N % 8 == 0 && it.ldy % 8 == 0 && it.ldx % 8 == 0, "dic_wgrad_group: M must be a multiple of 256, N / ldy / ldx of 8");
+        DIC_REQUIRE(((uintptr_t)it.dY % 16) == 0 && ((uintptr_t)it.X % 16) == 0 && ((uintptr_t)it.dW % 16) == 0, "dic_wgrad_group: operands must be 16-byte aligned");
+        DIC_REQUIRE((long long)T * it.ldy * 2 < 0x7FFFFFFFll && (long long)T * it.ldx * 2 < 0x7FFFFFFFll, "dic_wgrad_group: operand too large for 32-bit buffer offsets");
+        d.tile0[i] = tiles;
+        d.nbn[i] = (it.N + G::BN - 1) / G::BN;
+        tiles += (it.M / G::BM) * d.nbn[i];
+        d.A[i] = it.dY; d.B[i] = it.X; d.Cout[i] = it.dW; d.cs[i] = it.db; d.M[i] = it.M; d.N[i] = it.N; d.lda[i] = it.ldy; d.ldb[i] = it.ldx;
+    }
+    for (int i = n; i <= WG_MAX_PROBLEMS; ++i) d.tile0[i] = tiles;
+    for (int i = n; i < WG_MAX_PROBLEMS; ++i) { d.nbn[i] = 1; d.A[i] = d.B[i] = nullptr; d.Cout[i] = d.cs[i] = nullptr; d.M[i] = d.N[i] = d.lda[i] = d.ldb[i] = 0; }
+    d.tiles = tiles;
+    int cus = device_cus();
+    if (cu_cap > 0 && cu_cap < cus) cus = cu_cap;
+    // K-slices per tile: minimise rounds x (slice length + per-unit fixed cost ~ 8 K-steps: first DMA + a 256 KB partial tile written at ~16 B/clk)
+    double best = 1e30;
+    int best_s = 1;
+    for (int S = 1; S <= 64 && (S == 1 || d.nk / S >= 8); ++S) {
+        const long long units = (long long)tiles * S;
+        const double cost = (double)((units + cus - 1) / cus) * ((d.nk + S - 1) / S + 8.0);
+        if (cost < best - 1e-9) { best = cost; best_s = S; }
+    }
+    d.split = best_s;
+    d.per = (d.nk + best_s - 1) / best_s;
+    const long long units = (long long)tiles * best_s;
+    pl.grid = (int)(units < cus ? units : cus);
+    pl.ws_bytes = (size_t)units * ((size_t)G::BM * G::BN + G::BM) * sizeof(float);
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t dic_wgrad_group_ws_bytes(const DicWgradItem* items, int n, int T, int cu_cap) {
+    WgradPlan pl;
+    if (plan_wgrad_group(items, n, T, cu_cap, pl) != 0) return 0;
+    return pl.ws_bytes;
+}
+extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws, size_t ws_bytes, int cu_cap, void* stream) {
+    using G = Geo<T256>;
+    WgradPlan pl;
+    int rc = plan_wgrad_group(items, n, T, cu_cap, pl);
+    if (rc) return rc;
+    DIC_REQUIRE(ws != nullptr && ws_bytes >= pl.ws_bytes && ((uintptr_t)ws % 16) == 0, "dic_wgrad_group: workspace too small (dic_wgrad_group_ws_bytes)");
+    pl.dev.ws = (float*)ws;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        attr_set[dev] = true;
+    }
+    DicGemmParams q{};
+    q.K = T; q.out_f32 = 1; q.split_k = 1; q.tile = 256;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = prof_slot(&e0, &e1, [&] { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * items[i].M * items[i].N * T; return f; }());
+    if (prof) (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), G::LDS, st, q, pl.dev);
+    const int tiles = pl.dev.tiles;
+    hipLaunchKernelGGL(wgrad_group_fold_kernel, dim3(tiles, G::BM / 16), dim3(256), 0, st, pl.dev);
+    if (prof) (void)hipEventRecord(e1, st);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- optional per-launch timing (bench.py roofline leg): hipEvents recorded on the launch stream around each GEMM
 namespace {
 struct ProfRec { hipEvent_t a, b; double flops; };
@@ -1186,15 +1364,21 @@ extern "C" int dic_prof_end(double* total_ms, double* total_flops, int* n_launch
     return 0;
 }
 
+static std::mutex g_prof_mu;
+static bool prof_slot(hipEvent_t* a, hipEvent_t* b, double flops) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof || g_prof_n >= g_prof_cap) return false;
+    ProfRec& r = g_prof[g_prof_n++];
+    r.flops = flops; *a = r.a; *b = r.b;
+    return true;
+}
 static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream);
 extern "C" int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream) {
-    if (g_prof && g_prof_n < g_prof_cap) {
-        ProfRec& r = g_prof[g_prof_n];
-        (void)hipEventRecord(r.a, (hipStream_t)stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof_slot(&e0, &e1, 2.0 * pp->M * pp->N * pp->K)) {
+        (void)hipEventRecord(e0, (hipStream_t)stream);
         int rc = dic_gemm_impl(dtype, a_km, b_km, epi, pp, stream);
-        (void)hipEventRecord(r.b, (hipStream_t)stream);
-        r.flops = 2.0 * pp->M * pp->N * pp->K;
-        ++g_prof_n;
+        (void)hipEventRecord(e1, (hipStream_t)stream);
         return rc;
     }
     return dic_gemm_impl(dtype, a_km, b_km, epi, pp, stream);

@@ -74,6 +74,21 @@ typedef struct DicGemmParams {
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
 
+/* Weight gradients of several nn.Linear layers in ONE launch (bf16 operands, fp32 results): dW_i [M_i][N_i] = dY_i^T X_i over the T tokens,
+ * db_i [M_i] = column sums of dY_i (optional) -- what autograd computes for the q/k/v, out-proj and FFN Linears of a transformer block
+ * (hf:183-185, 201, 221-223 backward).  dY_i is [T][ldy] and X_i [T][ldx] (both k-major for this contraction).  Every 256 x 256 tile of
+ * every problem is cut into the same number of K-slices (chosen for the whole group), the (slice, tile) units are walked slice-slowest by one
+ * persistent grid, partial tiles land in `ws` and a second launch folds them in slice order (deterministic).  M_i must be a multiple of 256, N_i / ldy / ldx of 8; at most 8 problems; `items` is a HOST array.          */
+typedef struct DicWgradItem {
+    const void* dY; int ldy;
+    const void* X; int ldx;
+    float* dW;                  /* [M][N], overwritten */
+    float* db;                  /* [M] or NULL */
+    int M, N;
+} DicWgradItem;
+size_t dic_wgrad_group_ws_bytes(const DicWgradItem* items, int n, int T, int cu_cap);
+int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws, size_t ws_bytes, int cu_cap, void* stream);
+
 /* Workspace sizes (bytes) the caller must provide -- kernels never allocate.
  *   dic_gemm_split_ws_bytes : split_ws of a split-K launch (split_k slabs of M*N fp32, + M when colsum_out is used)
  *   dic_ce_n_partials       : records per row written to `partial` by CE_PARTIAL for this N and tile (pass to dic_ce_combine)

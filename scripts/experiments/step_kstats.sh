@@ -2,8 +2,8 @@
 # per-kernel stats of the training step (rocprofv3 --kernel-trace --stats), current build and optionally an A/B library: step_kstats.sh [ab-lib-name]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/kstats; mkdir -p $O
-run() { tag=$1; shift
-  env "$@" rocprofv3 --kernel-trace --stats -d $O/$tag --output-format csv -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 10 --warmup 3 > $O/$tag.log 2>&1
+run() { tag=$1; shift; rm -rf $O/$tag
+  env "$@" rocprofv3 --kernel-trace --stats -d $O/$tag --output-format csv -- python $R/bench.py --quick --no-roofline --steps 10 --warmup 3 > $O/$tag.log 2>&1
   f=$(find $O/$tag -name "*kernel_stats.csv" | head -1); cp $f $O/${tag}_kernel_stats.csv
   python - "$f" <<'PY'
 import csv,sys,re

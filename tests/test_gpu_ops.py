@@ -644,3 +644,36 @@ def test_step_prep_randint_zero(L):
     ok(L.dic_zero(p(z) + 16, 16 * 50, stream()), L)
     torch.cuda.synchronize()
     assert bool((z[4:204] == 0).all()) and bool((z[:4] == 3).all()) and bool((z[204:] == 3).all())
+
+
+@pytest.mark.parametrize("T,cu_cap", [(64 * 11 + 5, 0), (64 * 40, 0), (64 * 3 + 7, 0), (64 * 70 + 1, 7)])
+def test_wgrad_group_matches_separate_products(L, T, cu_cap):
+    """dic_wgrad_group: several dW = dY^T X (+ db = colsum dY) in one split-K launch + fold, against fp64; bit-identical when repeated; a small
+    cu_cap makes every workgroup walk many (slice, tile) units."""
+    shapes = [(768, 256, True), (256, 768, False), (512, 264, True)]            # (M, N, with bias gradient)
+    g = torch.Generator().manual_seed(T)
+    items, keep, refs = [], [], []
+    for M, N, has_b in shapes:
+        dY, X = torch.randn(T, M, generator=g), torch.randn(T, N, generator=g)
+        dYd, Xd = dev(dY, torch.bfloat16), dev(X, torch.bfloat16)
+        dW = torch.full((M, N), float("nan"), device="cuda")
+        db = torch.full((M,), float("nan"), device="cuda") if has_b else None
+        keep += [dYd, Xd, dW, db]
+        items.append(dic._lib.WgradItem(dY=p(dYd), ldy=M, X=p(Xd), ldx=N, dW=p(dW), db=p(db), M=M, N=N))
+        refs.append((dYd.float().cpu().double().t() @ Xd.float().cpu().double(), dYd.float().cpu().double().sum(0), dW, db))
+    arr = (dic._lib.WgradItem * len(items))(*items)
+    nbytes = L.dic_wgrad_group_ws_bytes(arr, len(items), T, cu_cap)
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, device="cuda")
+    outs = []
+    for _ in range(2):
+        ok(L.dic_wgrad_group(arr, len(items), T, p(ws), nbytes, cu_cap, stream()), L)
+        torch.cuda.synchronize()
+        outs.append([(r[2].clone(), None if r[3] is None else r[3].clone()) for r in refs])
+        ws.fill_(float("nan"))                                                     # nothing stale may be folded
+    for (w_ref, b_ref, dW, db), (w0, b0), (w1, b1) in zip(refs, outs[0], outs[1]):
+        assert relerr(w0, w_ref) < 2e-6 and torch.equal(w0, w1)
+        if db is not None:
+            assert relerr(b0, b_ref) < 2e-6 and torch.equal(b0, b1)
+    # too small a workspace is refused
+    assert L.dic_wgrad_group(arr, len(items), T, p(ws), nbytes - 16, cu_cap, stream()) != 0
