@@ -449,12 +449,13 @@ class Denoiser:
             if not (use_side and batch_side):
                 flush_side()
 
-        # DIC_WGRAD_GROUP=1 (bf16): the weight gradients of a layer are collected and go out as grouped launches (dic_wgrad_group: one K-slice
-        # count for all the tiles, 1-2 launches + folds per layer instead of 4 + 4).  Measured on the step: 2.4 % faster with everything on
-        # one stream (15.79 vs 16.16 ms), 1-2 % SLOWER with the weight gradients on their second stream -- a 256-workgroup persistent kernel
-        # holding 128 KB of LDS per CU for ~400 us keeps the main stream's GEMMs off the CUs for that long, four ~100 us launches interleave
-        # with them.  The shipped two-stream configuration therefore keeps the per-GEMM launches; the grouped path stays available.
-        group = self.bf16 and _os.environ.get("DIC_WGRAD_GROUP", "0") == "1"
+        # Grouped weight gradients (dic_wgrad_group: one K-slice count for all the tiles of several Linears, one launch + one fold).
+        # DIC_WGRAD_GROUP=1 groups all four Linears of a layer: 2.4 % faster with everything on one stream (15.79 vs 16.16 ms) but 1-2 %
+        # SLOWER with the weight gradients on their second stream -- a 256-workgroup persistent kernel holding 128 KB of LDS per CU for
+        # ~400 us keeps the main stream's GEMMs off the CUs for that long, ~100 us launches interleave with them.  The default, 2, groups only
+        # out-proj + qkv, the two with too few tiles to split well on their own (9 + 27 tiles x 7 slices = one round): 0.5-0.8 % on the step.
+        gmode = _os.environ.get("DIC_WGRAD_GROUP", "2")       # "0": none; "1": every Linear of the layer; "2": out-proj + qkv
+        group = self.bf16 and gmode in ("1", "2")
         items = []
 
         def flush_group():
@@ -471,7 +472,7 @@ class Denoiser:
         def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
             bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum)."""
-            if group and M % 256 == 0 and N % 8 == 0:
+            if group and M % 256 == 0 and N % 8 == 0 and (gmode == "1" or slot.endswith(("Wo", "Wqkv"))):
                 items.append(_lib.WgradItem(dY=dY, ldy=lda, X=X, ldx=ldb, dW=P.ptr(slot, "G"), db=P.ptr(bias_slot, "G") if bias_slot is not None else 0, M=M, N=N))
                 return
             sk, tile = pick_split_k(M, N, T, 64 if self.bf16 else 32)
