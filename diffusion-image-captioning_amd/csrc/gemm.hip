@@ -396,6 +396,15 @@ __device__ __forceinline__ void barrier_lds_only() {
     __builtin_amdgcn_s_barrier();
 }
 
+// value held by lane t ^ 8 of the same 16-lane row (DPP row_ror:8)
+__device__ __forceinline__ i32x4 xchg8(const i32x4& x) {
+    i32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = __builtin_amdgcn_update_dpp(0, x[r], 0x128, 0xF, 0xF, false);
+    return y;
+}
+__device__ __forceinline__ i32x4 sel4(bool c, const i32x4& a, const i32x4& b) { return c ? a : b; }
+
 // One wave's accumulators -> HBM.  m_first: global row of the wave's fragment 0 (CNT fragments of 16 rows); n_first: global column of
 // the wave's first column.
 // gfx950 has ONE counter (vmcnt) for loads and stores, and they complete out of order with respect to each other: any wait for a
@@ -408,7 +417,56 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     using G = Geo<C>;
     using T = bf16_t;
     const int g = lane >> 4, t = lane & 15;
-    auto put = [&](int i, int q, T* c, bool ok, const f32x4& x0, const f32x4& x1) { if (ok) *(i32x4*)c = pack8f(x0, x1); };
+    // FULL-LINE STORES.  In the accumulator layout lane (g,t) owns, per 16-row fragment i, row t and the two 16-byte chunks g and 4+g of the
+    // wave's 128-byte output row, so a store instruction per (i, chunk set) writes 16 rows x 64 B: half cache lines.  Measured on an
+    // otherwise idle CU (scripts/experiments/stprobe.hip): 32 B/clk with that map, 82-86 B/clk when one instruction writes 8 rows x 128 B.
+    // So lanes t and t^8 swap one chunk (4 DPP moves): instruction 0 then writes rows 0-7 of the fragment, instruction 1 rows 8-15,
+    // lane (g,t) at chunk g + 4*(t>>3) of row (t&7).  Same trick for fp32 outputs (a lane's 8 columns are 32 B: chunks 2g, 2g+1 of the
+    // 128-byte line of a 32-column group) and, mirrored, for the side-input loads (residual, GELU' pre-activation).
+    // Streaming (nt) stores for the FFN pre-activation / activation pair only: 214 MB written per launch pushed the weight panels out of the
+    // XCD's L2 between rounds of the persistent grid (PMC: 149 MB fetched for 31 MB of operands); with nt the launch is 14 % faster
+    // (130 -> 112 us, cold operands).  NOT for the other outputs: split-K slabs are re-read by the fold right away (nt: +20-50 %), the
+    // GELU' and residual epilogues measured 0-6 % slower with nt.
+    constexpr bool NT = EPI == DIC_EPI_BIAS_GELU;
+    static_assert(G::NP == 2, "line stores pair the two 8-column groups of a 64-column wave slab");
+    const bool hi = t >= 8;
+    const int lrow = t & 7, lcol = 8 * (g + 4 * (t >> 3));          // row within an 8-row half fragment; column of this lane's chunk in line order
+    auto st16 = [&](T* c, const i32x4& v) { if constexpr (NT) __builtin_nontemporal_store(v, (i32x4*)c); else *(i32x4*)c = v; };
+    // bf16 row pair of fragment i: P0 / P1 = this lane's chunks for column groups q = 0 / 1; n_lim = first invalid column (multiple of 8)
+    auto put_lines = [&](int i, T* Cb, size_t ld, const i32x4& P0, const i32x4& P1, int n_lim) {
+        const i32x4 Y = xchg8(sel4(hi, P0, P1));
+        const i32x4 D0 = sel4(hi, Y, P0), D1 = sel4(hi, P1, Y);
+        const int m = m_first + 16 * i + lrow, n = n_first + lcol;
+        if (n < n_lim) {
+            if (m < p.M) st16(Cb + (size_t)m * ld + n, D0);
+            if (m + 8 < p.M) st16(Cb + (size_t)(m + 8) * ld + n, D1);
+        }
+    };
+    // mirrored load: full-line loads now, this lane's chunks (q = 0, q = 1) of row t of fragment i after get_lines_finish
+    auto get_lines_issue = [&](int i, const T* Rb, size_t ld, i32x4& L0, i32x4& L1, int n_lim) {
+        const int m = m_first + 16 * i + lrow, n = n_first + lcol;
+        L0 = i32x4{0, 0, 0, 0}; L1 = L0;
+        if (n < n_lim) {
+            if (m < p.M) L0 = *(const i32x4*)(Rb + (size_t)m * ld + n);
+            if (m + 8 < p.M) L1 = *(const i32x4*)(Rb + (size_t)(m + 8) * ld + n);
+        }
+    };
+    auto get_lines_finish = [&](i32x4& L0, i32x4& L1) {          // in place: L0 -> chunk of q = 0, L1 -> chunk of q = 1
+        const i32x4 Y = xchg8(sel4(hi, L0, L1));
+        const i32x4 Q0 = sel4(hi, Y, L0), Q1 = sel4(hi, L1, Y);
+        L0 = Q0; L1 = Q1;
+    };
+    // fp32 pair of (fragment i, column group q): x0 / x1 = this lane's columns 8g..8g+3 / 8g+4..8g+7
+    auto put_lines_f32 = [&](int i, int q, float* Cb, size_t ld, const f32x4& x0, const f32x4& x1) {
+        const i32x4 X0 = __builtin_bit_cast(i32x4, x0), X1 = __builtin_bit_cast(i32x4, x1);
+        const i32x4 Y = xchg8(sel4(hi, X0, X1));
+        const i32x4 D0 = sel4(hi, Y, X0), D1 = sel4(hi, X1, Y);
+        const int m = m_first + 16 * i + lrow, n = n_first + 32 * q + 4 * (2 * g + (t >> 3));
+        if (n < p.N) {
+            if (m < p.M) *(i32x4*)(Cb + (size_t)m * ld + n) = D0;
+            if (m + 8 < p.M) *(i32x4*)(Cb + (size_t)(m + 8) * ld + n) = D1;
+        }
+    };
     int nc[G::NP];
     bool v0[G::NP], v1[G::NP];
 #pragma unroll
@@ -427,28 +485,22 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     }
     if constexpr (EPI == DIC_EPI_AFFINE) {
         const float inv_keep = drop_inv_keep(p.p_drop);
-        const bool general = p.accumulate || (p.R != nullptr && (!PF || (p.N & 7) != 0));
+        const bool general = p.accumulate || (p.R != nullptr && !PF) || ((p.N & 7) != 0 && (p.R != nullptr || !p.out_f32));
         if (!general) {
             i32x4 pre[PF ? CNT : 1][PF ? G::NP : 1];
             const T* R = (const T*)p.R;
             if constexpr (PF) {
                 if (R) {
 #pragma unroll
-                    for (int i = 0; i < CNT; ++i) {
-                        const int m = m_first + 16 * i + t;
-#pragma unroll
-                        for (int q = 0; q < G::NP; ++q) {
-                            pre[i][q] = i32x4{0, 0, 0, 0};
-                            if (m < p.M && v1[q]) pre[i][q] = *(const i32x4*)(R + (size_t)m * p.ldr + nc[q]);
-                        }
-                    }
+                    for (int i = 0; i < CNT; ++i) get_lines_issue(i, R, (size_t)p.ldr, pre[i][0], pre[i][1], p.N);
                     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the residual tile is in registers
                 }
             }
 #pragma unroll
             for (int i = 0; i < CNT; ++i) {
                 const int m = m_first + 16 * i + t;
-                const bool mok = m < p.M;
+                i32x4 P[G::NP];
+                if constexpr (PF) { if (R) get_lines_finish(pre[i][0], pre[i][1]); }
 #pragma unroll
                 for (int q = 0; q < G::NP; ++q) {
                     f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
@@ -459,16 +511,10 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                     if constexpr (PF) {
                         if (R) { f32x4 r0, r1; unpack8(pre[i][q], r0, r1); x0 += r0; x1 += r1; }
                     }
-                    if (p.out_f32) {
-                        float* c = (float*)p.C + (size_t)m * p.ldc + nc[q];
-                        if (mok && v0[q]) *(f32x4*)c = x0;
-                        if (mok && v1[q]) *(f32x4*)(c + 4) = x1;
-                    } else {
-                        T* c = (T*)p.C + (size_t)m * p.ldc + nc[q];
-                        if (v1[q]) put(i, q, c, mok, x0, x1);
-                        else if (mok && v0[q]) Elem<T>::st4(c, x0);
-                    }
+                    if (p.out_f32) put_lines_f32(i, q, (float*)p.C, (size_t)p.ldc, x0, x1);
+                    else P[q] = pack8f(x0, x1);
                 }
+                if (!p.out_f32) put_lines(i, (T*)p.C, (size_t)p.ldc, P[0], P[1], p.N);
             }
         } else {
             // rare combinations (accumulating into an fp32 C; a residual with N % 8 != 0): loads inside the loop.  Still fully unrolled:
@@ -505,40 +551,36 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {                 // N % 8 == 0 is required for this epilogue
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int m = m_first + 16 * i + t;
-            const bool mok = m < p.M;
+            i32x4 U[G::NP], A[G::NP];
 #pragma unroll
             for (int q = 0; q < G::NP; ++q) {
                 f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
-                if (mok && v1[q]) *(i32x4*)((T*)p.aux + (size_t)m * p.ldaux + nc[q]) = pack8f(x0, x1);     // pre-activation u (for GELU')
+                U[q] = pack8f(x0, x1);                                // pre-activation u (for GELU')
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
-                put(i, q, (T*)p.C + (size_t)m * p.ldc + nc[q], mok && v1[q], x0, x1);
+                A[q] = pack8f(x0, x1);
             }
+            put_lines(i, (T*)p.aux, (size_t)p.ldaux, U[0], U[1], p.N);
+            put_lines(i, (T*)p.C, (size_t)p.ldc, A[0], A[1], p.N);
         }
     } else if constexpr (EPI == DIC_EPI_GELU_BWD) {                  // dU = acc * gelu'(U)
         i32x4 pre[CNT][G::NP];
 #pragma unroll
-        for (int i = 0; i < CNT; ++i) {
-            const int m = m_first + 16 * i + t;
-#pragma unroll
-            for (int q = 0; q < G::NP; ++q) {
-                pre[i][q] = i32x4{0, 0, 0, 0};
-                if (m < p.M && v1[q]) pre[i][q] = *(const i32x4*)((const T*)p.aux + (size_t)m * p.ldaux + nc[q]);
-            }
-        }
+        for (int i = 0; i < CNT; ++i) get_lines_issue(i, (const T*)p.aux, (size_t)p.ldaux, pre[i][0], pre[i][1], p.N);
         __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int m = m_first + 16 * i + t;
+            get_lines_finish(pre[i][0], pre[i][1]);
+            i32x4 P[G::NP];
 #pragma unroll
             for (int q = 0; q < G::NP; ++q) {
                 f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1], u0, u1;
                 unpack8(pre[i][q], u0, u1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
-                put(i, q, (T*)p.C + (size_t)m * p.ldc + nc[q], m < p.M && v1[q], x0, x1);
+                P[q] = pack8f(x0, x1);
             }
+            put_lines(i, (T*)p.C, (size_t)p.ldc, P[0], P[1], p.N);
         }
     } else if constexpr (EPI == DIC_EPI_CE_DLOGITS) {                // (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
         float r_lse[CNT], r_sc[CNT];
@@ -557,6 +599,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             const int m = m_first + 16 * i + t;
             const float lse = r_lse[i], sc = r_sc[i];
             const long long tg = r_tg[i];
+            i32x4 P[G::NP];
 #pragma unroll
             for (int q = 0; q < G::NP; ++q) {
                 f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
@@ -568,8 +611,9 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                     if ((long long)(n + 4 + r) == tg) q1 -= 1.0f;
                     x0[r] = q0 * sc; x1[r] = q1 * sc;
                 }
-                put(i, q, (T*)p.C + (size_t)m * p.ldc + n, m < p.M && n < p.ldc, x0, x1);
+                P[q] = pack8f(x0, x1);
             }
+            put_lines(i, (T*)p.C, (size_t)p.ldc, P[0], P[1], p.ldc);          // only rows < M are written
         }
     }
 }
@@ -735,6 +779,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         return r;
     };
     auto dma16 = [](unsigned voff, const i32x4& rsrc, unsigned lds_addr) {   // 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1 KiB)
+#ifdef DIC_GEMM_ABL_NODMA       // ablation builds (scripts/experiments/gemm_ablate.sh): results are garbage, only the timing is read
+        return;
+#endif
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
     };
     // every wave's DMA pieces of the stage being published have landed, and every wave is done reading the stage being recycled
@@ -828,6 +875,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         if constexpr (!BKM) { aB[0] = sbB + (unsigned)ofB[0]; aB[1] = sbB + ((unsigned)ofB[0] ^ 64u); }
         auto read_frag = [&](bf16x8& dst, bool km, unsigned addr, auto imm_c, auto rowb4_c) {
             constexpr int imm = decltype(imm_c)::value, hi = decltype(rowb4_c)::value;
+#ifdef DIC_GEMM_ABL_NOREAD
+            { i32x4 v; asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr)); dst = __builtin_bit_cast(bf16x8, v); return; }
+#endif
             if (!km) {
                 i32x4 v;
                 asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(v) : "v"(addr), "i"(imm));
@@ -874,9 +924,11 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
                 asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fa[sidx % RING]) : "i"(after));
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifndef DIC_GEMM_ABL_NOMFMA
 #pragma unroll
             for (int j = 0; j < G::FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[sidx % RING], acc[i][j], 0, 0, 0);
+#endif
             // Where in the K-step the next stage's DMA is issued (DIC_GEMM_ISSUE_AT).  With operands resident in L2 / the infinity cache, issuing
             // behind the first few MFMA groups is 2-5 % faster (at the head of the K-step the ~8 x 60-180 issue cycles per wave sit in front of
             // the first MFMA of both waves of a SIMD); with operands coming from HBM -- the training step: every operand was just written by
@@ -942,11 +994,14 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #ifdef DIC_GEMM_TRACE      // measurement build only (scripts/experiments/gemm_trace.py): s_memtime stamps of wave 0 at the phase boundaries of every tile
     unsigned long long* trace = (unsigned long long*)p.tgt_logit + (size_t)blockIdx.x * 64;
     int trace_n = 0;
-#define DIC_STAMP() do { if (trace && tid == 0 && trace_n < 64) trace[trace_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIC_STAMP() do { if (trace && tid == 0 && trace_n < 61) trace[trace_n++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DIC_STAMP() do { } while (0)
 #endif
     DIC_STAMP();
+#ifdef DIC_GEMM_TRACE
+    if (trace && tid == 0) trace[62] = __builtin_amdgcn_s_memrealtime();     // 100 MHz wall clock next to the shader clock: their ratio is the GPU clock under this kernel's load
+#endif
     TileId tl;
     if constexpr (GROUP) {
         tl = group_unit(unit);
@@ -1042,6 +1097,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         DIC_STAMP();
         if (!more) break;
     }
+#ifdef DIC_GEMM_TRACE
+    if (trace && tid == 0) { trace[63] = __builtin_amdgcn_s_memrealtime(); trace[61] = __builtin_amdgcn_s_memtime(); }
+#endif
 }
 
 template <class C, bool AKM, bool BKM, int EPI, int CNT>
@@ -1408,7 +1466,7 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (p.split_k > 1)
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
-    if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % 4 == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
+    if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % (dtype == DIC_BF16 ? 8 : 4) == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DIC_BF16) return launch_layout<bf16_t>(p, a_km, b_km, epi, st);
     if (dtype == DIC_F32) return launch_layout<float>(p, a_km, b_km, epi, st);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-phase timeline of the bf16 GEMM from s_memtime stamps (needs the trace build: csrc/gemm.hip compiled with -DDIC_GEMM_TRACE,
 linked into ab/libdic_trace.so and loaded with DIC_HIP_LIB).  Wave 0 of every workgroup stamps: kernel entry; per tile: first K-step
-landed (loop top) / K loop done / epilogue issued.  Prints the mean duration of each phase over workgroups, in s_memtime ticks (100 MHz
-constant clock on gfx950: 10 ns) and the spread of the loop-top stamp across workgroups (how much in lockstep the chip runs)."""
+landed (loop top) / K loop done / epilogue issued.  Prints the mean duration of each phase over workgroups, in s_memtime ticks (shader clock; the build also stamps s_memrealtime, 100 MHz, at entry and exit so the
+clock the kernel actually ran at is printed) and the spread of the loop-top stamp across workgroups (how much in lockstep the chip runs)."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 import torch
@@ -34,7 +34,10 @@ def run(name, M, N, K, a_km=0, b_km=0, epi=0, resid=False, tile=256):
     t = tr.cpu().numpy().reshape(2048, 64)
     wg = t[t[:, 0] > 0]
     base = wg[:, 0].min()
+    clk = (wg[:, 61] - wg[:, 0]) / np.maximum(wg[:, 63] - wg[:, 62], 1) * 0.1      # shader ticks per 10 ns tick of the 100 MHz clock -> GHz
+    wg = wg.copy(); wg[:, 61:] = 0
     ntile = ((wg != 0).sum(1) - 1) // 3
+    print(f"   shader clock while the kernel ran: {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})")
     print(f"== {name}: M={M} N={N} K={K}  {len(wg)} workgroups, tiles/workgroup {ntile.min()}..{ntile.max()}, event time {e0.elapsed_time(e1)*1e3:.1f} us")
     print(f"   entry spread {(wg[:,0].max()-base)/1000:.2f} kcyc; last stamp {(wg.max()-base)/1000:.2f} kcyc after the first entry")
     for k in range(int(ntile.max())):
