@@ -133,7 +133,10 @@ __device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, i
     const int ntiles = nbm * nbn;
     t.kz = pid / ntiles;
     const int lin = pid - t.kz * ntiles;
-    constexpr int GW = 8;
+#ifndef DIC_GEMM_GW
+#define DIC_GEMM_GW 8
+#endif
+    constexpr int GW = DIC_GEMM_GW;
     const int grp = lin / (GW * nbm), rem = lin - grp * (GW * nbm);
     const int w = min(GW, nbn - grp * GW);
     t.bm = rem / w;
