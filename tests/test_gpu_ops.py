@@ -175,6 +175,40 @@ def test_gemm_bf16_epilogue_general_path(L, tile):
     assert relerr(Cp[:, :N].float(), acc) < 6e-3 and bool((Cp[:, N:] == 7.0).all())
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M", [301, 509])
+def test_gemm_line_store_edges(L, tile, M):
+    """The epilogue writes whole cache lines by swapping a chunk between lanes t and t^8 (rows r and r+8 of a fragment): the last
+    valid row falls inside an 8-row half (M % 8 = 5), the fp32 output has N % 8 == 4 (the line's last 16-byte chunk is the
+    row's last), every buffer has guard columns / rows that must keep their fill value."""
+    N, K = 776, 128
+    g = torch.Generator().manual_seed(M + tile)
+    A, B = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3
+    bias, Rr = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd, Rd = dev(A, torch.bfloat16), dev(B, torch.bfloat16), dev(Rr, torch.bfloat16)
+    acc = Ad.float().cpu().double() @ Bd.float().cpu().double().t()
+    Cd = torch.full((M + 9, N + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 8, bias=p(dev(bias)), R=p(Rd), ldr=N, tile=tile)
+    assert relerr(Cd[:M, :N].float(), acc + bias.double() + Rd.float().cpu().double()) < 6e-3
+    assert bool((Cd[:M, N:] == 7.0).all()) and bool((Cd[M:] == 7.0).all())
+    N2 = 772
+    Cf = torch.full((M + 9, N2 + 4), 7.0, dtype=torch.float32, device="cuda")
+    gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cf), M=M, N=N2, K=K, lda=K, ldb=K, ldc=N2 + 4, out_f32=1, tile=tile)
+    assert relerr(Cf[:M, :N2], acc[:, :N2]) < 2e-6
+    assert bool((Cf[:M, N2:] == 7.0).all()) and bool((Cf[M:] == 7.0).all())
+    U = torch.full((M + 9, N + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    G_ = torch.full((M + 9, N + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, 0, 0, 1, A=p(Ad), B=p(Bd), C=p(G_), M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 8, bias=p(dev(bias)), aux=p(U), ldaux=N + 8, tile=tile)
+    assert relerr(U[:M, :N].float(), acc + bias.double()) < 1e-2 and relerr(G_[:M, :N].float(), R.gelu(U[:M, :N].float().cpu().double())) < 1e-2
+    assert bool((U[:M, N:] == 7.0).all()) and bool((U[M:] == 7.0).all()) and bool((G_[:M, N:] == 7.0).all()) and bool((G_[M:] == 7.0).all())
+    Dd = torch.full((M + 9, N + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, 0, 0, 2, A=p(Ad), B=p(Bd), C=p(Dd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 8, aux=p(U), ldaux=N + 8, tile=tile)
+    uu = U[:M, :N].float().cpu().double().requires_grad_(True)
+    R.gelu(uu).sum().backward()
+    assert relerr(Dd[:M, :N].float(), acc * uu.grad) < 1e-2
+    assert bool((Dd[:M, N:] == 7.0).all()) and bool((Dd[M:] == 7.0).all())
+
+
 @pytest.mark.parametrize("split", [1, 3])
 def test_gemm_fused_bias_gradient(L, split):
     """bf16 weight-gradient GEMM also returns colsum(dY) (the bias gradient) from the LDS-resident A tiles."""
