@@ -597,6 +597,8 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             r_sc[i] = ok ? row_scale(p, m) : 0.f;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        // (a leaner per-element sequence -- fma + v_exp, 32-bit target compare, no bounds tests off the last tile column -- changed nothing:
+        // this epilogue is bound by its 1 GB of stores, not by VALU)
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             const int m = m_first + 16 * i + t;
@@ -637,31 +639,60 @@ __device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[CNT][Geo<C>::FN
         const int m = m_first + i * 16 + t;
         tgs[i] = (m < p.M && p.tgt) ? p.tgt[m] : -1;
     }
+    constexpr float L2E = 1.4426950408889634f;
+    const bool full = n_first + G::WCOLS <= p.N;            // wave-uniform: only the vocabulary's last tile column is ragged
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
         const int m = m_first + i * 16 + t;
         const long long tg = tgs[i];
-        float mx = -INFINITY;
+        float mx = -INFINITY, sm = 0.f;
         int ix = 0x7fffffff;
+        if (full) {
+            // short path (no bounds tests): max by a max3 chain, first argmax by a descending equality scan over compile-time column
+            // offsets, target logit by a 32-bit compare against the lane-relative target column, exp as fma + v_exp
+            const long long tgl = tg - (long long)(n_first + 8 * g);
+            const int tl = (tgl >= 0 && tgl < G::WCOLS) ? (int)tgl : -1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)            // (j, r) ascending = column ascending within a lane: the first maximum keeps the lowest index
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n_first + frag_col(j, g, r);
-                const float x = acc[i][j][r];
-                if (n < p.N) {
-                    if (x > mx) { mx = x; ix = n; }
-                    if ((long long)n == tg) p.tgt_logit[m] = x;
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
+            int il = 0;
+            float tv = 0.f;
+#pragma unroll
+            for (int j = 3; j >= 0; --j)
+#pragma unroll
+                for (int r = 3; r >= 0; --r) {
+                    const int c = 32 * (j >> 1) + 4 * (j & 1) + r;                    // column relative to n_first + 8g (= frag_col(j, g, r) - 8g)
+                    il = (acc[i][j][r] == mx) ? c : il;
+                    tv = (tl == c) ? acc[i][j][r] : tv;
                 }
-            }
-        float sm = 0.f;
+            ix = n_first + 8 * g + il;
+            if (((tl >= 0 && tl < 8) || (tl >= 32 && tl < 40)) && m < p.M) p.tgt_logit[m] = tv;
+            const float mx2 = mx * L2E;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n_first + frag_col(j, g, r);
-                if (n < p.N) sm += __expf(acc[i][j][r] - mx);
-            }
+                for (int r = 0; r < 4; ++r) sm += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][j][r], L2E, -mx2));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)            // (j, r) ascending = column ascending within a lane: the first maximum keeps the lowest index
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n_first + frag_col(j, g, r);
+                    const float x = acc[i][j][r];
+                    if (n < p.N) {
+                        if (x > mx) { mx = x; ix = n; }
+                        if ((long long)n == tg) p.tgt_logit[m] = x;
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n_first + frag_col(j, g, r);
+                    if (n < p.N) sm += __expf(acc[i][j][r] - mx);
+                }
+        }
 #pragma unroll
         for (int o = 16; o <= 32; o <<= 1) {       // merge the 4 lanes (g = 0..3) that share row m
             float mx2 = __shfl_xor(mx, o, 64), sm2 = __shfl_xor(sm, o, 64);
