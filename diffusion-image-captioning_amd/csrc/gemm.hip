@@ -415,8 +415,14 @@ __device__ __forceinline__ i32x4 sel4(bool c, const i32x4& a, const i32x4& b) { 
 // side input was loaded per row).  So all side inputs of the wave's tile are loaded first, one vmcnt(0) covers them, and the rest is
 // math + stores with nothing to wait on.  (The bias is added to the accumulators before the side tile is requested: its registers
 // are free again by then.)
-template <class C, int EPI, bool PF, int CNT>
-__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first, int lane) {
+// `issue_next` starts the next tile (address set-up + the first K-step's LDS-DMA).  It is called once, AFTER the last load this epilogue
+// waits for and BEFORE its first store: a wait for the bias / residual / pre-activation loads is a `vmcnt(0)` and would otherwise also
+// wait ~2.4 k cycles for that DMA (the s_memtime trace showed it in front of every epilogue), while behind the wait the DMA's latency
+// hides under the stores.
+template <class C, int EPI, bool PF, int CNT, class IssueNext, class Stamp>
+__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first, int lane, IssueNext&& issue_next_,
+                                                Stamp&& stamp) {
+    auto issue_next = [&]() { stamp(); issue_next_(); stamp(); };          // (stamp: s_memtime in the trace build, nothing otherwise)
     using G = Geo<C>;
     using T = bf16_t;
     const int g = lane >> 4, t = lane & 15;
@@ -434,42 +440,55 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     static_assert(G::NP == 2, "line stores pair the two 8-column groups of a 64-column wave slab");
     const bool hi = t >= 8;
     const int lrow = t & 7, lcol = 8 * (g + 4 * (t >> 3));          // row within an 8-row half fragment; column of this lane's chunk in line order
-    auto st16 = [&](T* c, const i32x4& v) { if constexpr (NT) __builtin_nontemporal_store(v, (i32x4*)c); else *(i32x4*)c = v; };
-    // bf16 row pair of fragment i: P0 / P1 = this lane's chunks for column groups q = 0 / 1; n_lim = first invalid column (multiple of 8)
-    auto put_lines = [&](int i, T* Cb, size_t ld, const i32x4& P0, const i32x4& P1, int n_lim) {
+    // Buffer addressing (32-bit lane offsets against a descriptor anchored at the wave's first row): no 64-bit address arithmetic and no
+    // exec-mask branches per store -- rows >= M fall outside the descriptor's range and are dropped (loads: read as zero) by the hardware,
+    // a lane whose 16-byte chunk lies beyond the last column gets an offset that is out of range for every row.  (The pointer form
+    // cost ~12 of the ~25 instructions per store, and the epilogue is issue-bound: s_memtime puts 4-13 k cycles of VALU per wave behind
+    // every tile, two waves per SIMD.)
+    struct LineBuf { __amdgpu_buffer_rsrc_t rs; unsigned off, row8; };
+    auto line_buf = [&](const void* base, int ld, int es, int col, int n_lim) {
+        long long bytes = (long long)(p.M - m_first) * ld * es;
+        bytes = bytes < 0 ? 0 : (bytes > 0x7FFFFFFFll ? 0x7FFFFFFFll : bytes);          // 16 rows x ld never get near 2 GB; 0x80000000 + that never wraps
+        LineBuf Lb;
+        Lb.rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (size_t)m_first * ld * es), 0, (int)bytes, 0x00020000);
+        Lb.row8 = 8u * (unsigned)ld * (unsigned)es;
+        Lb.off = col < n_lim ? ((unsigned)lrow * (unsigned)ld + (unsigned)col) * (unsigned)es : 0x80000000u;
+        return Lb;
+    };
+    constexpr int AUX = NT ? 2 : 0;                                   // cache-policy bits of the buffer instruction: 2 = nt
+    // bf16 row pair of fragment i: P0 / P1 = this lane's chunks for column groups q = 0 / 1
+    auto put_lines = [&](int i, const LineBuf& Lb, const i32x4& P0, const i32x4& P1) {
         const i32x4 Y = xchg8(sel4(hi, P0, P1));
         const i32x4 D0 = sel4(hi, Y, P0), D1 = sel4(hi, P1, Y);
-        const int m = m_first + 16 * i + lrow, n = n_first + lcol;
-        if (n < n_lim) {
-            if (m < p.M) st16(Cb + (size_t)m * ld + n, D0);
-            if (m + 8 < p.M) st16(Cb + (size_t)(m + 8) * ld + n, D1);
-        }
+        const unsigned o = Lb.off + (unsigned)(2 * i) * Lb.row8;
+#ifdef DIC_GEMM_ABL_NOSTORE     // timing ablation: the data still has to be produced
+        asm volatile("; no store %0 %1 %2" :: "v"(D0), "v"(D1), "v"(o));
+        return;
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(D0, Lb.rs, (int)o, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(D1, Lb.rs, (int)(o + Lb.row8), 0, AUX);
     };
     // mirrored load: full-line loads now, this lane's chunks (q = 0, q = 1) of row t of fragment i after get_lines_finish
-    auto get_lines_issue = [&](int i, const T* Rb, size_t ld, i32x4& L0, i32x4& L1, int n_lim) {
-        const int m = m_first + 16 * i + lrow, n = n_first + lcol;
-        L0 = i32x4{0, 0, 0, 0}; L1 = L0;
-        if (n < n_lim) {
-            if (m < p.M) L0 = *(const i32x4*)(Rb + (size_t)m * ld + n);
-            if (m + 8 < p.M) L1 = *(const i32x4*)(Rb + (size_t)(m + 8) * ld + n);
-        }
+    auto get_lines_issue = [&](int i, const LineBuf& Lb, i32x4& L0, i32x4& L1) {
+        const unsigned o = Lb.off + (unsigned)(2 * i) * Lb.row8;
+        L0 = __builtin_amdgcn_raw_buffer_load_b128(Lb.rs, (int)o, 0, 0);
+        L1 = __builtin_amdgcn_raw_buffer_load_b128(Lb.rs, (int)(o + Lb.row8), 0, 0);
     };
     auto get_lines_finish = [&](i32x4& L0, i32x4& L1) {          // in place: L0 -> chunk of q = 0, L1 -> chunk of q = 1
         const i32x4 Y = xchg8(sel4(hi, L0, L1));
         const i32x4 Q0 = sel4(hi, Y, L0), Q1 = sel4(hi, L1, Y);
         L0 = Q0; L1 = Q1;
     };
-    // fp32 pair of (fragment i, column group q): x0 / x1 = this lane's columns 8g..8g+3 / 8g+4..8g+7
-    auto put_lines_f32 = [&](int i, int q, float* Cb, size_t ld, const f32x4& x0, const f32x4& x1) {
+    // fp32 pair of (fragment i, column group q): x0 / x1 = this lane's columns 8g..8g+3 / 8g+4..8g+7; Lb is built for column group q
+    auto put_lines_f32 = [&](int i, const LineBuf& Lb, const f32x4& x0, const f32x4& x1) {
         const i32x4 X0 = __builtin_bit_cast(i32x4, x0), X1 = __builtin_bit_cast(i32x4, x1);
         const i32x4 Y = xchg8(sel4(hi, X0, X1));
         const i32x4 D0 = sel4(hi, Y, X0), D1 = sel4(hi, X1, Y);
-        const int m = m_first + 16 * i + lrow, n = n_first + 32 * q + 4 * (2 * g + (t >> 3));
-        if (n < p.N) {
-            if (m < p.M) *(i32x4*)(Cb + (size_t)m * ld + n) = D0;
-            if (m + 8 < p.M) *(i32x4*)(Cb + (size_t)(m + 8) * ld + n) = D1;
-        }
+        const unsigned o = Lb.off + (unsigned)(2 * i) * Lb.row8;
+        __builtin_amdgcn_raw_buffer_store_b128(D0, Lb.rs, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(D1, Lb.rs, (int)(o + Lb.row8), 0, 0);
     };
+    const int fcol = 4 * (2 * g + (t >> 3));                          // this lane's 4-column chunk inside a 32-column group (fp32 line order)
     int nc[G::NP];
     bool v0[G::NP], v1[G::NP];
 #pragma unroll
@@ -488,40 +507,61 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     }
     if constexpr (EPI == DIC_EPI_AFFINE) {
         const float inv_keep = drop_inv_keep(p.p_drop);
-        const bool general = p.accumulate || (p.R != nullptr && !PF) || ((p.N & 7) != 0 && (p.R != nullptr || !p.out_f32));
+        const bool general = p.accumulate || (p.R != nullptr && !PF) || ((p.N & 7) != 0 && (p.R != nullptr || !p.out_f32)) ||
+                             (p.out_f32 && (p.R != nullptr || p.p_drop > 0.f));         // fp32 output with a residual / dropout: nothing on the path asks for it
         if (!general) {
-            i32x4 pre[PF ? CNT : 1][PF ? G::NP : 1];
+            // The launch-uniform switches (dropout, residual, fp32 output) select one of eight straight-line bodies: left as run-time tests
+            // inside the unrolled (fragment, column group) loops they cost ~10 scalar branches per store instruction, with the dropout hash
+            // code to jump over each time.
             const T* R = (const T*)p.R;
-            if constexpr (PF) {
-                if (R) {
+            auto body = [&](auto drop_c, auto resid_c, auto f32_c) {
+                constexpr bool DROP = decltype(drop_c)::value, RESID = decltype(resid_c)::value, F32 = decltype(f32_c)::value;
+                i32x4 pre[RESID ? CNT : 1][RESID ? G::NP : 1];
+                const LineBuf bC = F32 ? LineBuf{} : line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
+                const LineBuf bF0 = F32 ? line_buf(p.C, p.ldc, 4, n_first + fcol, p.N) : LineBuf{};
+                const LineBuf bF1 = F32 ? line_buf(p.C, p.ldc, 4, n_first + 32 + fcol, p.N) : LineBuf{};
+                // (full-height tiles with a residual: the set-up's registers do not fit next to 128 accumulators + 64 residual registers,
+                // so there the DMA goes out first and the wait below covers it as well)
+                constexpr bool EARLY = RESID && CNT * G::FN * 4 + CNT * G::NP * 4 >= 192;
+                if constexpr (EARLY) issue_next();
+                if constexpr (RESID) {
+                    const LineBuf bR = line_buf(R, p.ldr, 2, n_first + lcol, p.N);
 #pragma unroll
-                    for (int i = 0; i < CNT; ++i) get_lines_issue(i, R, (size_t)p.ldr, pre[i][0], pre[i][1], p.N);
+                    for (int i = 0; i < CNT; ++i) get_lines_issue(i, bR, pre[i][0], pre[i][1]);
                     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the residual tile is in registers
                 }
-            }
+                if constexpr (!EARLY) issue_next();
 #pragma unroll
-            for (int i = 0; i < CNT; ++i) {
-                const int m = m_first + 16 * i + t;
-                i32x4 P[G::NP];
-                if constexpr (PF) { if (R) get_lines_finish(pre[i][0], pre[i][1]); }
+                for (int i = 0; i < CNT; ++i) {
+                    const int m = m_first + 16 * i + t;
+                    i32x4 P[G::NP];
+                    if constexpr (RESID) get_lines_finish(pre[i][0], pre[i][1]);
 #pragma unroll
-                for (int q = 0; q < G::NP; ++q) {
-                    f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
-                    if (p.p_drop > 0.f) {
-                        x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + nc[q], p.p_drop, inv_keep);
-                        x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + nc[q] + 4, p.p_drop, inv_keep);
+                    for (int q = 0; q < G::NP; ++q) {
+                        f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
+                        if constexpr (DROP) {
+                            x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + nc[q], p.p_drop, inv_keep);
+                            x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + nc[q] + 4, p.p_drop, inv_keep);
+                        }
+                        if constexpr (RESID) { f32x4 r0, r1; unpack8(pre[i][q], r0, r1); x0 += r0; x1 += r1; }
+                        if constexpr (F32) put_lines_f32(i, q == 0 ? bF0 : bF1, x0, x1);
+                        else P[q] = pack8f(x0, x1);
                     }
-                    if constexpr (PF) {
-                        if (R) { f32x4 r0, r1; unpack8(pre[i][q], r0, r1); x0 += r0; x1 += r1; }
-                    }
-                    if (p.out_f32) put_lines_f32(i, q, (float*)p.C, (size_t)p.ldc, x0, x1);
-                    else P[q] = pack8f(x0, x1);
+                    if constexpr (!F32) put_lines(i, bC, P[0], P[1]);
                 }
-                if (!p.out_f32) put_lines(i, (T*)p.C, (size_t)p.ldc, P[0], P[1], p.N);
+            };
+            const bool drop = p.p_drop > 0.f, resid = PF && R != nullptr, f32o = p.out_f32 != 0;
+            using Tt = std::true_type; using Ff = std::false_type;
+            if (f32o) body(Ff{}, Ff{}, Tt{});
+            else if constexpr (PF) {
+                if (resid) { if (drop) body(Tt{}, Tt{}, Ff{}); else body(Ff{}, Tt{}, Ff{}); } else { if (drop) body(Tt{}, Ff{}, Ff{}); else body(Ff{}, Ff{}, Ff{}); }
+            } else {                                            // weight gradients: never a residual in this path
+                if (drop) body(Tt{}, Ff{}, Ff{}); else body(Ff{}, Ff{}, Ff{});
             }
         } else {
             // rare combinations (accumulating into an fp32 C; a residual with N % 8 != 0): loads inside the loop.  Still fully unrolled:
             // a run-time index into the accumulator array would move it to scratch memory.
+            issue_next();
 #pragma unroll
             for (int i = 0; i < CNT; ++i) {
                 const int m = m_first + 16 * i + t;
@@ -552,6 +592,8 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             }
         }
     } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {                 // N % 8 == 0 is required for this epilogue
+        issue_next();
+        const LineBuf bU = line_buf(p.aux, p.ldaux, 2, n_first + lcol, p.N), bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             i32x4 U[G::NP], A[G::NP];
@@ -563,14 +605,16 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
                 A[q] = pack8f(x0, x1);
             }
-            put_lines(i, (T*)p.aux, (size_t)p.ldaux, U[0], U[1], p.N);
-            put_lines(i, (T*)p.C, (size_t)p.ldc, A[0], A[1], p.N);
+            put_lines(i, bU, U[0], U[1]);
+            put_lines(i, bC, A[0], A[1]);
         }
     } else if constexpr (EPI == DIC_EPI_GELU_BWD) {                  // dU = acc * gelu'(U)
         i32x4 pre[CNT][G::NP];
+        const LineBuf bU = line_buf(p.aux, p.ldaux, 2, n_first + lcol, p.N), bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
 #pragma unroll
-        for (int i = 0; i < CNT; ++i) get_lines_issue(i, (const T*)p.aux, (size_t)p.ldaux, pre[i][0], pre[i][1], p.N);
+        for (int i = 0; i < CNT; ++i) get_lines_issue(i, bU, pre[i][0], pre[i][1]);
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        issue_next();
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             get_lines_finish(pre[i][0], pre[i][1]);
@@ -583,7 +627,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
                 P[q] = pack8f(x0, x1);
             }
-            put_lines(i, (T*)p.C, (size_t)p.ldc, P[0], P[1], p.N);
+            put_lines(i, bC, P[0], P[1]);
         }
     } else if constexpr (EPI == DIC_EPI_CE_DLOGITS) {                // (softmax - onehot) * row_scale; columns in [N, ldc) are written as zeros
         float r_lse[CNT], r_sc[CNT];
@@ -597,6 +641,8 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             r_sc[i] = ok ? row_scale(p, m) : 0.f;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        issue_next();
+        const LineBuf bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.ldc);
         // (a leaner per-element sequence -- fma + v_exp, 32-bit target compare, no bounds tests off the last tile column -- changed nothing:
         // this epilogue is bound by its 1 GB of stores, not by VALU)
 #pragma unroll
@@ -618,16 +664,16 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 }
                 P[q] = pack8f(x0, x1);
             }
-            put_lines(i, (T*)p.C, (size_t)p.ldc, P[0], P[1], p.ldc);          // only rows < M are written
+            put_lines(i, bC, P[0], P[1]);          // only rows < M are written
         }
     }
 }
 
 // CE_PARTIAL for the bf16 geometries: every wave owns its rows x 64 columns of the tile and emits one (max, sum exp, first argmax)
 // record per row; record slot = bn * WN + wn, so a row has nbn * WN records for ce_combine.
-template <class C, int CNT>
+template <class C, int CNT, class IssueNext>
 __device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first,
-                                                    int wn, int lane, int bn, int nbn) {
+                                                    int wn, int lane, int bn, int nbn, IssueNext&& issue_next) {
     using G = Geo<C>;
     static_assert(G::WCOLS == 64 && G::FN == 4, "one 64-column record per wave");
     const int g = lane >> 4, t = lane & 15;
@@ -639,6 +685,8 @@ __device__ __forceinline__ void epilogue_ce_partial(f32x4 (&acc)[CNT][Geo<C>::FN
         const int m = m_first + i * 16 + t;
         tgs[i] = (m < p.M && p.tgt) ? p.tgt[m] : -1;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // the target ids are in; only now the next tile's DMA goes out (see epilogue_direct)
+    issue_next();
     constexpr float L2E = 1.4426950408889634f;
     const bool full = n_first + G::WCOLS <= p.N;            // wave-uniform: only the vocabulary's last tile column is ragged
 #pragma unroll
@@ -1045,7 +1093,15 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
     for (;;) {
+#ifdef DIC_GEMM_TRACE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        DIC_STAMP();
+        asm volatile("s_barrier" ::: "memory");
+#elif defined(DIC_GEMM_ABL_EARLY)    // timing ablation (results invalid): no wait for the previous tile's stores at the loop top
+        if (unit == (int)blockIdx.x) dma_barrier(); else barrier_lds_only();
+#else
         dma_barrier();                       // the tile's first K-step has landed (and the previous tile's output stores have drained)
+#endif
         DIC_STAMP();
 #pragma unroll
         for (int i = 0; i < CNT; ++i)
@@ -1087,21 +1143,20 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
             pe.ldc = G::BN; pe.M = G::BM; pe.N = G::BN; pe.out_f32 = 1; pe.accumulate = 0; pe.bias = nullptr; pe.R = nullptr; pe.p_drop = 0.f;
             unit += gridDim.x;
             more = unit < grp->split * grp->tiles;
-            if (more) {
-                tl = group_unit(unit);
-                setup(tl);
-                if (tl.kt0 < tl.kt1) issue(0);
-            }
+            if (more) tl = group_unit(unit);
         } else {
             unit += gridDim.x;
             more = unit < total;
+            if (more) tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+            if (p.split_k > 1) redirect_to_slab(pe, done.kz);
+        }
+        // The next tile's first K-step goes out from inside the epilogue: behind its last load wait, in front of its first store.
+        auto issue_next = [&]() {
             if (more) {
-                tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
                 setup(tl);
                 if (tl.kt0 < tl.kt1) issue(0);
             }
-            if (p.split_k > 1) redirect_to_slab(pe, done.kz);
-        }
+        };
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
             if (do_cs) {       // fold the thread groups through LDS, fixed order
                 float* red = (float*)(smem + G::STAGE);
@@ -1124,9 +1179,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         }
         const int m_first = (GROUP ? 0 : done.bm * tile_rows) + row0_w, n_first = (GROUP ? 0 : done.bn * G::BN) + wn * G::WCOLS;
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
-            epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn);
+            epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn, issue_next);
         } else {
-            epilogue_direct<C, EPI, !AKM, CNT>(acc, pe, m_first, n_first, lane);
+            epilogue_direct<C, EPI, !AKM, CNT>(acc, pe, m_first, n_first, lane, issue_next, [&]() { DIC_STAMP(); });
         }
         DIC_STAMP();
         if (!more) break;

@@ -36,17 +36,15 @@ def run(name, M, N, K, a_km=0, b_km=0, epi=0, resid=False, tile=256):
     base = wg[:, 0].min()
     clk = (wg[:, 61] - wg[:, 0]) / np.maximum(wg[:, 63] - wg[:, 62], 1) * 0.1      # shader ticks per 10 ns tick of the 100 MHz clock -> GHz
     wg = wg.copy(); wg[:, 61:] = 0
-    ntile = ((wg != 0).sum(1) - 1) // 3
-    print(f"   shader clock while the kernel ran: {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})")
+    ntile = ((wg != 0).sum(1) - 1) // 6
     print(f"== {name}: M={M} N={N} K={K}  {len(wg)} workgroups, tiles/workgroup {ntile.min()}..{ntile.max()}, event time {e0.elapsed_time(e1)*1e3:.1f} us")
-    print(f"   entry spread {(wg[:,0].max()-base)/1000:.2f} kcyc; last stamp {(wg.max()-base)/1000:.2f} kcyc after the first entry")
+    print(f"   shader clock while the kernel ran: {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})")
+    # stamps per tile (wave 0): own loads+stores drained | barrier passed (loop top) | K loop done | epilogue: side loads in | next tile's DMA issued | stores issued
     for k in range(int(ntile.max())):
         sel = wg[ntile > k]
-        top, kend, eend = sel[:, 1 + 3 * k], sel[:, 2 + 3 * k], sel[:, 3 + 3 * k]
-        prev = sel[:, 3 * k]
-        print(f"   tile {k}: wait-for-first-stage {np.mean(top-prev)/1000:6.2f} kcyc | K loop {np.mean(kend-top)/1000:6.2f} kcyc | epilogue issue {np.mean(eend-kend)/1000:6.2f} kcyc"
-              f" | loop-top spread across workgroups {(top.max()-top.min())/1000:5.2f} kcyc (std {np.std(top)/1000:4.2f})")
-
+        prev, vm, top, kend, eb, ei, eend = (sel[:, j + 6 * k] for j in range(7))
+        print(f"   tile {k}: drain {np.mean(vm-prev)/1000:5.2f} + barrier {np.mean(top-vm)/1000:5.2f} | K loop {np.mean(kend-top)/1000:6.2f} | epilogue: to loads-in {np.mean(eb-kend)/1000:5.2f}"
+              f" + next-tile set-up/DMA issue {np.mean(ei-eb)/1000:5.2f} + math/stores {np.mean(eend-ei)/1000:5.2f} kcyc")
 
     # K-step anatomy of the first tile (waves 0 and NW-1 of every workgroup): compute | wait for the next stage's DMA | wait at the barrier
     k = ks.cpu().numpy().reshape(2048, 2, 16, 4)[: len(wg)]
