@@ -419,7 +419,7 @@ __device__ __forceinline__ i32x4 sel4(bool c, const i32x4& a, const i32x4& b) { 
 // waits for and BEFORE its first store: a wait for the bias / residual / pre-activation loads is a `vmcnt(0)` and would otherwise also
 // wait ~2.4 k cycles for that DMA (the s_memtime trace showed it in front of every epilogue), while behind the wait the DMA's latency
 // hides under the stores.
-template <class C, int EPI, bool PF, int CNT, class IssueNext, class Stamp>
+template <class C, int EPI, bool PF, int CNT, bool BIAS_IN_ACC, class IssueNext, class Stamp>
 __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first, int lane, IssueNext&& issue_next_,
                                                 Stamp&& stamp) {
     auto issue_next = [&]() { stamp(); issue_next_(); stamp(); };          // (stamp: s_memtime in the trace build, nothing otherwise)
@@ -493,7 +493,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     bool v0[G::NP], v1[G::NP];
 #pragma unroll
     for (int q = 0; q < G::NP; ++q) { nc[q] = n_first + 32 * q + 8 * g; v0[q] = nc[q] < p.N; v1[q] = nc[q] + 4 < p.N; }
-    if constexpr (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU) {
+    if constexpr ((EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU) && !BIAS_IN_ACC) {       // (forward Linears: the accumulators started from the bias)
         if (p.bias) {
 #pragma unroll
             for (int q = 0; q < G::NP; ++q) {
@@ -601,8 +601,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             for (int q = 0; q < G::NP; ++q) {
                 f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
                 U[q] = pack8f(x0, x1);                                // pre-activation u (for GELU')
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { x0[r] = gelu_fast(x0[r]); x1[r] = gelu_fast(x1[r]); }
+                gelu_fast4(x0); gelu_fast4(x1);
                 A[q] = pack8f(x0, x1);
             }
             put_lines(i, bU, U[0], U[1]);
@@ -623,8 +622,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             for (int q = 0; q < G::NP; ++q) {
                 f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1], u0, u1;
                 unpack8(pre[i][q], u0, u1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { x0[r] *= gelu_grad_fast(u0[r]); x1[r] *= gelu_grad_fast(u1[r]); }
+                gelu_grad_mul4(x0, u0); gelu_grad_mul4(x1, u1);
                 P[q] = pack8f(x0, x1);
             }
             put_lines(i, bC, P[0], P[1]);
@@ -1084,6 +1082,25 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #ifdef DIC_GEMM_TRACE
     if (trace && tid == 0) trace[62] = __builtin_amdgcn_s_memrealtime();     // 100 MHz wall clock next to the shader clock: their ratio is the GPU clock under this kernel's load
 #endif
+    // Forward Linears (k-contiguous A and B): the accumulators START from the bias instead of zero.  The bias row of the tile's 64 columns
+    // per wave is loaded where nothing waits for it -- behind the previous tile's stores (before the first tile: behind the first DMA) --
+    // and the epilogue has no load and no wait left in front of its first store (s_memtime: ~2 k cycles per tile for that wait).
+    constexpr bool BIAS_INIT = !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU);
+    f32x4 binit[BIAS_INIT ? G::FN : 1];
+    auto load_bias = [&](const TileId& t_) {
+        if constexpr (BIAS_INIT) {
+#pragma unroll
+            for (int j = 0; j < G::FN; ++j) binit[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const int nf = t_.bn * G::BN + wn * G::WCOLS + 8 * g;
+#pragma unroll
+                for (int q = 0; q < G::NP; ++q) {
+                    if (nf + 32 * q < p.N) binit[2 * q] = *(const f32x4*)(p.bias + nf + 32 * q);
+                    if (nf + 32 * q + 4 < p.N) binit[2 * q + 1] = *(const f32x4*)(p.bias + nf + 32 * q + 4);
+                }
+            }
+        }
+    };
     TileId tl;
     if constexpr (GROUP) {
         tl = group_unit(unit);
@@ -1092,6 +1109,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     }
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
+    load_bias(tl);
     for (;;) {
 #ifdef DIC_GEMM_TRACE
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1106,7 +1124,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #pragma unroll
         for (int i = 0; i < CNT; ++i)
 #pragma unroll
-            for (int j = 0; j < G::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < G::FN; ++j) acc[i][j] = BIAS_INIT ? binit[BIAS_INIT ? j : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
             do_cs = p.colsum_out != nullptr && tl.bn == 0;
             cs0 = f32x4{0.f, 0.f, 0.f, 0.f}; cs1 = cs0;
@@ -1181,8 +1199,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
             epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn, issue_next);
         } else {
-            epilogue_direct<C, EPI, !AKM, CNT>(acc, pe, m_first, n_first, lane, issue_next, [&]() { DIC_STAMP(); });
+            epilogue_direct<C, EPI, !AKM, CNT, BIAS_INIT>(acc, pe, m_first, n_first, lane, issue_next, [&]() { DIC_STAMP(); });
         }
+        if constexpr (BIAS_INIT) { if (more) load_bias(tl); }       // behind this tile's stores; the loop-top wait covers it
         DIC_STAMP();
         if (!more) break;
     }
