@@ -399,14 +399,15 @@ __device__ __forceinline__ void barrier_lds_only() {
     __builtin_amdgcn_s_barrier();
 }
 
-// value held by lane t ^ 8 of the same 16-lane row (DPP row_ror:8)
-__device__ __forceinline__ i32x4 xchg8(const i32x4& x) {
+// Lanes t and t^8 of a 16-lane row trade one 16-byte chunk (DPP row_ror:8 with a bank mask: only half of the lanes take the rotated
+// value, the others keep `keep` -- no select instructions).  HI: lanes 8..15 of each row receive, else lanes 0..7.
+template <bool HI>
+__device__ __forceinline__ i32x4 take8(const i32x4& keep, const i32x4& from_partner) {
     i32x4 y;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = __builtin_amdgcn_update_dpp(0, x[r], 0x128, 0xF, 0xF, false);
+    for (int r = 0; r < 4; ++r) y[r] = __builtin_amdgcn_update_dpp(keep[r], from_partner[r], 0x128, 0xF, HI ? 0xC : 0x3, false);
     return y;
 }
-__device__ __forceinline__ i32x4 sel4(bool c, const i32x4& a, const i32x4& b) { return c ? a : b; }
 
 // One wave's accumulators -> HBM.  m_first: global row of the wave's fragment 0 (CNT fragments of 16 rows); n_first: global column of
 // the wave's first column.
@@ -438,7 +439,6 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     // GELU' and residual epilogues measured 0-6 % slower with nt.
     constexpr bool NT = EPI == DIC_EPI_BIAS_GELU;
     static_assert(G::NP == 2, "line stores pair the two 8-column groups of a 64-column wave slab");
-    const bool hi = t >= 8;
     const int lrow = t & 7, lcol = 8 * (g + 4 * (t >> 3));          // row within an 8-row half fragment; column of this lane's chunk in line order
     // Buffer addressing (32-bit lane offsets against a descriptor anchored at the wave's first row): no 64-bit address arithmetic and no
     // exec-mask branches per store -- rows >= M fall outside the descriptor's range and are dropped (loads: read as zero) by the hardware,
@@ -458,8 +458,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     constexpr int AUX = NT ? 2 : 0;                                   // cache-policy bits of the buffer instruction: 2 = nt
     // bf16 row pair of fragment i: P0 / P1 = this lane's chunks for column groups q = 0 / 1
     auto put_lines = [&](int i, const LineBuf& Lb, const i32x4& P0, const i32x4& P1) {
-        const i32x4 Y = xchg8(sel4(hi, P0, P1));
-        const i32x4 D0 = sel4(hi, Y, P0), D1 = sel4(hi, P1, Y);
+        const i32x4 D0 = take8<true>(P0, P1), D1 = take8<false>(P1, P0);      // rows 0-7: lanes t >= 8 carry lane t-8's second chunk; rows 8-15: lanes t < 8 carry lane t+8's first
         const unsigned o = Lb.off + (unsigned)(2 * i) * Lb.row8;
 #ifdef DIC_GEMM_ABL_NOSTORE     // timing ablation: the data still has to be produced
         asm volatile("; no store %0 %1 %2" :: "v"(D0), "v"(D1), "v"(o));
@@ -475,15 +474,13 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
         L1 = __builtin_amdgcn_raw_buffer_load_b128(Lb.rs, (int)(o + Lb.row8), 0, 0);
     };
     auto get_lines_finish = [&](i32x4& L0, i32x4& L1) {          // in place: L0 -> chunk of q = 0, L1 -> chunk of q = 1
-        const i32x4 Y = xchg8(sel4(hi, L0, L1));
-        const i32x4 Q0 = sel4(hi, Y, L0), Q1 = sel4(hi, L1, Y);
+        const i32x4 Q0 = take8<true>(L0, L1), Q1 = take8<false>(L1, L0);
         L0 = Q0; L1 = Q1;
     };
     // fp32 pair of (fragment i, column group q): x0 / x1 = this lane's columns 8g..8g+3 / 8g+4..8g+7; Lb is built for column group q
     auto put_lines_f32 = [&](int i, const LineBuf& Lb, const f32x4& x0, const f32x4& x1) {
         const i32x4 X0 = __builtin_bit_cast(i32x4, x0), X1 = __builtin_bit_cast(i32x4, x1);
-        const i32x4 Y = xchg8(sel4(hi, X0, X1));
-        const i32x4 D0 = sel4(hi, Y, X0), D1 = sel4(hi, X1, Y);
+        const i32x4 D0 = take8<true>(X0, X1), D1 = take8<false>(X1, X0);
         const unsigned o = Lb.off + (unsigned)(2 * i) * Lb.row8;
         __builtin_amdgcn_raw_buffer_store_b128(D0, Lb.rs, (int)o, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(D1, Lb.rs, (int)(o + Lb.row8), 0, 0);
