@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// PAT 3: pattern 1 + `s_waitcnt vmcnt(0); s_barrier` after every tile (what a persistent GEMM pays between two tiles);
+// PAT 4: as 3, and 64 KB of LDS-DMA loads issued right behind the tile's stores (the next tile's first K-step): does the load wait behind the stores?
 template <int PAT, bool NT>
 __global__ __launch_bounds__(512, 2) void probe(char* C, int ldc_bytes, int tiles_n, int tiles_total, int passes, unsigned long long* out) {
     extern __shared__ char smem[];
@@ -29,6 +31,20 @@ __global__ __launch_bounds__(512, 2) void probe(char* C, int ldc_bytes, int tile
                 char* p = base + (size_t)row * ldc_bytes + chunk * 16;
                 if (NT) __builtin_nontemporal_store(v, (i32x4*)p); else *(i32x4*)p = v;
             }
+            if (PAT == 4) {
+                const unsigned long long b = (unsigned long long)C;
+                i32x4 r;
+                r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b); r[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+                r[2] = 0x7fffffff; r[3] = 0x00020000;
+                const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (wave * 8 + j) * 1024);
+                    const unsigned vo = ((unsigned)(blockIdx.x % 64) * 256u + (wave * 8 + j) * 8 + (lane >> 3)) * 6144u + (lane & 7) * 16;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(r), "s"(dst) : "memory");
+                }
+            }
+            if (PAT >= 3) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -65,6 +81,8 @@ int main() {
             run<1, false>("8 rows x 128 B per instruction", C, M, N, grid, out);
             run<0, true>("16 rows x 64 B per instruction, nt", C, M, N, grid, out);
             run<1, true>("8 rows x 128 B per instruction, nt", C, M, N, grid, out);
+            run<3, false>("8 rows x 128 B, wait + barrier per tile", C, M, N, grid, out);
+            run<4, false>("same + 64 KB LDS-DMA behind the stores", C, M, N, grid, out);
         }
     return 0;
 }
