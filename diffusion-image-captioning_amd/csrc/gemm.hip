@@ -1108,6 +1108,13 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     if (tl.kt0 < tl.kt1) issue(0);
     load_bias(tl);
     for (;;) {
+        // the NEXT unit's tile coordinates (a handful of integer divisions) are worked out here, where the wave waits for the first DMA anyway
+        TileId tl_next = tl;
+        bool more_next = false;
+        if constexpr (!GROUP) {
+            more_next = unit + (int)gridDim.x < total;
+            if (more_next) tl_next = tile_of_unit(p, BK, unit + (int)gridDim.x, tile_rows, G::BN);
+        }
 #ifdef DIC_GEMM_TRACE
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         DIC_STAMP();
@@ -1161,8 +1168,8 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
             if (more) tl = group_unit(unit);
         } else {
             unit += gridDim.x;
-            more = unit < total;
-            if (more) tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+            more = more_next;
+            tl = tl_next;
             if (p.split_k > 1) redirect_to_slab(pe, done.kz);
         }
         // The next tile's first K-step goes out from inside the epilogue: behind its last load wait, in front of its first store.
