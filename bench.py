@@ -237,7 +237,7 @@ def main():
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_src,
                 "launches_per_step": n.value // max(args.steps, 1), "gemm_ms_per_step": round(ms.value / args.steps, 3),
                 "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
-        if args.dtype == "bf16":
+        if args.dtype == "bf16" and w == 0.0:
             # the backward recomputes the rounding logits instead of storing them: that GEMM is executed work, not algorithmic work
             rec = 2.0 * ((S + 1) * B * L) * 30592 * 768
             roof["frac_excluding_logits_recompute"] = round((fl.value / args.steps - rec) / (ms.value / args.steps * 1e-3) / 1e12 / peak, 4)
