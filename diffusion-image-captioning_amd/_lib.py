@@ -25,6 +25,7 @@ EXPORTS = [
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
+    "dic_gemm_set_variant",
 ]
 
 
@@ -53,7 +54,7 @@ class WgradItem(C.Structure):
 def build(verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into one shared library, in-tree (it travels with the snapshot)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_pp.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -133,6 +134,7 @@ def lib():
         L.dic_adamw.argtypes = [P, P, P, P, P, I64, F, F, F, F, F, F, F, F, P]
         L.dic_cast_bf16.argtypes = [P, P, I64, P]
         L.dic_probe_tr16.argtypes = [P, P, P]
+        L.dic_gemm_set_variant.argtypes = [I]
         L.dic_prof_begin.argtypes = [I]
         L.dic_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _lib = L

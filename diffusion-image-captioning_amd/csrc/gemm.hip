@@ -1222,6 +1222,15 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
 __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmParams p, WgradGroupDev grp) {
     gemm_bf16_body<T256, true, true, DIC_EPI_AFFINE, Geo<T256>::FM, true>(p, &grp);
 }
+
+#include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (default for the 256-column geometry)
+
+// Which K loop the 256-column geometry runs: the ping-pong one (gemm_pp.h) unless DIC_GEMM_PP=0 / dic_gemm_set_variant(0) (A/B measurements).
+int g_pp = -1;
+bool pp_enabled() {
+    if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && e[0] == '0') ? 0 : 1; }
+    return g_pp == 1;
+}
 // Fold of a grouped launch: tile t = sum of its K-slices' slabs in slice order (deterministic).  Block = (tile, 16-row chunk); 256 threads x
 // (4 rows x 4 columns).  The bias gradient rides in each slab's tail.
 __global__ __launch_bounds__(256) void wgrad_group_fold_kernel(WgradGroupDev grp) {
@@ -1351,12 +1360,22 @@ int pick_tile_rows(int M, int nbn_split, int slots, int BM, int K) {
 template <class C, bool AKM, bool BKM, int E, int CNT>
 void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
     using G = Geo<C>;
-    static bool attr_set[64] = {};
+    static bool attr_set[2][64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {           // per device: one process may drive several GPUs
+    if constexpr (std::is_same_v<C, T256>) {
+        if (pp_enabled()) {
+            if (dev >= 0 && dev < 64 && !attr_set[1][dev]) {
+                (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AKM, BKM, E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+                attr_set[1][dev] = true;
+            }
+            launch_timed(gemm_pp_kernel<AKM, BKM, E, CNT>, dim3(grid), dim3(G::NTH), (unsigned)G::LDS, st, q);
+            return;
+        }
+    }
+    if (dev >= 0 && dev < 64 && !attr_set[0][dev]) {           // per device: one process may drive several GPUs
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AKM, BKM, E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr_set[dev] = true;
+        attr_set[0][dev] = true;
     }
     launch_timed(gemm_bf16_kernel<C, AKM, BKM, E, CNT>, dim3(grid), dim3(G::NTH), (unsigned)G::LDS, st, q);
 }
@@ -1513,19 +1532,23 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute((const void*)wgrad_group_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr_set[dev] = true;
     }
     DicGemmParams q{};
     q.K = T; q.out_f32 = 1; q.split_k = 1; q.tile = 256;
     hipStream_t st = (hipStream_t)stream;
     tl_prof = prof_slot([&] { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * items[i].M * items[i].N * T; return f; }());
-    launch_timed(wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
+    launch_timed(pp_enabled() ? wgrad_group_pp_kernel : wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
     const int tiles = pl.dev.tiles;
     launch_timed(wgrad_group_fold_kernel, dim3(tiles, G::BM / 16), dim3(256), 0u, st, pl.dev);
     tl_prof = nullptr;
     DIC_CHECK_LAUNCH();
     return 0;
 }
+
+// measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry (default), 0 = the lock-step loop
+extern "C" int dic_gemm_set_variant(int pp) { g_pp = pp ? 1 : 0; return 0; }
 
 // ---- optional per-launch timing (bench.py roofline leg), see launch_timed above
 namespace {

@@ -101,6 +101,11 @@ size_t dic_ce_partial_bytes(int M, int N, int tile);
 size_t dic_colsum_ws_bytes(int in_dtype, int rows, int cols);
 size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
 
+/* Measurement switch (PROCESS-GLOBAL state, like dic_prof_* below -- not for concurrent use from several threads): which K loop the bf16
+ * 256-column geometry runs.  1 (default; env DIC_GEMM_PP) = the ping-pong loop of csrc/gemm_pp.h, 0 = the lock-step loop.  Results are
+ * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
+int dic_gemm_set_variant(int pp);
+
 /* Measurement hooks for bench.py: between begin/end every dic_gemm launch is bracketed by hipEvents recorded on its own
  * stream; end() (after the caller synchronised) returns the summed kernel time, algorithmic flops (2*M*N*K) and count. */
 int dic_prof_begin(int max_launches);
