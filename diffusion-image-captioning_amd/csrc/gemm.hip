@@ -1083,7 +1083,12 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     // Forward Linears (k-contiguous A and B): the accumulators START from the bias instead of zero.  The bias row of the tile's 64 columns
     // per wave is loaded where nothing waits for it -- behind the previous tile's stores (before the first tile: behind the first DMA) --
     // and the epilogue has no load and no wait left in front of its first store (s_memtime: ~2 k cycles per tile for that wait).
-    constexpr bool BIAS_INIT = !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU);
+    // (Only without the cross-tile prefetch below: with it nothing waits behind the stores any more, so the bias is added in the epilogue.)
+#ifndef DIC_GEMM_XT
+#define DIC_GEMM_XT 0          // measured in round 3 (profiles/r03_gemm_xt_ab.txt): 3-7 % SLOWER on every shape, K loop included -- off
+#endif
+    constexpr bool XT = DIC_GEMM_XT != 0;
+    constexpr bool BIAS_INIT = !XT && !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU);
     f32x4 binit[BIAS_INIT ? G::FN : 1];
     auto load_bias = [&](const TileId& t_) {
         if constexpr (BIAS_INIT) {
@@ -1108,6 +1113,15 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
     load_bias(tl);
+    // CROSS-TILE PREFETCH (XT).  The tile's last K-step has no successor inside the tile, so its DMA slot carries the NEXT unit's first K-step
+    // (into the stage that step is not reading), and the end-of-step barrier publishes it BEFORE this tile's output is stored.  The epilogue
+    // then issues the next unit's second K-step into the stage the last step has just released, still in front of its first store.  The next
+    // tile therefore starts without any wait: its first vmcnt(0) -- which on gfx950 also waits for every store issued before it -- comes at
+    // the end of its first K-step, a full K-step (~2.9 k cycles) after the last store went out, instead of at the loop top (s_memtime trace
+    // of round 2: 5-8 k cycles per tile between the epilogue and the first MFMA).  The stage parity runs on across tiles.
+    int cur = 0;
+    bool k0_ready = false;         // this tile's first K-step was published by the previous tile's last barrier
+    bool k1_issued = false;        // this tile's second K-step was issued by the previous tile's epilogue
     for (;;) {
         // the NEXT unit's tile coordinates (a handful of integer divisions) are worked out here, where the wave waits for the first DMA anyway
         TileId tl_next = tl;
@@ -1115,6 +1129,8 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         if constexpr (!GROUP) {
             more_next = unit + (int)gridDim.x < total;
             if (more_next) tl_next = tile_of_unit(p, BK, unit + (int)gridDim.x, tile_rows, G::BN);
+        } else {
+            more_next = unit + (int)gridDim.x < grp->split * grp->tiles;
         }
 #ifdef DIC_GEMM_TRACE
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1123,7 +1139,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #elif defined(DIC_GEMM_ABL_EARLY)    // timing ablation (results invalid): no wait for the previous tile's stores at the loop top
         if (unit == (int)blockIdx.x) dma_barrier(); else barrier_lds_only();
 #else
-        dma_barrier();                       // the tile's first K-step has landed (and the previous tile's output stores have drained)
+        if (!k0_ready) dma_barrier();        // the tile's first K-step has landed (without XT: and the previous tile's output stores have drained)
 #endif
         DIC_STAMP();
 #pragma unroll
@@ -1135,11 +1151,22 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
             cs0 = f32x4{0.f, 0.f, 0.f, 0.f}; cs1 = cs0;
         }
         const int nk = tl.kt1;
-        int cur = 0;
+        const TileId done = tl;
+        const int slab_done = slab;
+        DicGemmParams pe = p;                        // (grouped launches: group_unit() below re-points p at the next problem)
+        bool next_set = false, next_k0 = false;      // next unit's addressing is set up / its first K-step is in flight or landed
         // (A software-pipelined variant -- barrier before the last MFMA group, first fragments of the next stage prefetched across it,
         // DMA re-armed 1.75 K-steps ahead -- was measured in round 1: +2-5 % on isolated GEMMs, -2 % on the training step; not kept.)
         for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
-            compute(cur, kt + 1 < nk);                 //  register allocator keep two copies of the accumulator tile); issues the next K-step's DMA
+            bool do_issue = kt + 1 < nk;               //  register allocator keep two copies of the accumulator tile); issues the next K-step's DMA
+            if (do_issue) { if (k1_issued && kt == tl.kt0) do_issue = false; }
+            else if (XT && more_next) {
+                if constexpr (GROUP) tl_next = group_unit(unit + (int)gridDim.x);
+                setup(tl_next);
+                next_set = true;
+                do_issue = next_k0 = tl_next.kt0 < tl_next.kt1;
+            }
+            compute(cur, do_issue);
 #ifdef DIC_GEMM_TRACE
             if (p.partial && (kt - tl.kt0) < 16 && unit == (int)blockIdx.x && (wave == 0 || wave == G::NW - 1)) {
                 unsigned long long* kst = (unsigned long long*)p.partial + (((size_t)blockIdx.x * 2 + (wave != 0)) * 16 + (kt - tl.kt0)) * 4;
@@ -1155,34 +1182,30 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
             cur ^= 1;
         }
         DIC_STAMP();
-        // Both LDS stages are free now.  The next tile's first K-step goes out BEFORE this tile is written: its latency hides under the
-        // epilogue, which touches no LDS (except the bias-gradient fold of the weight-gradient GEMMs, which uses the second stage).
-        const TileId done = tl;
-        DicGemmParams pe = p;
-        bool more;
+        // `cur` is now the stage that holds (or will hold) the next unit's first K-step; the other stage is free.
+        bool more = more_next;
         if constexpr (GROUP) {
             // the unit's partial tile goes to its own slab, in tile-local coordinates (the fold kernel adds a tile's slices up)
-            pe.C = grp->ws + (size_t)slab * (G::BM * G::BN + G::BM);
+            pe.C = grp->ws + (size_t)slab_done * (G::BM * G::BN + G::BM);
             pe.ldc = G::BN; pe.M = G::BM; pe.N = G::BN; pe.out_f32 = 1; pe.accumulate = 0; pe.bias = nullptr; pe.R = nullptr; pe.p_drop = 0.f;
-            unit += gridDim.x;
-            more = unit < grp->split * grp->tiles;
-            if (more) tl = group_unit(unit);
         } else {
-            unit += gridDim.x;
-            more = more_next;
-            tl = tl_next;
             if (p.split_k > 1) redirect_to_slab(pe, done.kz);
         }
-        // The next tile's first K-step goes out from inside the epilogue: behind its last load wait, in front of its first store.
+        unit += gridDim.x;
+        // The next tile's remaining start-up goes out from inside the epilogue: behind its last load wait, in front of its first store.
         auto issue_next = [&]() {
-            if (more) {
-                setup(tl);
-                if (tl.kt0 < tl.kt1) issue(0);
+            if (!more) return;
+            if (!next_set) {                         // no K-step of this tile could carry the prefetch (a unit without K-steps), or XT is off
+                if constexpr (GROUP) tl_next = group_unit(unit);
+                setup(tl_next);
+                if (tl_next.kt0 < tl_next.kt1) issue(cur);
+            } else if (next_k0 && tl_next.kt0 + 1 < tl_next.kt1) {
+                issue(cur ^ 1);
             }
         };
         if constexpr (AKM && BKM && EPI == DIC_EPI_AFFINE) {
-            if (do_cs) {       // fold the thread groups through LDS, fixed order
-                float* red = (float*)(smem + G::STAGE);
+            if (do_cs) {       // fold the thread groups through LDS (the free stage), fixed order
+                float* red = (float*)(smem + (cur ^ 1) * G::STAGE);
                 *(f32x4*)(red + (tid / CS_CPR) * G::BM + (tid % CS_CPR) * 8) = cs0;
                 *(f32x4*)(red + (tid / CS_CPR) * G::BM + (tid % CS_CPR) * 8 + 4) = cs1;
                 barrier_lds_only();
@@ -1192,9 +1215,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
                     for (int gq = 0; gq < CS_GROUPS; ++gq) v += red[gq * G::BM + tid];
                     const int m = done.bm * G::BM + tid;
                     if constexpr (GROUP) ((float*)pe.C)[G::BM * G::BN + tid] = v;
-                    else if (m < p.M) {
-                        if (p.split_k > 1) ((float*)pe.C)[(size_t)p.M * p.ldc + m] = v;
-                        else p.colsum_out[m] = p.accumulate ? p.colsum_out[m] + v : v;
+                    else if (m < pe.M) {
+                        if (pe.split_k > 1) ((float*)pe.C)[(size_t)pe.M * pe.ldc + m] = v;
+                        else pe.colsum_out[m] = pe.accumulate ? pe.colsum_out[m] + v : v;
                     }
                 }
                 barrier_lds_only();
@@ -1206,6 +1229,10 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         } else {
             epilogue_direct<C, EPI, !AKM, CNT, BIAS_INIT>(acc, pe, m_first, n_first, lane, issue_next, [&]() { DIC_STAMP(); });
         }
+        k0_ready = more && next_set && next_k0;
+        k1_issued = k0_ready && tl_next.kt0 + 1 < tl_next.kt1;
+        if (more && next_set && !next_k0) k0_ready = true;          // a unit without K-steps: nothing to wait for
+        tl = tl_next;
         if constexpr (BIAS_INIT) { if (more) load_bias(tl); }       // behind this tile's stores; the loop-top wait covers it
         DIC_STAMP();
         if (!more) break;
@@ -1223,12 +1250,14 @@ __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmP
     gemm_bf16_body<T256, true, true, DIC_EPI_AFFINE, Geo<T256>::FM, true>(p, &grp);
 }
 
-#include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (default for the 256-column geometry)
+#include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (measured alternative)
 
-// Which K loop the 256-column geometry runs: the ping-pong one (gemm_pp.h) unless DIC_GEMM_PP=0 / dic_gemm_set_variant(0) (A/B measurements).
+// Which K loop the 256-column geometry runs: the lock-step one above, or the ping-pong one of gemm_pp.h with DIC_GEMM_PP=1 /
+// dic_gemm_set_variant(1).  Round 3 measured them equal within noise on the step's k-contiguous shapes and the ping-pong loop 10-20 %
+// slower with k-major operands (two ds_read_b64_tr_b16 per fragment in its load segments), so the lock-step loop stays the default.
 int g_pp = -1;
 bool pp_enabled() {
-    if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && e[0] == '0') ? 0 : 1; }
+    if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && e[0] == '1') ? 1 : 0; }
     return g_pp == 1;
 }
 // Fold of a grouped launch: tile t = sum of its K-slices' slabs in slice order (deterministic).  Block = (tile, 16-row chunk); 256 threads x
@@ -1443,10 +1472,12 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
     }
     switch (epi) {
         case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(st, p); break;
+#ifndef DIC_GEMM_MIN          // (measurement builds instantiate the plain forward GEMM only: scripts/experiments/pp_ablate.sh)
         case DIC_EPI_BIAS_GELU: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(st, p); break;
         case DIC_EPI_GELU_BWD: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(st, p); break;
         case DIC_EPI_CE_PARTIAL: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(st, p); break;
         case DIC_EPI_CE_DLOGITS: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(st, p); break;
+#endif
     }
     if (split > 1) {
         const long long n4 = (long long)p.M * p.ldc / 4, n4cs = p.colsum_out ? p.M / 4 : 0;
@@ -1462,8 +1493,10 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
 template <typename T>
 int launch_layout(const DicGemmParams& p, int a_km, int b_km, int epi, hipStream_t st) {
     if (!a_km && !b_km) return launch_epi<T, false, false>(p, epi, st);
+#ifndef DIC_GEMM_MIN
     if (!a_km && b_km) return launch_epi<T, false, true>(p, epi, st);
     if (a_km && b_km) return launch_epi<T, true, true>(p, epi, st);
+#endif
     dic_set_error("dic_gemm: (A k-major, B k-contiguous) is not used by the path and not built");
     return 1003;
 }
@@ -1547,7 +1580,7 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     return 0;
 }
 
-// measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry (default), 0 = the lock-step loop
+// measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry, 0 = the lock-step loop (default)
 extern "C" int dic_gemm_set_variant(int pp) { g_pp = pp ? 1 : 0; return 0; }
 
 // ---- optional per-launch timing (bench.py roofline leg), see launch_timed above

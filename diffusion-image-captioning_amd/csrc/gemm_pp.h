@@ -44,8 +44,6 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
     static_assert(G::FN == 4 && G::NW == 8, "two wave rows of four waves, four B fragments per wave");
     static_assert(!GROUP || (AKM && BKM && EPI == DIC_EPI_AFFINE), "grouped launches are weight gradients");
     constexpr int FH = CNT >= 5 ? 4 : CNT / 2, BH = CNT - FH;                 // A fragments per wave in the front / back region
-    constexpr int NPH0 = (FH + 1) / 2, NPH1 = FH / 2, NPH2 = (BH + 1) / 2, NPH3 = BH / 2;      // fragments per phase
-    constexpr int PB1 = NPH0, PB2 = FH, PB3 = FH + NPH2;                        // first fragment of phases 1..3
     constexpr int NF = 4 * FH / 8;                                            // front pieces (1 KiB) per wave and K-step
     constexpr int NBS = (4 * BH + 7) / 8;                                     // back piece slots per wave
     constexpr bool BACK_EVEN = (4 * BH) % 8 == 0;                             // else waves 4..7 (the second wave row) own one piece fewer
@@ -101,6 +99,9 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
     // 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1 KiB).  (s_nop 3: m0 write -> LDS-DMA needs one wait state, and a descriptor SGPR fresh
     // from v_readfirstlane five before a VMEM instruction reads it -- nothing pads inside an asm statement.)
     auto dma16 = [](unsigned voff, const i32x4& rsrc, unsigned lds_addr) {
+#ifdef DIC_PP_NODMA             // timing ablations (scripts/experiments/pp_ablate.sh): results are garbage
+        return;
+#endif
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
     };
     // tile-local piece numbers of this wave (front slot j / back slot j) and their LDS offsets inside a stage.  k-contiguous A: a piece is
@@ -232,13 +233,18 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
     // store in flight -- the previous tile's output -- only makes the wait stricter, never weaker.)
     auto wait_vm = [&](auto n0_c, auto n1_c) {
         constexpr int n0 = decltype(n0_c)::value, n1 = decltype(n1_c)::value;
+#ifdef DIC_PP_NOVMWAIT
+        return;
+#endif
         if (!c_valid) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (n0 == n1 || wm == 0) asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(n0) : "memory");
         else asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(n1) : "memory");
     };
     auto bar = []() {
         __builtin_amdgcn_sched_barrier(0);
+#ifndef DIC_PP_NOBAR
         asm volatile("s_barrier" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -246,7 +252,11 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
     auto read_kc = [](bf16x8& dst, unsigned addr, auto imm_c) {
         constexpr int imm = decltype(imm_c)::value;
         i32x4 v;
+#ifdef DIC_PP_NOREAD
+        asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr));
+#else
         asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(v) : "v"(addr), "i"(imm));
+#endif
         dst = __builtin_bit_cast(bf16x8, v);
     };
     auto read_km = [](bf16x8& dst, unsigned addr, auto imm_c, auto hi_c) {
@@ -256,37 +266,43 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
         dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     f32x4 acc[CNT][G::FN];
-    bf16x8 fb[2][G::FN], fa[2][2];
-    unsigned sbA = 0, sbB = 0, aA[2] = {0, 0}, aB[2] = {0, 0};
-    auto read_a = [&](auto i_c, auto s_c) {              // both 32-deep halves of A fragment i into slot s
-        constexpr int i = decltype(i_c)::value, s = decltype(s_c)::value;
-        if constexpr (!AKM) {
-            read_kc(fa[s][0], aA[0], std::integral_constant<int, i * 2048>{});
-            read_kc(fa[s][1], aA[1], std::integral_constant<int, i * 2048>{});
-        } else {
-            read_km(fa[s][0], sbA + (unsigned)ofA[i], std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * ROWB_A>{});
-            read_km(fa[s][1], sbA + (unsigned)ofA[i], std::integral_constant<int, 32 * ROWB_A>{}, std::integral_constant<int, 4 * ROWB_A>{});
-        }
+    bf16x8 fb[2][G::FN], fa[2][4];          // fb[32-deep half][column fragment]; fa[phase parity][fragment of the phase]
+    constexpr int RA = AKM ? 2 : 1, RB = BKM ? 2 : 1;                  // LDS instructions per fragment read
+    constexpr int cap15 = 15;
+    constexpr int N_FB = (FH * RA + G::FN * RB) < cap15 ? (FH * RA + G::FN * RB) : cap15;      // reads of a "front + B" batch (lgkmcnt counts to 15)
+    constexpr int N_BK = BH * RA;
+    auto rd_a = [&](bf16x8& dst, unsigned sA, auto i_c, auto kk_c) {     // fragment i (0..CNT-1), 32-deep half kk, of the A tile at LDS address sA
+        constexpr int i = decltype(i_c)::value, kk = decltype(kk_c)::value;
+        if constexpr (!AKM) read_kc(dst, sA + ((unsigned)ofA[0] ^ (unsigned)(kk * 64)), std::integral_constant<int, i * 2048>{});
+        else read_km(dst, sA + (unsigned)ofA[i], std::integral_constant<int, kk * 32 * ROWB_A>{}, std::integral_constant<int, 4 * ROWB_A>{});
     };
-    auto read_b = [&](auto j_c) {
-        constexpr int j = decltype(j_c)::value;
-        if constexpr (!BKM) {
-            read_kc(fb[0][j], aB[0], std::integral_constant<int, (32 * (j >> 1) + 4 * (j & 1)) * 128>{});
-            read_kc(fb[1][j], aB[1], std::integral_constant<int, (32 * (j >> 1) + 4 * (j & 1)) * 128>{});
-        } else {
-            read_km(fb[0][j], sbB + (unsigned)ofB[j], std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * ROWB_B>{});
-            read_km(fb[1][j], sbB + (unsigned)ofB[j], std::integral_constant<int, 32 * ROWB_B>{}, std::integral_constant<int, 4 * ROWB_B>{});
-        }
+    auto rd_b = [&](bf16x8& dst, unsigned sB, auto j_c, auto kk_c) {
+        constexpr int j = decltype(j_c)::value, kk = decltype(kk_c)::value;
+        if constexpr (!BKM) read_kc(dst, sB + ((unsigned)ofB[0] ^ (unsigned)(kk * 64)), std::integral_constant<int, (32 * (j >> 1) + 4 * (j & 1)) * 128>{});
+        else read_km(dst, sB + (unsigned)ofB[j], std::integral_constant<int, kk * 32 * ROWB_B>{}, std::integral_constant<int, 4 * ROWB_B>{});
+    };
+    // batch reads: `first` A fragment, `n` fragments, half kk -> fa[set][0..n-1]; all four B fragments of half kk -> fb[kk]
+    auto read_a_batch = [&](unsigned sA, auto first_c, auto n_c, auto kk_c, auto set_c) {
+        constexpr int first = decltype(first_c)::value, n = decltype(n_c)::value, set = decltype(set_c)::value;
+        if constexpr (n >= 1) rd_a(fa[set][0], sA, std::integral_constant<int, first>{}, kk_c);
+        if constexpr (n >= 2) rd_a(fa[set][1], sA, std::integral_constant<int, first + 1>{}, kk_c);
+        if constexpr (n >= 3) rd_a(fa[set][2], sA, std::integral_constant<int, first + 2>{}, kk_c);
+        if constexpr (n >= 4) rd_a(fa[set][3], sA, std::integral_constant<int, first + 3>{}, kk_c);
+    };
+    auto read_b_batch = [&](unsigned sB, auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        rd_b(fb[kk][0], sB, std::integral_constant<int, 0>{}, kk_c); rd_b(fb[kk][1], sB, std::integral_constant<int, 1>{}, kk_c);
+        rd_b(fb[kk][2], sB, std::integral_constant<int, 2>{}, kk_c); rd_b(fb[kk][3], sB, std::integral_constant<int, 3>{}, kk_c);
     };
     // fused bias gradient (weight gradients): column sums of the A tile that is in LDS anyway.  Thread -> source chunk cs = tid & 15 (8 tile rows)
     // of k-rows (tid >> 4) and (tid >> 4) + 32 of each half tile; the chunk sits at position cs ^ key(k).
     bool do_cs = false;
     f32x4 csF0{0.f, 0.f, 0.f, 0.f}, csF1 = csF0, csK0 = csF0, csK1 = csF0;
     i32x4 csr0, csr1;
-    auto cs_read = [&csr0, &csr1, &sbA, tid](auto half_c) {      // (explicit captures: an asm operand alone does not make a generic lambda capture)
+    auto cs_read = [&csr0, &csr1, tid](unsigned sA, auto half_c) {      // (explicit captures: an asm operand alone does not make a generic lambda capture)
         constexpr int half = decltype(half_c)::value;
         const int k0 = tid >> 4, cs = tid & 15;
-        const unsigned a0 = sbA + half * 16384 + k0 * 256 + ((cs ^ km_key(k0)) << 4);      // km_key(k + 32) == km_key(k)
+        const unsigned a0 = sA + half * 16384 + k0 * 256 + ((cs ^ km_key(k0)) << 4);      // km_key(k + 32) == km_key(k)
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192" : "=&v"(csr0), "=v"(csr1) : "v"(a0));
     };
     auto cs_add = [&csr0, &csr1](f32x4& s0, f32x4& s1) {
@@ -294,83 +310,108 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
         unpack8(csr0, a, b); s0 += a; s1 += b;
         unpack8(csr1, a, b); s0 += a; s1 += b;
     };
-    // the segment's reads have returned (the statement names what it validates: no consumer may be scheduled above it)
-    auto wait_frags = [&fa, &fb, &csr0, &csr1](auto with_b_c, auto with_cs_c) {
-        if constexpr (decltype(with_b_c)::value) {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3]),
-                           "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]));
-        } else if constexpr (decltype(with_cs_c)::value) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(csr0), "+v"(csr1));
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]));
-        }
+    // Counted wait at the end of a load segment: the operands of the NEXT compute segment (read one segment earlier) have returned; the n
+    // LDS instructions issued in this segment may still be in flight (LDS returns in order).  The statement names what it validates, so no
+    // consumer can be scheduled above it.
+    auto wait_ops = [&fa, &fb, &csr0, &csr1](auto set_c, auto n_c, auto nfrag_c, auto with_b_c) {
+        constexpr int set = decltype(set_c)::value, n = decltype(n_c)::value < 15 ? decltype(n_c)::value : 15, nf = decltype(nfrag_c)::value;
+        constexpr bool wb = decltype(with_b_c)::value;
+        // (only the registers the coming compute segment reads are named: naming a dead register would keep it allocated)
+        if constexpr (wb) asm volatile("; operands B" : "+v"(fb[set][0]), "+v"(fb[set][1]), "+v"(fb[set][2]), "+v"(fb[set][3]));
+        if constexpr (COLSUM) asm volatile("; operands cs" : "+v"(csr0), "+v"(csr1));
+        if constexpr (nf == 4) asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]) : "i"(n));
+        else if constexpr (nf == 3) asm volatile("s_waitcnt lgkmcnt(%c3)" : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]) : "i"(n));
+        else if constexpr (nf == 2) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(fa[set][0]), "+v"(fa[set][1]) : "i"(n));
+        else if constexpr (nf == 1) asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fa[set][0]) : "i"(n));
+        else asm volatile("s_waitcnt lgkmcnt(%c0)" ::"i"(n));
+        if constexpr (wb) asm volatile("; operands B" : "+v"(fb[set][0]), "+v"(fb[set][1]), "+v"(fb[set][2]), "+v"(fb[set][3]));
+        if constexpr (COLSUM) asm volatile("; operands cs" : "+v"(csr0), "+v"(csr1));
     };
-    auto phase_reads = [&](auto f0_c, auto n_c) {
-        constexpr int f0 = decltype(f0_c)::value, n = decltype(n_c)::value;
-        if constexpr (n >= 1) read_a(std::integral_constant<int, f0>{}, std::integral_constant<int, 0>{});
-        if constexpr (n >= 2) read_a(std::integral_constant<int, f0 + 1>{}, std::integral_constant<int, 1>{});
-    };
-    auto phase_mfma = [&](auto f0_c, auto n_c) {
-        constexpr int f0 = decltype(f0_c)::value, n = decltype(n_c)::value;
+    // compute segment: n fragments starting at `first`, operands fa[set] / fb[set]
+    auto phase_mfma = [&](auto first_c, auto n_c, auto set_c) {
+        constexpr int first = decltype(first_c)::value, n = decltype(n_c)::value, set = decltype(set_c)::value;
+#ifndef DIC_PP_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int s = 0; s < n; ++s)
 #pragma unroll
-            for (int s = 0; s < n; ++s)
-#pragma unroll
-                for (int j = 0; j < G::FN; ++j)
-                    acc[f0 + s][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[s][kk], acc[f0 + s][j], 0, 0, 0);
+            for (int j = 0; j < G::FN; ++j) {
+#ifdef DIC_PP_NOMFMA
+                asm volatile("; no mfma %0 %1 %2" : "+v"(acc[first + s][j]) : "v"(fb[set][j]), "v"(fa[set][s]));
+#else
+                acc[first + s][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][s], acc[first + s][j], 0, 0, 0);
+#endif
+            }
+#ifndef DIC_PP_NOPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
+#ifdef DIC_PP_TRACE      // measurement build (scripts/experiments/pp_trace.py): s_memtime of waves 0 and 4 of workgroup 0 around every barrier of K-steps 4..11
+    unsigned long long* trace = (unsigned long long*)p.tgt_logit;
+    int trace_n = -1;        // >= 0: recording
+#define PP_STAMP() do { if (trace_n >= 0 && trace_n < 256) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (lane == 0) trace[(wave >> 2) * 256 + trace_n] = t__; ++trace_n; } } while (0)
+#else
+#define PP_STAMP() do { } while (0)
+#endif
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
+    using IFH = std::integral_constant<int, FH>;
+    using IBH = std::integral_constant<int, BH>;
     using Tt = std::true_type;
     using Ff = std::false_type;
-    auto kstep = [&](int stage, bool fresh) {
-        sbA = lds_base + (unsigned)stage * G::STAGE; sbB = sbA + G::A_BYTES;
-        if constexpr (!AKM) { aA[0] = sbA + (unsigned)ofA[0]; aA[1] = sbA + ((unsigned)ofA[0] ^ 64u); }
-        if constexpr (!BKM) { aB[0] = sbB + (unsigned)ofB[0]; aB[1] = sbB + ((unsigned)ofB[0] ^ 64u); }
+    // The operands of a compute segment are read one load segment EARLIER (into the other fa set / the other half of fb), so a load segment
+    // never waits for the latency of its own reads -- it only issues -- and the compute order is: front fragments x first half, front x second
+    // half, back x first half, back x second half (both halves of an accumulator are two segments apart).
+    //   L0: reads [front, B] second half        | waits back(k) landed        | M0: front x half 0
+    //   L1: reads back first half               | DMA back(k+1), cursor on    | M1: front x half 1
+    //   L2: reads back second half              | waits front/B(k+1) landed, DMA front(k+2) + half of B(k+2) | M2: back x half 0
+    //   L3: reads [front, B] first half of k+1  | DMA rest of B(k+2)          | M3: back x half 1
+    auto kstep = [&](int stage, bool fresh, bool last) {
+        const unsigned sbA = lds_base + (unsigned)stage * G::STAGE, sbB = sbA + G::A_BYTES;
+        const unsigned nbA = lds_base + (unsigned)(stage ^ 1) * G::STAGE, nbB = nbA + G::A_BYTES;
         // ---- L0 | M0
-        read_b(I0{}); read_b(I1{}); read_b(I2{}); read_b(I3{});
-        phase_reads(I0{}, std::integral_constant<int, NPH0>{});
+        read_a_batch(sbA, I0{}, IFH{}, I1{}, I1{});
+        read_b_batch(sbB, I1{});
+        if constexpr (COLSUM) { if (do_cs) cs_read(sbA, I0{}); }
+        if (!fresh) wait_vm(std::integral_constant<int, NF + 4>{}, std::integral_constant<int, NF + 4>{});
+        if constexpr (COLSUM) { if (do_cs) wait_ops(I0{}, std::integral_constant<int, N_FB + 2>{}, IFH{}, Tt{}); else wait_ops(I0{}, std::integral_constant<int, N_FB>{}, IFH{}, Tt{}); }
+        else wait_ops(I0{}, std::integral_constant<int, N_FB>{}, IFH{}, Tt{});
+        PP_STAMP(); bar(); PP_STAMP();
+        phase_mfma(I0{}, IFH{}, I0{});
+        PP_STAMP(); bar(); PP_STAMP();
+        // ---- L1 | M1
+        read_a_batch(sbA, IFH{}, IBH{}, I0{}, I0{});
         issue_back();
         advance();
-        wait_frags(Tt{}, Ff{});
-        bar();
-        phase_mfma(I0{}, std::integral_constant<int, NPH0>{});
-        bar();
-        // ---- L1 | M1: the back region of this stage (issued one K-step ago) must have landed before L2 reads it
-        phase_reads(std::integral_constant<int, PB1>{}, std::integral_constant<int, NPH1>{});
-        if constexpr (COLSUM) { if (do_cs) cs_read(I0{}); }
-        if (!fresh) wait_vm(std::integral_constant<int, 4 + NF + NBK0>{}, std::integral_constant<int, 4 + NF + NBK1>{});
-        issue_b(I0{});
-        if constexpr (COLSUM) {
-            if (do_cs) { wait_frags(Ff{}, Tt{}); cs_add(csF0, csF1); } else wait_frags(Ff{}, Ff{});
-        } else wait_frags(Ff{}, Ff{});
-        bar();
-        phase_mfma(std::integral_constant<int, PB1>{}, std::integral_constant<int, NPH1>{});
-        bar();
+        wait_ops(I1{}, std::integral_constant<int, N_BK>{}, IFH{}, Tt{});
+        if constexpr (COLSUM) { if (do_cs) cs_add(csF0, csF1); }
+        PP_STAMP(); bar(); PP_STAMP();
+        phase_mfma(I0{}, IFH{}, I1{});
+        PP_STAMP(); bar(); PP_STAMP();
         // ---- L2 | M2
-        phase_reads(std::integral_constant<int, PB2>{}, std::integral_constant<int, NPH2>{});
+        read_a_batch(sbA, IFH{}, IBH{}, I1{}, I1{});
+        if constexpr (COLSUM) { if (do_cs) cs_read(sbA, I1{}); }
+        if (!fresh) wait_vm(std::integral_constant<int, NBK0>{}, std::integral_constant<int, NBK1>{});
         issue_front();
-        wait_frags(Ff{}, Ff{});
-        bar();
-        phase_mfma(std::integral_constant<int, PB2>{}, std::integral_constant<int, NPH2>{});
-        bar();
-        // ---- L3 | M3: the next K-step's front + B regions must have landed before its L0 reads them
-        phase_reads(std::integral_constant<int, PB3>{}, std::integral_constant<int, NPH3>{});
-        if constexpr (COLSUM) { if (do_cs) cs_read(I1{}); }
-        if (!fresh) wait_vm(std::integral_constant<int, 2 + NF + NBK0>{}, std::integral_constant<int, 2 + NF + NBK1>{});
+        issue_b(I0{});
+        if constexpr (COLSUM) { if (do_cs) wait_ops(I0{}, std::integral_constant<int, N_BK + 2>{}, IBH{}, Ff{}); else wait_ops(I0{}, std::integral_constant<int, N_BK>{}, IBH{}, Ff{}); }
+        else wait_ops(I0{}, std::integral_constant<int, N_BK>{}, IBH{}, Ff{});
+        PP_STAMP(); bar(); PP_STAMP();
+        phase_mfma(IFH{}, IBH{}, I0{});
+        PP_STAMP(); bar(); PP_STAMP();
+        // ---- L3 | M3
+        if (!last) {
+            read_a_batch(nbA, I0{}, IFH{}, I0{}, I0{});
+            read_b_batch(nbB, I0{});
+        }
         issue_b(I2{});
-        if constexpr (COLSUM) {
-            if (do_cs) { wait_frags(Ff{}, Tt{}); cs_add(csK0, csK1); } else wait_frags(Ff{}, Ff{});
-        } else wait_frags(Ff{}, Ff{});
-        bar();
-        phase_mfma(std::integral_constant<int, PB3>{}, std::integral_constant<int, NPH3>{});
-        bar();
+        if (!last) wait_ops(I1{}, std::integral_constant<int, N_FB>{}, IBH{}, Ff{}); else wait_ops(I1{}, I0{}, IBH{}, Ff{});
+        if constexpr (COLSUM) { if (do_cs) cs_add(csK0, csK1); }
+        PP_STAMP(); bar(); PP_STAMP();
+        phase_mfma(IFH{}, IBH{}, I1{});
+        PP_STAMP(); bar(); PP_STAMP();
     };
 
     // ---- prologue: the stream's first two K-steps (all of the first; B and front of the second) -------------------------------------------
@@ -393,9 +434,17 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
             do_cs = p.colsum_out != nullptr && tl.bn == 0;
             csF0 = f32x4{0.f, 0.f, 0.f, 0.f}; csF1 = csF0; csK0 = csF0; csK1 = csF0;
         }
+        if (tl.kt0 < tl.kt1) {                  // the first compute segment's operands (later ones are read one segment ahead inside the loop)
+            const unsigned sbA0 = lds_base + (unsigned)(par & 1) * G::STAGE;
+            read_a_batch(sbA0, I0{}, IFH{}, I0{}, I0{});
+            read_b_batch(sbA0 + G::A_BYTES, I0{});
+        }
         if (wm == 1) bar();                     // second wave row: half a phase behind
         for (int kt = tl.kt0; kt < tl.kt1; ++kt) {
-            kstep(par & 1, fresh);
+#ifdef DIC_PP_TRACE
+            if (trace && blockIdx.x == 0 && (wave & 3) == 0 && unit == (int)blockIdx.x) { if (kt - tl.kt0 == 4) trace_n = 0; if (kt - tl.kt0 == 12) trace_n = -1; }
+#endif
+            kstep(par & 1, fresh, kt + 1 == tl.kt1);
             fresh = false;
             ++par;
         }

@@ -102,7 +102,7 @@ size_t dic_colsum_ws_bytes(int in_dtype, int rows, int cols);
 size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
 
 /* Measurement switch (PROCESS-GLOBAL state, like dic_prof_* below -- not for concurrent use from several threads): which K loop the bf16
- * 256-column geometry runs.  1 (default; env DIC_GEMM_PP) = the ping-pong loop of csrc/gemm_pp.h, 0 = the lock-step loop.  Results are
+ * 256-column geometry runs.  0 (default) = the lock-step loop, 1 (env DIC_GEMM_PP=1) = the ping-pong loop of csrc/gemm_pp.h.  Results are
  * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
 int dic_gemm_set_variant(int pp);
 
