@@ -27,7 +27,8 @@ def __getattr__(name):
         from .engine import Denoiser
         return Denoiser
     if name in ("AdamW", "diffuse_t", "generate_diffuse_pair", "loss", "train_func", "validate", "sample",
-                "alpha_cumprod_table", "set_alpha_cumprod", "seed_noise", "set_loaders", "dedup_columns"):
+                "alpha_cumprod_table", "set_alpha_cumprod", "seed_noise", "seed_timesteps", "seed_guidance", "seed_all", "rng_state",
+                "set_rng_state", "set_loaders", "dedup_columns"):
         from . import diffusion
         return getattr(diffusion, name)
     if name in ("bleu", "harness"):

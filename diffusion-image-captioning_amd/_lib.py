@@ -25,7 +25,7 @@ EXPORTS = [
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
-    "dic_gemm_set_variant",
+    "dic_gemm_set_variant", "dic_fuse_ln_fwd_x",
 ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.dic_embed_gather.argtypes = [P, P, P, I, I, I, P, P]
         L.dic_qsample.argtypes = [P, P, P, P, P, P, P, I, I, I, I, U64, P]
         L.dic_fuse_ln_fwd.argtypes = [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, P]
+        L.dic_fuse_ln_fwd_x.argtypes = [I, I, P, I64, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, P]
         L.dic_fuse_ln_bwd.argtypes = [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64, P]
         L.dic_temb_grad.argtypes = [P, P, I, I, I, I, P, P]
         L.dic_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]

@@ -63,9 +63,9 @@ constexpr int LNB_WAVES = 8;
 // Optional timestep embedding (BASELINE north_star names the operand; the reference has none -- its forward takes no t, ref :271 -- so it
 // is off, temb == NULL, in every parity configuration): row temb[tidx[n]] of a learned [steps][D] table is added to every token row of
 // sequence n before the LayerNorm (tidx[n] < 0: none for that sequence).
-__device__ __forceinline__ void fused_row(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+__device__ __forceinline__ void fused_row(int mode, const float* x, long long xs, const float* img, const float* txt, const uint8_t* add_txt,
                                           const float* seg, const float* pos, const float* temb, const int* tidx, int n, int t, int L, int lane,
-                                          f32x4 (&v)[NCH]) {
+                                          f32x4 (&v)[NCH]) {          // xs: elements between the first rows of consecutive sequences of x (L*D when packed)
     f32x4 p[NCH];
     load_row<float>(pos + (size_t)t * D, lane, p);
     if (temb) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void fused_row(int mode, const float* x, const float*
         }
     }
     if (mode != 1) {
-        const float* src = t < L ? x + ((size_t)n * L + t) * D : (t == L ? img + (size_t)n * D : txt + (size_t)n * D);
+        const float* src = t < L ? x + (size_t)n * xs + (size_t)t * D : (t == L ? img + (size_t)n * D : txt + (size_t)n * D);
         f32x4 s[NCH];
         load_row<float>(src, lane, v);
         load_row<float>(seg + (t < L ? 0 : D), lane, s);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void fused_row(int mode, const float* x, const float*
         for (int c = 0; c < NCH; ++c) v[c] = (v[c] + s[c]) + p[c];     // hstack + segment (ref :300), then + position (hf:115)
     } else {
         f32x4 a[NCH];
-        load_row<float>(x + ((size_t)n * L + t) * D, lane, v);
+        load_row<float>(x + (size_t)n * xs + (size_t)t * D, lane, v);
         load_row<float>(img + (size_t)n * D, lane, a);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) v[c] = v[c] + a[c];
@@ -101,7 +101,7 @@ __device__ __forceinline__ void fused_row(int mode, const float* x, const float*
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+__global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float* x, long long xs, const float* img, const float* txt, const uint8_t* add_txt,
                                                            const float* seg, const float* pos, const float* temb, const int* tidx,
                                                            const float* gamma, const float* beta, T* h,
                                                            float* mean, float* rstd, int N, int L, int Tk, float eps, float p_drop,
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float*
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH];
-        fused_row(mode, x, img, txt, add_txt, seg, pos, temb, tidx, n, t, L, lane, v);
+        fused_row(mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, n, t, L, lane, v);
         float mu, rs;
         row_stats(v, eps, mu, rs);
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void fuse_ln_bwd_kernel(int mode, c
     for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         const int n = row / Tk, t = row - n * Tk;
         f32x4 v[NCH], d[NCH];
-        fused_row(mode, x, img, txt, add_txt, seg, pos, temb, tidx, n, t, L, lane, v);
+        fused_row(mode, x, (long long)L * D, img, txt, add_txt, seg, pos, temb, tidx, n, t, L, lane, v);
         load_row<T>(dh + (size_t)row * D, lane, d);
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
@@ -319,19 +319,26 @@ inline int rows_grid(int rows, int cap) { int g = (rows + 3) / 4; return g < 1 ?
 
 #define DISPATCH_T(dtype, CALL_BF, CALL_F32) do { if ((dtype) == DIC_BF16) { CALL_BF; } else { CALL_F32; } } while (0)
 
-extern "C" int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
-                               const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
-                               void* h, float* mean, float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
+extern "C" int dic_fuse_ln_fwd_x(int dtype, int mode, const float* x, int64_t x_seq_stride, const float* img, const float* txt, const uint8_t* add_txt,
+                                 const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
+                                 void* h, float* mean, float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
     DIC_REQUIRE(temb == nullptr || tidx != nullptr, "dic_fuse_ln_fwd: a timestep-embedding table needs the per-sequence indices");
     DIC_REQUIRE(Dd == D, "dic_fuse_ln_fwd: D must be 768");
+    DIC_REQUIRE(x_seq_stride >= (int64_t)L * D && x_seq_stride % 4 == 0, "dic_fuse_ln_fwd_x: the sequence stride of x must cover L rows (and keep 16-byte alignment)");
     const int Tk = mode == 0 ? L + 2 : (mode == 2 ? L + 1 : L);
     dim3 grid(rows_grid(N * Tk, 2048)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const long long xs = (long long)x_seq_stride;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed),
-               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed));
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed),
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed));
     DIC_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
+                               const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
+                               void* h, float* mean, float* rstd, int N, int L, int Dd, float eps, float p_drop, uint64_t seed, void* stream) {
+    return dic_fuse_ln_fwd_x(dtype, mode, x, (int64_t)L * D, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, h, mean, rstd, N, L, Dd, eps, p_drop, seed, stream);
 }
 extern "C" int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,
                                const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const void* dh,

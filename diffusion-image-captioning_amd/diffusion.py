@@ -92,17 +92,61 @@ def _guidance_uniform(n, dev):
 T_SEED_BASE = 0x7157E9        # timestep draws: the SAME stream on every rank (one t-vector per step for the whole global batch, ref :461)
 
 
+def _next_t_seed() -> int:
+    """Seed of the next timestep draw: a per-process counter.  Its start follows torch's global seed (`torch.manual_seed(s)` changes the
+    t-vectors, as it does for the reference's `torch.randint`, ref :460-461) unless `seed_timesteps` / `seed_all` set it; under data
+    parallelism `parallel.configure_model_for_rank` makes every rank start from rank 0's value, so the ranks agree on t without a
+    per-step collective (`parallel.assert_shared_timestep_seed` checks it)."""
+    if "t_seed" not in _state:
+        _state["t_seed"] = (T_SEED_BASE + (torch.initial_seed() & 0x3FFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+    _state["t_seed"] += 1
+    return _state["t_seed"]
+
+
 def _draw_t(S, dev):
-    """torch.randint(0, STEP_TOT, (S,1,1)) of ref :460-461 from a Philox kernel.  The seed is a per-process step counter that starts from
-    the same value on every rank, so data-parallel ranks agree on t without a collective (and without a torch generator)."""
-    _state["t_seed"] = _state.get("t_seed", T_SEED_BASE) + 1
+    """torch.randint(0, STEP_TOT, (S,1,1)) of ref :460-461 from a Philox kernel keyed by the step counter above."""
+    seed = _next_t_seed()
     t = torch.empty((S, 1, 1), dtype=torch.int64, device=dev)
-    _lib.check(_lib.lib().dic_randint(_p(t), S, int(cfg.STEP_TOT), _state["t_seed"], torch.cuda.current_stream().cuda_stream), "randint")
+    _lib.check(_lib.lib().dic_randint(_p(t), S, int(cfg.STEP_TOT), seed, torch.cuda.current_stream().cuda_stream), "randint")
     return t
 
 
 def seed_timesteps(seed: int):
-    _state["t_seed"] = int(seed)
+    _state["t_seed"] = int(seed) & 0x7FFFFFFFFFFFFFFF
+
+
+def seed_all(seed: int, device=None):
+    """One integer for every random stream of the step (timesteps, q_sample noise, guidance mask): what `torch.manual_seed(seed)` is to the
+    reference's script.  Call it with the same value on every data-parallel rank BEFORE `parallel.configure_model_for_rank` (which then
+    mixes the rank into the per-item streams and leaves the timestep stream shared).  Dropout masks follow the model's own seed."""
+    s = int(seed) & 0xFFFFFFFFFFFF
+    seed_timesteps(T_SEED_BASE + s * 0x9E3779B1)
+    _state["noise_base"], _state["guidance_base"] = NOISE_SEED_BASE + s * 0x85EBCA6B, GUIDANCE_SEED_BASE + s * 0xC2B2AE35     # un-mixed: the
+    seed_noise(_state["noise_base"])                                                                    # per-rank seeds derive from these
+    seed_guidance(_state["guidance_base"], device)
+
+
+def rng_state(model=None) -> dict:
+    """Everything a resumed run needs to continue the SAME random streams (harness.save_checkpoint stores it): the timestep counter, the
+    q_sample noise counter, the guidance generators and, given the model, its dropout-mask counter."""
+    st = {"t_seed": _state.get("t_seed"), "noise_seed": _state["noise_seed"],
+          "guidance": {k: g.get_state().cpu() for k, g in _state["cfg_gen"].items()}}
+    if model is not None:
+        st["dropout_seed"] = int(model._seed)
+    return st
+
+
+def set_rng_state(st: dict, model=None):
+    if st.get("t_seed") is not None:
+        _state["t_seed"] = int(st["t_seed"])
+    _state["noise_seed"] = int(st["noise_seed"])
+    for k, gs in st.get("guidance", {}).items():
+        g = _state["cfg_gen"].get(k)
+        if g is None:
+            g = _state["cfg_gen"][k] = torch.Generator(device=torch.device(k))
+        g.set_state(gs)
+    if model is not None and "dropout_seed" in st:
+        model._seed = int(st["dropout_seed"])
 
 
 def _t_one(dev):
@@ -400,6 +444,10 @@ class AdamW:
 
 # ------------------------------------------------------------------ training step (ref :458-486)
 def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, cfg_uniform=None):
+    """ref :458-486.  Returns (l, x_t_loss, x_1_loss, prob_loss) as 0-dim device tensors.  LIFETIME: they are views into a ring of
+    LOSS_RING (4096) result slots per encoder workspace, written by the loss kernels themselves (no ATen kernel on the step): a value stays
+    valid for the next 4095 calls.  Accumulating (`acc += l`, what the reference's epoch loop does, ref :530-533) or reading them is always
+    fine; a caller that keeps per-step tensors for longer than that must `.clone()` them."""
     from . import parallel
     dev = model.device
     x_0 = model.embedding(x["input_ids"].to(dev))
@@ -475,36 +523,69 @@ def validate(model: Denoiser, val_loader=None):
             _, a, b, c = train_func(model, _state["trainer"], x, train=False)
             acc = [acc[0] + a.clone(), acc[1] + b.clone(), acc[2] + c.clone()]
             n += 1
+    model.check_ids(sync=True)          # an out-of-range token id in the last batch would otherwise never surface (nn.Embedding raises at once)
     model.train()
     return acc[0] / n, acc[1] / n, acc[2] / n
 
 
 # ------------------------------------------------------------------ sampling loop (ref :611-621, COCO_BLEU.py:249-256)
+_SAMPLE_GRAPH = _os.environ.get("DIC_SAMPLE_GRAPH", "1") == "1"      # replay passes 3..K of a sampling loop as one hipGraph (A/B switch)
+
+
 @torch.no_grad()
 def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=False):
     """x_0-prediction refinement from pure noise: `steps` encoder passes feeding the prediction straight back in,
     then round to token ids.  The logits are only needed after the last pass, and only their argmax: the
-    rounding GEMM runs in exact fp32 (MFMA f32) with a streaming arg-max, so ids match the CPU oracle bit-for-bit."""
+    rounding GEMM runs in exact fp32 (MFMA f32) with a streaming arg-max, so ids match the CPU oracle bit-for-bit.
+
+    What is constant over the loop is done once: the CLIP rows and the key mask are packed into the encoder's workspace and the CLIP
+    projections computed by the first pass only; every pass reads rows [:, :L] of the previous pass's x_out in place (strided read in
+    dic_fuse_ln_fwd_x) instead of compacting them; from the third pass on the passes are launch-for-launch identical and are replayed as
+    one hipGraph.  With cfg.TIMESTEP_EMBEDDING (not in the reference, which has no timestep input): the first pass sees pure noise and
+    takes the table row of t = STEP_TOT - 1, every later pass sees an x_0 estimate and takes row 1, the row training uses for the x_1 pass."""
     if model.te:
         from . import train_embedding
         return train_embedding.sample(model, image_clip, steps, start, return_hidden)
     dev = model.device
     B, L = image_clip.shape[0], cfg.MAX_LENGTH
-    Tk = L + 2 if model.concat else L
-    img = image_clip.to(dev, torch.float32)
-    restored = start.to(dev, torch.float32) if start is not None else torch.randn(B, L + 2, cfg.IN_CHANNEL, device=dev)
-    one = torch.ones(B, 1, dtype=torch.uint8, device=dev)
-    ones_l = torch.ones(B, L, dtype=torch.uint8, device=dev)
+    img = image_clip.to(dev, torch.float32).reshape(B, 512)
+    restored = (start.to(dev, torch.float32) if start is not None else torch.randn(B, L + 2, cfg.IN_CHANNEL, device=dev)).contiguous()
+    assert restored.shape[0] == B and restored.shape[1] >= L and restored.shape[2] == 768
     # the text row is masked as a key ([1, 0]) and only rows < L are fed back: skip it unless the caller wants the full hidden state
     drop_txt = model.concat and cfg.DROP_UNUSED_TEXT_ROW and not return_hidden
-    km = (torch.cat([ones_l, one], 1) if drop_txt else torch.cat([ones_l, one, 0 * one], 1)) if model.concat else ones_l
-    zeros = torch.zeros_like(img)
-    x = restored[:, :L, :].contiguous()
-    for _ in range(steps):
-        x_out = model.encode(x, img, zeros, km, drop_txt=drop_txt)
-        x = x_out[:, :L, :].contiguous()
-    xr = x.reshape(B * L, 768)
-    _, ids, _ = model.rounding(xr, B * L, dtype=_lib.DIC_F32)
+    ws = model._workspace(B, L, drop_txt)
+    Tk = ws["Tk"]
+    ws["img_in"][:B].copy_(img)
+    ws["txt_in"][:B].zero_()
+    ws["kmask"][:B].fill_(1)
+    if model.concat and not drop_txt:
+        ws["kmask"][:B, L + 1].zero_()
+    ws["addtxt"][:B].zero_()
+    t_first = t_later = None
+    if model.temb:
+        t_first = torch.full((B,), int(cfg.STEP_TOT) - 1, dtype=torch.int32, device=dev)
+        t_later = torch.ones(B, dtype=torch.int32, device=dev)
+    x_view = (restored.data_ptr(), restored.shape[1] * 768, B, L)
+    x_out, graph = None, None
+    for k in range(steps):
+        if graph is not None:
+            graph.replay()
+            continue
+        if k >= 1:
+            x_view = (x_out.data_ptr(), Tk * 768, B, L)
+        run = lambda: model.encode(None, None, None, None, drop_txt=drop_txt, x_view=x_view, inputs_ready=k > 0, tidx=t_first if k == 0 else t_later)
+        if _SAMPLE_GRAPH and k == 2 and steps >= 8 and not _os.environ.get("DIC_SAMPLE_GRAPH_OFF"):
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    run()
+                graph.replay()
+                continue
+            except Exception:                             # capture not possible here: run the loop launch by launch
+                graph = None
+        x_out = run()
+    x = x_out[:, :L, :].contiguous()
+    _, ids, _ = model.rounding(x.reshape(B * L, 768), B * L, dtype=_lib.DIC_F32)
     ids = ids.clone().reshape(B, L)
     return (ids, x_out.clone()) if return_hidden else ids
 

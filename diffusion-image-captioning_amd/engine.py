@@ -37,6 +37,8 @@ class Ops:
         self.dt = dtype_flag
         self._gp = GemmParams()
         self.stream = None
+        self.default_cu_cap = 0          # >0: bf16 GEMMs issued without an explicit cu_cap keep to this many CUs (set by parallel.GradReducer
+                                         # while a gradient slice is on the wire, DIC_DP_CU_CAP)
 
     def begin(self):
         self.stream = torch.cuda.current_stream().cuda_stream
@@ -56,7 +58,7 @@ class Ops:
         if tile is None:
             tile = choose_tile(M, N, split_k, epi) if (dt == DIC_BF16 and epi != EPI_CE_PARTIAL and (not a_km or M % 256 == 0)) else 128
         g.tile = tile
-        g.cu_cap = cu_cap
+        g.cu_cap = cu_cap if cu_cap else self.default_cu_cap
         _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
 
 
@@ -127,6 +129,9 @@ class Denoiser:
         self.te = bool(cfg.TRAIN_EMBEDDING)
         te_kw = dict(train_embedding_vocab=int(cfg.VOCAB_SIZE), in_channel=int(cfg.IN_CHANNEL)) if self.te else {}
         self.temb = bool(cfg.TIMESTEP_EMBEDDING)
+        if self.temb and self.te:
+            raise NotImplementedError("cfg.TIMESTEP_EMBEDDING is not wired into the TRAIN_EMBEDDING ablation (its loss / sampling paths pass no "
+                                      "timestep): the table would silently stay untrained")
         if self.temb:
             te_kw["timestep_embedding"] = int(cfg.STEP_TOT)
         self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16, **te_kw)
@@ -327,11 +332,18 @@ class Denoiser:
         return ws
 
     # ------------------------------------------------------------------ encoder forward (hf:92-118, 150-259, 501-513)
-    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None, tidx=None):
+    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None, tidx=None, x_view=None, inputs_ready=False):
         """x [N,L,768] fp32; image_clip/text_clip [N,512]; key_mask [N,Tk] uint8 -> x_out [N,Tk,768] fp32.
         Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training.
-        drop_txt (concat fusion, no guided row in the batch): run with Tk = L+1, leaving the never-read text row out."""
-        N, L, _ = x.shape
+        drop_txt (concat fusion, no guided row in the batch): run with Tk = L+1, leaving the never-read text row out.
+        x_view = (data_ptr, elements between sequences, N, L): read the L input rows of every sequence in place from a larger fp32 tensor
+        (the sampling loop's feedback of x_out[:, :L], ref :613-620) instead of from `x`; inputs_ready: the workspace's CLIP rows, key mask
+        and CLIP projections are those of the previous call (constant over a sampling loop) -- neither copied nor recomputed."""
+        if x_view is not None:
+            x_ptr, x_stride, N, L = x_view
+        else:
+            N, L, _ = x.shape
+            x_ptr, x_stride = None, L * self.dim
         ws = self._workspace(N, L, drop_txt, cap)
         Tk, T, D, Hd = ws["Tk"], ws["T"], self.dim, self.hidden
         o, P, lib = self.ops, self.params, self.ops.L
@@ -343,9 +355,11 @@ class Denoiser:
         self._seed += 64
         seed = self._seed
         ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
-        if x.data_ptr() != ws["xin"].data_ptr():
-            ws["xin"][:N].copy_(x)
-        if image_clip is not None:                     # None: the caller filled the workspace's input buffers itself
+        if x_ptr is None:
+            if x.data_ptr() != ws["xin"].data_ptr():
+                ws["xin"][:N].copy_(x)
+            x_ptr = _p(ws["xin"])
+        if image_clip is not None and not inputs_ready:                     # None: the caller filled the workspace's input buffers itself
             ws["img_in"][:N].copy_(image_clip.reshape(N, 512))
             ws["txt_in"][:N].copy_(text_clip.reshape(N, 512))
             ws["kmask"][:N].copy_(key_mask)
@@ -361,13 +375,14 @@ class Denoiser:
         temb_p, tidx_p = (P.ptr("temb"), _p(ws["tidx"])) if self.temb else (0, 0)
         mode = ws["mode"]
         # K3: CLIP projections, exact fp32 MFMA (tiny)
-        o.gemm(_p(ws["img_in"]), P.ptr("Wimg"), _p(ws["img_p"]), N, D, 512, 512, 512, D, bias=P.ptr("bimg"), out_f32=1, dtype=DIC_F32)
-        if mode != 2:
-            o.gemm(_p(ws["txt_in"]), P.ptr("Wtxt"), _p(ws["txt_p"]), N, D, 512, 512, 512, D, bias=P.ptr("btxt"), out_f32=1, dtype=DIC_F32)
+        if not inputs_ready:
+            o.gemm(_p(ws["img_in"]), P.ptr("Wimg"), _p(ws["img_p"]), N, D, 512, 512, 512, D, bias=P.ptr("bimg"), out_f32=1, dtype=DIC_F32)
+            if mode != 2:
+                o.gemm(_p(ws["txt_in"]), P.ptr("Wtxt"), _p(ws["txt_p"]), N, D, 512, 512, 512, D, bias=P.ptr("btxt"), out_f32=1, dtype=DIC_F32)
         # K4: concat/add fusion + segment + position + LayerNorm (+ dropout)
-        _lib.check(lib.dic_fuse_ln_fwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
-                                       P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
-                                       _p(ws["h"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
+        _lib.check(lib.dic_fuse_ln_fwd_x(self.dt, mode, x_ptr, x_stride, _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
+                                         P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
+                                         _p(ws["h"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
         for i in range(self.n_layers):
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
@@ -641,9 +656,13 @@ class Denoiser:
         return guided, plain, gmask
 
     @torch.no_grad()
-    def forward(self, x, image_clip, text_clip, mask, concat_mask, with_logits=True):
+    def forward(self, x, image_clip, text_clip, mask, concat_mask, with_logits=True, *, t=None):
         """Inference-shaped call with the reference's signature: returns (vocab_logits [N,L,V], x_out [N,Tk,768]).
-        Training goes through `diffusion.loss`, which shares `encode`/`rounding` but never builds the logits."""
+        Training goes through `diffusion.loss`, which shares `encode`/`rounding` but never builds the logits.
+        t ([N] ints, keyword-only): the timestep of every row, REQUIRED when cfg.TIMESTEP_EMBEDDING is on (the reference's forward has no
+        such input, ref :271; a model trained with the table must not silently run without it)."""
+        if self.temb and t is None:
+            raise ValueError("this model was built with cfg.TIMESTEP_EMBEDDING: forward() needs t= (the timestep of every row)")
         n = x.shape[0]
         L = cfg.MAX_LENGTH
         assert x.shape == (n, L, cfg.IN_CHANNEL)
@@ -665,7 +684,11 @@ class Denoiser:
             add_txt = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev), torch.ones(len(gi), dtype=torch.uint8, device=dev)])
         else:
             xs, ic, tc, km, add_txt = x, image_clip, text_clip, plain, torch.zeros(n, dtype=torch.uint8, device=dev)
-        x_all = self.encode(xs.contiguous(), ic, tc, km, add_txt)
+        tidx = None
+        if self.temb:
+            tt = torch.as_tensor(t).to(dev, torch.int32).reshape(n)
+            tidx = torch.cat([tt, tt[gi]]) if gi is not None else tt
+        x_all = self.encode(xs.contiguous(), ic, tc, km, add_txt, tidx=tidx)
         if gi is not None:
             Tk = x_all.shape[1]
             _lib.check(self.ops.L.dic_cfg_mix_fwd(_p(x_all), _p(x_all[n:]), _p(gi), len(gi), Tk * 768, float(w), self.ops.stream), "cfg_mix")

@@ -46,8 +46,11 @@ def log_line(epoch, acc, n_batches, val):
 def save_checkpoint(path, model, trainer=None, **extra):
     """State-dict checkpoint: reference-named parameter tensors + (unlike the reference, which drops it on resume :508)
     the AdamW state + the hyper-parameter snapshot."""
+    from . import diffusion
+    if hasattr(model, "check_ids"):
+        model.check_ids(sync=True)               # never persist parameters trained on a batch with an out-of-range token id
     sd = {"params": {k: v.cpu() for k, v in model.params.state_dict().items()}, "n_layers": model.n_layers,
-          "cfg": dict(vars(cfg)), "extra": extra}
+          "cfg": dict(vars(cfg)), "extra": extra, "rng": diffusion.rng_state(model)}     # rng: a resumed run continues the same t / noise / mask streams
     if trainer is not None and hasattr(trainer, "state_dict"):
         o = trainer.state_dict()
         sd["optimizer"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in o.items()}
@@ -61,6 +64,9 @@ def load_checkpoint(path, model, trainer=None):
     if trainer is not None and "optimizer" in sd and hasattr(trainer, "load_state_dict"):
         o = sd["optimizer"]
         trainer.load_state_dict({k: (v.to(model.device) if torch.is_tensor(v) else v) for k, v in o.items()})
+    if "rng" in sd:
+        from . import diffusion
+        diffusion.set_rng_state(sd["rng"], model)
     return sd.get("extra", {})
 
 
@@ -71,7 +77,7 @@ def fit(model, trainer, train_loader, val_loader, epochs=None, scheduler="linspa
     ref :520-522), accumulate the four losses lazily (no host sync inside the loop, ref :530-533), validate once per epoch,
     early-stop bookkeeping (`val > EARLY_STOP_RATIO * train`: write "early stop!", save once, keep training; ref :547-553),
     optional dynamic rounding weight (ref :535-536), one log line per epoch."""
-    from . import diffusion
+    from . import diffusion, parallel
     train_func = train_func or diffusion.train_func
     validate = validate or diffusion.validate
     epochs = cfg.EPOCH_NUM if epochs is None else epochs
@@ -93,6 +99,10 @@ def fit(model, trainer, train_loader, val_loader, epochs=None, scheduler="linspa
                 cfg.ROUNDING_WEIGHT = float(((acc[0] + acc[1]) / acc[2]).detach()) * cfg.DYNAMIC_ROUNDING_WEIGHT
             if cfg.DEBUG:
                 break
+        if hasattr(model, "check_ids"):
+            model.check_ids(sync=True)           # the epoch's last batch (validate() checks its own)
+        if parallel.world_size() > 1:
+            parallel.assert_shared_timestep_seed()
         val = validate(model, val_loader)
         n_batches = len(train_loader) if hasattr(train_loader, "__len__") else max(n, 1)      # the reference divides by len(train_loader)
         if float(val[0] + val[1] + val[2]) > cfg.EARLY_STOP_RATIO * float(acc[3]) / max(n_batches, 1):

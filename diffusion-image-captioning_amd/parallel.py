@@ -63,23 +63,6 @@ def shard(batch: dict, rank_: int | None = None, world: int | None = None) -> di
     return out
 
 
-_shared_gen = {}
-
-
-def shared_randint(lo: int, hi: int, shape, device) -> torch.Tensor:
-    """torch.randint whose result is identical on every rank.  The reference draws ONE t-vector per step for the whole batch
-    (ref :461); data parallel, every rank draws it from its own generator seeded with the same value (DIC_SHARED_SEED, default
-    fixed), so the ranks agree without a per-step collective."""
-    if not (is_initialized() and world_size() > 1):
-        return torch.randint(lo, hi, shape, device=device)
-    key = str(device)
-    g = _shared_gen.get(key)
-    if g is None:
-        g = _shared_gen[key] = torch.Generator(device=device)
-        g.manual_seed(int(os.environ.get("DIC_SHARED_SEED", "20260929")))
-    return torch.randint(lo, hi, shape, device=device, generator=g)
-
-
 def allreduce_flat(flat: torch.Tensor) -> torch.Tensor:
     """Sum `flat` across ranks in place with ONE collective."""
     if is_initialized() and world_size() > 1:
@@ -109,12 +92,22 @@ class GradReducer:
         # DIC_FORCE_REDUCER=1: run the exchange path at world size 1 too (single-GPU test of the data-parallel code path)
         self.active = is_initialized() and (world_size() > 1 or os.environ.get("DIC_FORCE_REDUCER", "0") == "1")
         self.group = max(1, int(os.environ.get("DIC_DP_GROUP", "3")))
+        # DIC_DP_SINGLE=1: north_star's literal design -- exactly ONE all-reduce of the whole flat buffer, after the backward (nothing
+        # overlaps it; A/B partner of the sliced default on the first multi-GPU run)
+        self.single = os.environ.get("DIC_DP_SINGLE", "0") == "1"
+        # DIC_DP_CU_CAP=n: while a slice is on the wire, the backward's persistent GEMMs keep to n CUs' worth of workgroups so that RCCL's
+        # kernels find free CUs (the 256-column GEMM holds 128 KB of LDS on every CU it runs on); 0 = no cap
+        self.cu_cap = int(os.environ.get("DIC_DP_CU_CAP", "0"))
+        self.model = model
+        self.n_collectives = 0
+        self.timing = os.environ.get("DIC_DP_TIMING", "0") == "1" and torch.cuda.is_available()
+        self._ev = []
 
     def layer_done(self, i):
         """Called by Denoiser.backward right after layer i's parameter gradients are complete (layers finish in descending
         order).  Layers are exchanged in groups of DIC_DP_GROUP (default 3: 85 MB per collective at 12 layers -- xGMI rings are
         per-link bound, fewer and larger collectives use them better than one per layer) as soon as a group is complete."""
-        if not self.active:
+        if not self.active or self.single:
             return
         rng = exchange_group(i, self.store.n_layers, self.group)
         if rng is None:
@@ -122,7 +115,18 @@ class GradReducer:
         last = rng[1]
         lo = self.store.off(f"L{i}.Wqkv")
         hi = self.store.off(f"L{last}.Wqkv") if last < self.store.n_layers else self.store.off("pos")
-        self.handles.append((dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi))
+        self._issue(lo, hi)
+        ops = getattr(self.model, "ops", None)
+        if self.cu_cap > 0 and ops is not None:
+            ops.default_cu_cap = self.cu_cap
+
+    def _issue(self, lo, hi):
+        ev0 = None
+        if self.timing:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        self.handles.append((dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi, ev0))
+        self.n_collectives += 1
 
     def finish(self, trainer=None):
         """Reduce the tail, then hand every slice to the optimizer as soon as ITS exchange has finished: with the fused AdamW the
@@ -131,22 +135,44 @@ class GradReducer:
         if not self.active:
             return
         tail = self.store.off("pos")
-        self.handles.append((dist.all_reduce(self.G[tail:], op=dist.ReduceOp.SUM, async_op=True), tail, self.store.numel))
+        ops = getattr(self.model, "ops", None)
+        if ops is not None:
+            ops.default_cu_cap = 0
+        if self.single:
+            self._issue(0, self.store.numel)
+        else:
+            self._issue(tail, self.store.numel)
         w = world_size()
         streamed = trainer is not None and hasattr(trainer, "step_range") and hasattr(trainer, "begin_step")
         if streamed:
             trainer.grad_scale = 1.0 / w
             trainer.begin_step()
-        for h, lo, hi in self.handles:
+        for h, lo, hi, ev0 in self.handles:
             h.wait()                                   # the current stream waits for this slice only
-            if streamed and hi <= tail:
+            if ev0 is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                self._ev.append((ev0, ev1))
+            if streamed and hi <= tail and not self.single:
                 trainer.step_range(lo, hi)
         self.handles = []
+        GradReducer.last = self
         if not streamed:
             if trainer is not None and hasattr(trainer, "grad_scale"):
                 trainer.grad_scale = 1.0 / w
             else:
                 self.G.mul_(1.0 / w)
+
+
+    def allreduce_ms(self):
+        """Issue-to-completion time of this step's collectives on the compute stream (DIC_DP_TIMING=1), summed; synchronises."""
+        if not self._ev:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._ev)
+
+
+GradReducer.last = None
 
 
 def allreduce_grads(model, trainer=None):
@@ -184,11 +210,38 @@ def rank_seed(base: int, rank_: int | None = None) -> int:
 def configure_model_for_rank(model, rank_: int | None = None):
     """What differs between the ranks of a data-parallel job: the noise eps, the dropout masks and the
     guidance uniforms are per item, so every rank draws its own (seeds mixed with the rank); the t-vector stays shared
-    (`shared_randint`); the forced unguided/guided rows 0/1 of ref :408-409 exist once per GLOBAL batch, i.e. on rank 0."""
+    (`share_timestep_seed`: rank 0's counter); the forced unguided/guided rows 0/1 of ref :408-409 exist once per GLOBAL batch, i.e. on rank 0."""
     from . import diffusion
     r = rank() if rank_ is None else rank_
     model.rank_rows_forced = r == 0
     model.set_dropout_seed(rank_seed(model.dropout_seed_base, r))
-    diffusion.seed_noise(rank_seed(diffusion.NOISE_SEED_BASE, r))
-    diffusion.seed_guidance(rank_seed(diffusion.GUIDANCE_SEED_BASE, r), model.device)
+    diffusion.seed_noise(rank_seed(diffusion._state.get("noise_base", diffusion.NOISE_SEED_BASE), r))
+    gbase = diffusion._state.get("guidance_base", diffusion.GUIDANCE_SEED_BASE)
+    diffusion.seed_guidance(rank_seed(gbase, r), model.device)
+    share_timestep_seed()
     return model
+
+
+def share_timestep_seed():
+    """Every rank continues the timestep stream from rank 0's counter (one small broadcast at configuration time, none per step)."""
+    from . import diffusion
+    if "t_seed" not in diffusion._state:
+        diffusion._next_t_seed()                          # materialise the default (torch.initial_seed()-derived) start
+    if is_initialized() and world_size() > 1:
+        box = [diffusion._state["t_seed"]]
+        dist.broadcast_object_list(box, src=0)
+        diffusion._state["t_seed"] = int(box[0])
+    return diffusion._state["t_seed"]
+
+
+def assert_shared_timestep_seed():
+    """The ranks must have drawn the same number of t-vectors (train AND validation steps): a rank-0-only validation, or uneven validation
+    shards, would silently desynchronise t.  One all-gather of an int; harness.fit calls it once per epoch."""
+    from . import diffusion
+    if not (is_initialized() and world_size() > 1):
+        return
+    seeds = [None] * world_size()
+    dist.all_gather_object(seeds, diffusion._state.get("t_seed"))
+    if len(set(seeds)) != 1:
+        raise RuntimeError(f"data-parallel ranks disagree on the timestep stream (t_seed per rank: {seeds}): every rank must call "
+                           "train_func / validate the same number of times")

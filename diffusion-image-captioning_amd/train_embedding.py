@@ -17,6 +17,8 @@ from . import _lib
 from ._lib import DIC_F32
 from .config import cfg
 
+LOSS_RING = 4096          # same lifetime of returned loss tensors as diffusion.LOSS_RING
+
 KP = 32          # K-step of the fp32 MFMA GEMM: the 16-d operands are zero-padded to it
 
 
@@ -40,7 +42,7 @@ def _buffers(model, N, L, Tk, M):
             return torch.zeros(*s, dtype=torch.float32, device=dev)
         b = dict(x16=f(N, L, C), x16p=f(N * L, KP), Winp=f(768, KP), x_out16=f(N, Tk, C), Woutp=f(KP, 768), dx16=f(N, Tk, C), g16=f(N, Tk, C),
                  dx16p=f(N * Tk, KP), xr16=f(M, C), xr32=f(M, KP), Wlm32=f(model.vpad, KP), dxr32=f(M, KP), dxr16=f(M, C),
-                 x16Tk=f(N, Tk, C), dxin16=f(N, Tk, C), dx0=f(cfg.BATCH_SIZE, L, C), dlogits=None, per_seq=f(N), gscale=f(N), ring=f(256, 8), slot=0,
+                 x16Tk=f(N, Tk, C), dxin16=f(N, Tk, C), dx0=f(cfg.BATCH_SIZE, L, C), dlogits=None, per_seq=f(N), gscale=f(N), ring=f(LOSS_RING, 8), slot=0,
                  cs=f(64 * max(Tk * C, 768)))
         model._te_ws[key] = b
     return b
@@ -170,7 +172,7 @@ def loss(model, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx, kind, cf
     off = (Nt + Ng) * row * 4
     _lib.check(lib.dic_emb_loss(DIC_F32, kind, _p(x_out16) + off, _p(x_0c), B, _p(b["per_seq"]) + Nt * 4, (dx + off) if want_grad else 0,
                                 _p(b["gscale"]) + Nt * 4, _p(b["xr16"]) + Nt * L * C * 4, B, L, Tk, C, st), "emb_loss")
-    b["slot"] = (b["slot"] + 1) % 256           # ring of result slots, as diffusion.loss (returned losses stay valid for 256 calls)
+    b["slot"] = (b["slot"] + 1) % LOSS_RING     # ring of result slots, as diffusion.loss (same lifetime: LOSS_RING calls)
     out = b["ring"][b["slot"]]
     _lib.check(lib.dic_seg_sum(_p(b["per_seq"]), Nt + B, Nt, sa, sb, _p(out), 0, st), "seg_sum")
     if want_grad:

@@ -140,6 +140,12 @@ int dic_fuse_ln_fwd(int dtype, int mode, const float* x, const float* img, const
                     const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
                     void* h, float* mean, float* rstd, int N, int L, int D, float eps,
                     float p_drop, uint64_t seed, void* stream);
+/* The same with x read in place from a larger tensor: sequence n's L rows start at x + n * x_seq_stride floats (the sampling loop feeds
+ * rows [:, :L] of the previous pass's x_out [N][Tk][D] straight back in, ref:613-620, without a compaction copy).                      */
+int dic_fuse_ln_fwd_x(int dtype, int mode, const float* x, int64_t x_seq_stride, const float* img, const float* txt, const uint8_t* add_txt,
+                      const float* seg, const float* pos, const float* temb, const int32_t* tidx, const float* gamma, const float* beta,
+                      void* h, float* mean, float* rstd, int N, int L, int D, float eps,
+                      float p_drop, uint64_t seed, void* stream);
 /* Backward: dh (T) -> dy [N][Tk][D] f32 (gradient wrt the pre-LN fused rows) and per-block partial sums of
  * dgamma/dbeta in `partial` [nblocks][2*D] (reduce with dic_colsum).                                              */
 int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float* img, const float* txt, const uint8_t* add_txt,

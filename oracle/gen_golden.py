@@ -318,8 +318,12 @@ def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "refdefault":
         # G: the reference's DEFAULT shape (ref :57-114: B=8, S=100, L=16, DistilBertConfig() = 6 layers, cosine T=1000, L1 loss): eval-mode
-        # forward + validate()-style losses only (one CPU training step at this size takes ~35 s and adds nothing the small cases do not pin)
-        run_case("refdefault_b8s100l16", B=8, S=100, L=16, n_layers=6, store_hidden=None, n_steps=0)
+        # forward + validate()-style losses + ONE AdamW step (backward and optimizer at the shape the reference actually trains at)
+        run_case("refdefault_b8s100l16", B=8, S=100, L=16, n_layers=6, store_hidden=None, n_steps=1)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg6":
+        # H: config-5 flavour at the reference depth: L=32, linear T=100, classifier-free guidance w=0.3, 6 layers
+        run_case("cfg6_b2s2l32", B=2, S=2, L=32, n_layers=6, cosine=False, step_tot=100, cfg_w=0.3, store_hidden=False)
         return
     run_lr_tables()
     # A: reference defaults shrunk (cosine T=1000, concat, L1, no CFG)

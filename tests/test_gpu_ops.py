@@ -312,8 +312,10 @@ def test_rounding_ce_partial_combine_and_backward(L, dtype, V, tile):
         top = logits.max(-1).values
         chosen = logits.gather(1, am.cpu().unsqueeze(1)).squeeze(1)
         assert float((top - chosen).max()) < 1e-3
-    np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=2e-6 if dtype == F32 else 2e-4)
-    np.testing.assert_allclose(nll.cpu().numpy(), o["lse"] - o["tgt_logit"], rtol=1e-5 if dtype == F32 else 1e-3, atol=1e-5)
+    # (the oracle sees the SAME bf16-rounded operands: what is tested is the streaming logsumexp / gather itself, measured at 3e-8 relative on
+    # 16 384 rows, profiles/r03_ce_gap_probe.txt line A; the bf16 engine's distance from the fp32 engine comes from its activations, not from here)
+    np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=2e-6 if dtype == F32 else 2e-5)
+    np.testing.assert_allclose(nll.cpu().numpy(), o["lse"] - o["tgt_logit"], rtol=1e-5 if dtype == F32 else 1e-4, atol=1e-5)
     # backward: dlogits epilogue + (KC,KM) GEMM against autograd of the oracle's rounding loss
     rows_a, sa, sb = M * 3 // 5, 0.5 / 3, 0.5 / 2
     dlog = torch.full((M, vpad), float("nan"), dtype=DT[dtype], device="cuda")
