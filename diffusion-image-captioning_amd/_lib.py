@@ -25,7 +25,7 @@ EXPORTS = [
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
-    "dic_gemm_set_variant", "dic_fuse_ln_fwd_x",
+    "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep",
 ]
 
 
@@ -123,6 +123,7 @@ def lib():
         L.dic_add_rows.argtypes = [P, P, I, I, I, I, P]
         L.dic_seg_sum.argtypes = [P, I, I, F, F, P, P, P]
         L.dic_step_prep.argtypes = [P, P, P, P, I, I, I, I, P, P, P, P, P, P, F, F, P]
+        L.dic_cfg_prep.argtypes = [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, F, F, P, P, P]
         L.dic_randint.argtypes = [P, I, I, U64, P]
         L.dic_zero.argtypes = [P, I64, P]
         L.dic_wgrad_group.argtypes = [C.POINTER(WgradItem), I, I, P, C.c_size_t, I, P]

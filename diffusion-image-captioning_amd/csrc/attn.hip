@@ -428,6 +428,11 @@ __device__ __forceinline__ bf16x8 tr_frag_clamped64(const char* lds, int s, int 
     s16x8 v = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
+// R1: registers of the SECOND 32-token tile that can hold a valid token (register r of a lane half covers tokens (r&3) + 8 (r>>2) + 4 hi): 4 up to
+// 40 tokens, 8 up to 48, 16 beyond.  Everything past them is padding whose probabilities are exactly zero, so the softmax / dropout / dS arithmetic
+// on those registers and the MFMA k-steps made only of them are skipped at compile time (34 tokens = config 5: 20 of 32 score registers per lane
+// and 3 of 4 k-steps remain; the kernel is VALU-bound on exactly that arithmetic).
+template <int R1>
 __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
                                                          int H, float scale, float p_drop, unsigned long long seed, int tile_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -488,6 +493,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if (kt == 1 && r >= R1) { st[kt][r] = 0.f; continue; }
                     const bool ok = (mbits >> (32 * kt + reg_tok(r, hi))) & 1ull;
                     st[kt][r] = ok ? st[kt][r] * scale : -INFINITY;
                     mx = fmaxf(mx, st[kt][r]);
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[kt][r] = (mx == -INFINITY) ? 0.f : __expf(st[kt][r] - mx); sum += st[kt][r]; }
+                for (int r = 0; r < 16; ++r) { if (kt == 1 && r >= R1) continue; st[kt][r] = (mx == -INFINITY) ? 0.f : __expf(st[kt][r] - mx); sum += st[kt][r]; }
             sum += __shfl_xor(sum, 32, 64);
             const float inv = sum > 0.f ? 1.0f / sum : 0.f;
             f32x16 dpt[2] = {rowdot_reg(fv0, fo), rowdot_reg(fv1, fo)};                 // dPd^T[key][query]
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
+                    if (kt == 1 && r >= R1) continue;
                     st[kt][r] *= inv; st[kt][r + 1] *= inv;                             // P
                     if (p_drop > 0.f) {
                         const unsigned hsh = attn_drop_hash64(mix, (unsigned)pair, 32 * qt + c, 32 * kt + reg_tok(r, hi));
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[kt][r] = st[kt][r] * (dpt[kt][r] - delta) * scale;      // dS[query][key]
+                for (int r = 0; r < 16; ++r) { if (kt == 1 && r >= R1) continue; st[kt][r] = st[kt][r] * (dpt[kt][r] - delta) * scale; }      // dS[query][key]
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             f32x16 o[2];
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
             for (int db = 0; db < 2; ++db) {                                            // dQ^T[d][query] = sum_key K[key][d] dS[query][key]
                 o[db] = zero16();
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < (R1 > 8 ? 4 : 3); ++s)          // 16-key steps; the last one is all padding up to 48 tokens
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(kt_, s, db, lane, zero_row), pack8(st[s >> 1], s & 1), o[db], 0, 0, 0);
             }
             put_out(ot, o[0], o[1], dQ, ld, 32 * qt, Tk, lane);
@@ -541,13 +548,16 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
         const int key = 32 * kt + c;
         const bool kok = (mbits >> key) & 1ull;
         f32x16 ov[2] = {zero16(), zero16()}, ok_[2] = {zero16(), zero16()};
-        for (int qt = 0; qt < nt; ++qt) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {              // (this kernel only runs beyond 32 tokens: always two query tiles; unrolled so that the
+                                                      //  padding tests below are compile-time)
             const RowFrags fq = rows_lds(qt_, 32 * qt), fo = rows_lds(dot, 32 * qt);
             f32x16 s2 = rowdot_reg(fq, fk);                                             // S[query(reg)][key(lane)]
             f32x16 dp2 = rowdot_reg(fo, fv);                                            // dPd[query][key]
             f32x16 pd, ds;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                if (qt == 1 && r >= R1) { pd[r] = 0.f; ds[r] = 0.f; continue; }
                 const int qi = 32 * qt + reg_tok(r, hi);
                 const float m_ = stats[qi], inv = stats[64 + qi], delta = stats[128 + qi];
                 float pr = (kok && m_ > -INFINITY) ? __expf(s2[r] * scale - m_) * inv : 0.f;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {       // queries 32 qt + 16 s ..: dV^T[d][key] += dO[q][d] Pd[q][key];  dK^T[d][key] += Q[q][d] dS[q][key]
+                for (int s = 0; s < ((qt == 1 && R1 <= 8) ? 1 : 2); ++s) {       // queries 32 qt + 16 s ..: dV^T[d][key] += dO[q][d] Pd[q][key];  dK^T[d][key] += Q[q][d] dS[q][key]
                     ov[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(dot, 2 * qt + s, db, lane, zero_row), pack8(pd, s), ov[db], 0, 0, 0);
                     ok_[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(qt_, 2 * qt + s, db, lane, zero_row), pack8(ds, s), ok_[db], 0, 0, 0);
                 }
@@ -725,7 +735,10 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
         const int rows = Tk < 64 ? ((Tk + 1 + 3) & ~3) : 64;          // valid rows + one zero row
         const int tile_bytes = rows * VSTRIDE;
         const size_t lds = (size_t)(4 * tile_bytes + TILE + 768);
-        hipLaunchKernelGGL(attn_bwd_bf16_t64, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
+        };
+        if (Tk <= 40) go(attn_bwd_bf16_t64<4>); else if (Tk <= 48) go(attn_bwd_bf16_t64<8>); else go(attn_bwd_bf16_t64<16>);
     } else if (dtype == DIC_BF16) {
         const int rows = Tk < 32 ? ((Tk + 1 + 3) & ~3) : 32;          // valid rows + one zero row
         const int tile_bytes = rows * VSTRIDE;

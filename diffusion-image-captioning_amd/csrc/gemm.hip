@@ -185,7 +185,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const DicGemmParams
                     }
                 } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {
                     v += *(const f32x4*)(p.bias + n);
-                    Elem<T>::st4((T*)p.aux + (size_t)m * p.ldaux + n, v);   // pre-activation u (for GELU')
+                    if (p.aux) Elem<T>::st4((T*)p.aux + (size_t)m * p.ldaux + n, v);   // pre-activation u (for GELU'); NULL: forward-only call
                     f32x4 gl;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) gl[r] = sizeof(T) == 2 ? gelu_fast(v[r]) : gelu_f(v[r]);
@@ -591,7 +591,9 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
         }
     } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {                 // N % 8 == 0 is required for this epilogue
         issue_next();
-        const LineBuf bU = line_buf(p.aux, p.ldaux, 2, n_first + lcol, p.N), bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
+        // aux == NULL: a forward-only call (sampling / validation under no_grad) -- the pre-activation is not kept: half the epilogue's stores
+        const bool keep_u = p.aux != nullptr;
+        const LineBuf bU = line_buf(keep_u ? p.aux : p.C, keep_u ? p.ldaux : p.ldc, 2, n_first + lcol, p.N), bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             i32x4 U[G::NP], A[G::NP];
@@ -602,7 +604,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 gelu_fast4(x0); gelu_fast4(x1);
                 A[q] = pack8f(x0, x1);
             }
-            put_lines(i, bU, U[0], U[1]);
+            if (keep_u) put_lines(i, bU, U[0], U[1]);
             put_lines(i, bC, A[0], A[1]);
         }
     } else if constexpr (EPI == DIC_EPI_GELU_BWD) {                  // dU = acc * gelu'(U)
@@ -1644,7 +1646,8 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (!a_km) DIC_REQUIRE((long long)BM * p.lda * es < 0x7FFFFFFFll, "dic_gemm: lda too large");
     if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
     if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD))
-        DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && p.ldaux % 8 == 0, "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
+        DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && (p.aux == nullptr || p.ldaux % 8 == 0), "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
+    if (epi == DIC_EPI_GELU_BWD) DIC_REQUIRE(p.aux != nullptr, "dic_gemm: GELU_BWD needs the pre-activation (aux)");
     if (dtype == DIC_BF16) DIC_REQUIRE(p.ldc % 4 == 0 && (p.R == nullptr || p.ldr % 4 == 0), "dic_gemm: ldc/ldr must be multiples of 4");
     if (p.tile == 256)
         DIC_REQUIRE(dtype == DIC_BF16 && !(epi == DIC_EPI_CE_PARTIAL && bf16_on_v1()) && (!a_km || p.M % 256 == 0) && (!b_km || p.N % 256 == 0 || p.N % 8 == 0),

@@ -218,6 +218,73 @@ extern "C" int dic_step_prep(const float* img, const float* txt, const int64_t* 
     DIC_CHECK_LAUNCH();
     return 0;
 }
+// The same for a step WITH classifier-free guidance (ref :406-415, 313-317): stacked batch [S*B x_t rows | Ng guided copies | B x_1 rows], where guided
+// copy i repeats x_t row gi[i] with the text key unmasked (concat fusion) / the text projection added ("add" fusion).  The host draws the guidance
+// mask (it needs Ng for every launch shape), uploads the row list once, and this launch does everything the reference's cat / repeat / index ops do:
+// CLIP rows, key masks, add_txt flags, target ids and loss scales (the rounding head and the embedding losses see only the x_t and x_1 rows), the
+// copy of the guided rows' noisy inputs inside xin, and the zero fill of their dx_out rows (cfg_mix_bwd accumulates into them).
+__global__ __launch_bounds__(256) void cfg_prep_kernel(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, const int64_t* gi, int S,
+                                                       int B, int L, int Tk, int Ng, float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt,
+                                                       int64_t* tgt, float* gscale, float sa, float sb, float* xin, float* dx, int D4) {
+    const int Nt = S * B, N = Nt + Ng + B;
+    const long long n_clip = (long long)N * 128, n_km = (long long)N * Tk, n_tgt = tgt ? (long long)(Nt + B) * L : 0, n_seq = N;
+    const long long n_x = (long long)Ng * L * D4, n_dx = dx ? (long long)Ng * Tk * D4 : 0;
+    const long long total = n_clip + n_km + n_tgt + n_seq + n_x + n_dx;
+    auto src_b = [&](int n, bool& guided) {          // batch item that row n of the stacked batch belongs to
+        guided = n >= Nt && n < Nt + Ng;
+        return n < Nt ? n % B : (guided ? (int)(gi[n - Nt] % B) : n - Nt - Ng);
+    };
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long j = i;
+        bool gd;
+        if (j < n_clip) {
+            const int n = (int)(j >> 7), c = (int)(j & 127), b = src_b(n, gd);
+            ((f32x4*)img_in)[j] = ((const f32x4*)img)[(size_t)b * 128 + c];
+            ((f32x4*)txt_in)[j] = ((const f32x4*)txt)[(size_t)b * 128 + c];
+            continue;
+        }
+        j -= n_clip;
+        if (j < n_km) {
+            const int n = (int)(j / Tk), c = (int)(j - (long long)n * Tk), b = src_b(n, gd);
+            kmask[j] = c < L ? (mask[(size_t)b * L + c] != 0) : (c == L ? 1 : (gd ? 1 : 0));   // token keys | image row | text row: guided copies only
+            continue;
+        }
+        j -= n_km;
+        if (j < n_tgt) {
+            const int n = (int)(j / L), c = (int)(j - (long long)n * L), b = n < Nt ? n % B : n - Nt;
+            tgt[j] = ids[(size_t)b * L + c];
+            continue;
+        }
+        j -= n_tgt;
+        if (j < n_seq) {
+            const int n = (int)j;
+            addtxt[n] = n >= Nt && n < Nt + Ng;
+            if (gscale && n < Nt + B) gscale[n] = n < Nt ? sa : sb;
+            continue;
+        }
+        j -= n_seq;
+        if (j < n_x) {
+            const long long row4 = (long long)L * D4;
+            const int g = (int)(j / row4);
+            ((f32x4*)xin)[(size_t)(Nt + g) * row4 + (j - g * row4)] = ((const f32x4*)xin)[(size_t)gi[g] * row4 + (j - g * row4)];
+            continue;
+        }
+        j -= n_x;
+        ((f32x4*)dx)[(size_t)Nt * Tk * D4 + j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+extern "C" int dic_cfg_prep(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, const int64_t* gi, int S, int B, int L, int Tk,
+                            int Ng, int D, float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt, int64_t* tgt, float* gscale, float scale_a,
+                            float scale_b, float* xin, float* dx, void* stream) {
+    DIC_REQUIRE(S > 0 && B > 0 && L > 0 && (Tk == L || Tk == L + 2) && Ng >= 0 && Ng <= S * B && D % 4 == 0, "dic_cfg_prep: Tk must be L or L+2, 0 <= Ng <= S*B");
+    DIC_REQUIRE(Ng == 0 || gi != nullptr, "dic_cfg_prep: guided row list missing");
+    const long long N = (long long)S * B + Ng + B;
+    const long long total = N * (128 + Tk + 1) + (long long)(S * B + B) * L + (long long)Ng * (L + Tk) * (D / 4);
+    hipLaunchKernelGGL(cfg_prep_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, img, txt, mask, ids, gi, S, B, L, Tk, Ng, img_in,
+                       txt_in, kmask, addtxt, tgt, gscale, scale_a, scale_b, xin, dx, D / 4);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
 // out[i] = uniform integer in [0, hi) from Philox4x32-10 keyed by (seed, i): the step's timestep vector (ref :460-461 torch.randint)
 __global__ void randint_kernel(int64_t* out, int n, unsigned hi, unsigned long long seed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

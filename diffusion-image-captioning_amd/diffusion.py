@@ -74,19 +74,61 @@ def seed_noise(seed: int):
 
 
 def seed_guidance(seed: int, device=None):
-    """(Re)seed the generator the classifier-free-guidance uniforms come from (one per device; per rank under data parallelism)."""
-    dev = torch.device(device if device is not None else "cuda:0")
-    g = torch.Generator(device=dev)
+    """(Re)seed the generator the classifier-free-guidance uniforms come from (per process = per rank under data parallelism).  It lives on
+    the HOST: the step needs the number of guided rows for its launch shapes, and drawing the Nt uniforms on the CPU (a few hundred numbers)
+    is what lets a guided step run without a device->host synchronisation.  `device` is accepted for compatibility and ignored."""
+    g = torch.Generator(device="cpu")
     g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
-    _state["cfg_gen"][str(dev)] = g
+    _state["cfg_gen"]["cpu"] = g
+    return g
+
+
+def _guidance_gen():
+    g = _state["cfg_gen"].get("cpu")
+    if g is None:
+        g = seed_guidance(GUIDANCE_SEED_BASE)
     return g
 
 
 def _guidance_uniform(n, dev):
-    g = _state["cfg_gen"].get(str(torch.device(dev)))
-    if g is None:
-        g = seed_guidance(GUIDANCE_SEED_BASE, dev)
-    return torch.rand((n, 1), device=dev, generator=g)
+    """torch.rand((n, 1)) of ref :407 from the guidance generator (host), returned on `dev`."""
+    return torch.rand((n, 1), generator=_guidance_gen()).to(dev)
+
+
+def _guidance_draw(model, Nt, cfg_uniform=None):
+    """ref :406-412: which of the Nt x_t rows get a guided copy.  Host-side draw (see seed_guidance); the ascending row list goes to the device
+    through a small ring of pinned staging buffers (asynchronous copy, no synchronisation).  Returns {"gi": device int64 [>= Ng], "Ng", "Nt"}."""
+    dev = model.device
+    if cfg_uniform is not None:                        # injected draw (parity tests): a host copy of it (this is the only path that may sync)
+        u = cfg_uniform.detach().reshape(-1).to("cpu", torch.float32)
+        assert u.numel() == Nt
+    else:
+        u = torch.rand(Nt, generator=_guidance_gen())
+    cm = u > cfg.CLASSIFIER_FREE_PROB
+    if model.rank_rows_forced:
+        cm[0] = False
+        cm[1] = True
+    gi = cm.nonzero().squeeze(1)
+    Ng = int(gi.numel())
+    ring = _state.setdefault(("gi_ring", str(dev)), {"slots": [], "i": 0})
+    if len(ring["slots"]) < 8:
+        ring["slots"].append({"host": torch.empty(max(Nt, 1), dtype=torch.int64).pin_memory(), "dev": torch.empty(max(Nt, 1), dtype=torch.int64, device=dev),
+                              "ev": None})
+        slot = ring["slots"][-1]
+    else:
+        ring["i"] = (ring["i"] + 1) % 8
+        slot = ring["slots"][ring["i"]]
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()                   # its last upload (8 steps ago) has long finished
+        if slot["host"].numel() < Nt:
+            slot["host"] = torch.empty(Nt, dtype=torch.int64).pin_memory()
+            slot["dev"] = torch.empty(Nt, dtype=torch.int64, device=dev)
+    if Ng:
+        slot["host"][:Ng].copy_(gi)
+        slot["dev"][:Ng].copy_(slot["host"][:Ng], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
+    return {"gi": slot["dev"], "Ng": Ng, "Nt": Nt}
 
 
 T_SEED_BASE = 0x7157E9        # timestep draws: the SAME stream on every rank (one t-vector per step for the whole global batch, ref :461)
@@ -216,18 +258,15 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     w = float(cfg.CLASSIFIER_FREE_WEIGHT)
     want_grad = torch.is_grad_enabled()
 
-    # ---- classifier-free-guidance draw (ref :406-412)
+    # ---- classifier-free-guidance draw (ref :406-412): on the host, so that Ng is known without a device->host synchronisation
     gi = None
+    Ng = 0
     if w > 0:
-        u = cfg_uniform.to(dev) if cfg_uniform is not None else _guidance_uniform(Nt, dev)
-        cm = (u > cfg.CLASSIFIER_FREE_PROB).reshape(Nt)
-        if model.rank_rows_forced:
-            cm[0] = False
-            cm[1] = True
-        gi = cm.nonzero().squeeze(1)
-        if gi.numel() == 0:
-            gi = None
-    Ng = 0 if gi is None else int(gi.numel())
+        draw = _state.pop("cfg_pending", None)          # train_func draws ahead (it places the x_1 rows behind the guided copies)
+        if draw is None or draw["Nt"] != Nt or cfg_uniform is not None and not draw.get("injected"):
+            draw = _guidance_draw(model, Nt, cfg_uniform)
+        Ng = draw["Ng"]
+        gi = draw["gi"][:Ng] if Ng else None
     model.params.text_unused = (not model.concat) and Ng == 0
     N = Nt + Ng + B
     # without a guided row the text row is masked as a key everywhere and its outputs are unused: leave it out (Tk = L+1)
@@ -273,9 +312,16 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
 
     def resident(t_, dtype):
         return t_.device == dev and t_.dtype == dtype and t_.is_contiguous()
-    fast = (w <= 0 and not model.temb and resident(image_clip, torch.float32) and resident(text_clip, torch.float32)
+    fast = (not model.temb and resident(image_clip, torch.float32) and resident(text_clip, torch.float32)
             and resident(mask, torch.int64) and resident(idx, torch.int64))
-    if fast:
+    if fast and Ng:
+        # guided step: the cats / repeats / index copies of ref :406-415, the guided rows' inputs and the zero fill of their dx rows are ONE kernel
+        st0 = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.dic_cfg_prep(_p(image_clip), _p(text_clip), _p(mask), _p(idx), _p(gi), S, B, L, Tk, Ng, 768, _p(ws["img_in"]), _p(ws["txt_in"]),
+                                    _p(ws["kmask"]), _p(ws["addtxt"]), _p(cw["tgt"]) if cfg.USE_PROB_LOSS else 0, _p(sc["gscale"]) if want_grad else 0,
+                                    sa, sb, _p(xin), _p(dx) if want_grad else 0, st0), "cfg_prep")
+        x_out = model.encode(xin[:N], None, None, None, drop_txt=drop_txt, cap=cap)
+    elif fast:
         # no guidance: the repeats / hstacks / cats of ref :406-415, 426 and the target ids of :434-437 are ONE kernel writing the
         # encoder's and the rounding head's input buffers (no ATen kernel on the step)
         st0 = torch.cuda.current_stream().cuda_stream
@@ -318,10 +364,9 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         _lib.check(lib.dic_cfg_mix_fwd(_p(x_out), _p(x_out) + Nt * row * 4, _p(gi), Ng, row, w, st), "cfg_mix_fwd")
 
     # ---- embedding losses (ref :77-87, 418, 428) + compact rows for the rounding head
-    if want_grad:
-        if not fast:
-            sc["gscale"][:Nt].fill_(sa)
-            sc["gscale"][Nt:Nt + B].fill_(sb)
+    if want_grad and not fast:
+        sc["gscale"][:Nt].fill_(sa)
+        sc["gscale"][Nt:Nt + B].fill_(sb)
         if Ng:
             dx[Nt:Nt + Ng].zero_()
     tgt_t, tgt_rows = (x_0, B) if cfg.X_0_PREDICTION else (x_tgt, Nt)
@@ -458,11 +503,20 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
     nz = list(noises) if noises is not None else [None, None, None]
     # without classifier-free guidance the stacked encoder batch is [x_t rows | x_1 rows]: q_sample writes straight into it
     out_t = out_1 = None
-    if float(cfg.CLASSIFIER_FREE_WEIGHT) <= 0 and cfg.X_0_PREDICTION and not model.te:
+    if cfg.X_0_PREDICTION and not model.te:
         Bc, Lc = x_0.shape[0], x_0.shape[1]
         Nt = t.numel() * Bc
-        xin = model._workspace(Nt + Bc, Lc, model.concat and cfg.DROP_UNUSED_TEXT_ROW)["xin"]
-        out_t, out_1 = xin[:Nt], xin[Nt:]
+        if float(cfg.CLASSIFIER_FREE_WEIGHT) <= 0:
+            xin = model._workspace(Nt + Bc, Lc, model.concat and cfg.DROP_UNUSED_TEXT_ROW)["xin"]
+            out_t, out_1 = xin[:Nt], xin[Nt:]
+        else:
+            # guidance: the guided copies sit between the x_t and the x_1 rows, so their number is drawn now (host side, no sync)
+            draw = _guidance_draw(model, Nt, cfg_uniform)
+            draw["injected"] = cfg_uniform is not None
+            _state["cfg_pending"] = draw
+            Ng_ = draw["Ng"]
+            xin = model._workspace(Nt + Ng_ + Bc, Lc, model.concat and cfg.DROP_UNUSED_TEXT_ROW and Ng_ == 0, 2 * Nt + Bc)["xin"]
+            out_t, out_1 = xin[:Nt], xin[Nt + Ng_:Nt + Ng_ + Bc]
     if cfg.X_0_PREDICTION:
         x_t = diffuse_t(x_0, t, noise=nz.pop(0), out=out_t)
         x_tgt = None

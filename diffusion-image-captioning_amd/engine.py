@@ -355,6 +355,8 @@ class Denoiser:
         self._seed += 64
         seed = self._seed
         ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
+        keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
+        ws["has_u"] = keep_u
         if x_ptr is None:
             if x.data_ptr() != ws["xin"].data_ptr():
                 ws["xin"][:N].copy_(x)
@@ -394,7 +396,8 @@ class Denoiser:
             o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(h), ldr=D)
             _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             # K8: FFN
-            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU, bias=P.ptr(pre + "b1"), aux=_p(Lw["u"]), ldaux=Hd)
+            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU, bias=P.ptr(pre + "b1"),
+                   aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
             o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa"]), ldr=D,
                    p_drop=ph, seed=seed + 4 * i + 2)
             _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
@@ -411,6 +414,7 @@ class Denoiser:
         layer_done(i): optional callback fired once layer i's gradients are complete (data-parallel overlap)."""
         ws = self._saved
         assert ws is not None, "backward() without a saved forward"
+        assert ws.get("has_u", True), "backward() after a forward run under torch.no_grad() (the FFN pre-activations were not kept)"
         N, L, Tk, T, D, Hd = ws["N"], ws["L"], ws["Tk"], ws["T"], self.dim, self.hidden
         o, P, lib = self.ops, self.params, self.ops.L
         o.begin()

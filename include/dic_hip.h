@@ -35,7 +35,8 @@ const char* dic_last_error(void);
  * Epilogues:
  *   AFFINE      C = dropout(acc + bias[n]) + R[m][n]   (bias, R optional; p_drop 0 = none); out T or f32,
  *               accumulate=1 adds the previous C (f32 output only)         -- nn.Linear fwd/bwd, residual adds
- *   BIAS_GELU   aux = acc + bias ; C = gelu(aux)                            -- hf:221-222 (ffn.lin1 + GELU)
+ *   BIAS_GELU   aux = acc + bias ; C = gelu(aux)                            -- hf:221-222 (ffn.lin1 + GELU); aux == NULL: the
+ *               pre-activation is not kept (forward-only calls: sampling, validation)
  *   GELU_BWD    C = acc * gelu'(aux)                                        -- backward of the above
  *   CE_PARTIAL  per (row, 64-col half tile): {max, sum exp(x-max), first argmax}; tgt_logit[m] = acc[m][tgt[m]]
  *               -- streaming form of softmax/gather/argmax over the 30522-wide logits (ref:323,436-437,620)
@@ -209,6 +210,13 @@ int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, f
 int dic_step_prep(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, int S, int B, int L, int Tk,
                   float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt, int64_t* tgt, float* gscale, float scale_a, float scale_b,
                   void* stream);
+/* The same for a step WITH classifier-free guidance (ref :406-415, 313-317): stacked batch [S*B x_t rows | Ng guided copies | B x_1 rows]; guided copy i
+ * repeats x_t row gi[i] (device list, ascending) with the text key unmasked (Tk = L+2) / add_txt set (Tk = L).  Also copies the guided rows' noisy inputs
+ * inside xin [N][L][D] (rows S*B+i <- rows gi[i]) and zero-fills rows [S*B, S*B+Ng) of dx [N][Tk][D] (optional).  tgt / gscale cover the S*B + B rows the
+ * losses see.  The host draws the guidance mask (it needs Ng for the launch shapes), so a guided step has no device->host sync and no ATen kernel.   */
+int dic_cfg_prep(const float* img, const float* txt, const int64_t* mask, const int64_t* ids, const int64_t* gi, int S, int B, int L, int Tk, int Ng, int D,
+                 float* img_in, float* txt_in, uint8_t* kmask, uint8_t* addtxt, int64_t* tgt, float* gscale, float scale_a, float scale_b,
+                 float* xin, float* dx, void* stream);
 /* out[i] ~ U{0..hi-1}, Philox4x32-10 keyed by (seed, i) -- the step's shared timestep vector (ref:460-461).                          */
 int dic_randint(int64_t* out, int n, int hi, uint64_t seed, void* stream);
 /* zero a 16-byte aligned device range (gradient slots a backward does not write)                                                      */
