@@ -216,12 +216,22 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # one GPU, no guidance: the step is captured once as a hipGraph and replayed (diffusion-image-captioning_amd/graph.py: same kernels, same
+    # arithmetic, bit-identical to the eager step; DIC_STEP_GRAPH=0 times the eager launches instead)
+    step = lambda: dic.train_func(model, trainer, x)
+    graph_note = "eager launches"
+    if world == 1 and w <= 0 and os.environ.get("DIC_STEP_GRAPH", "1") == "1":
+        try:
+            step = dic.GraphedTrainStep(model, trainer, x, warmup=2)
+            graph_note = "hipGraph replay of the captured step"
+        except Exception as e:                       # capture refused: time the eager step
+            graph_note = f"eager launches (graph capture failed: {type(e).__name__}: {e})"[:200]
     for _ in range(args.warmup):
-        dic.train_func(model, trainer, x)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = dic.train_func(model, trainer, x)
+        out = step()
     barrier()
     dt = time.perf_counter() - t0
     dt_local = dt
@@ -369,7 +379,7 @@ def main():
             "config": {"workload": f"train_func: B={B}/GPU x S={S} (+x_1 pass) = {(S + 1) * B} sequences x {L}+2 tokens (an unguided text row is "
                                    f"skipped), {args.layers}-layer DistilBERT-width denoiser, concat fusion, linear beta T=100, dropout 0.1, AdamW{guided}",
                        "global_batch": world * B, "seq_len": L, "sample_size": S, "n_layers": args.layers,
-                       "parallelism": f"dp{world}", "loss": round(loss_val, 4),
+                       "parallelism": f"dp{world}", "loss": round(loss_val, 4), "launch": graph_note,
                        "algorithmic_tflop_per_s": round(value * gf / 1e3, 2),
                        "executed_tflop_per_s": round(value * gflop_per_seq(L, args.layers, L + 1 if w <= 0 else L + 2) * (S + 1) / 1e3, 2)},
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, "bf16_vs_fp32_loss_rel": dtype_delta, "fp32_mode": fp32_mode,

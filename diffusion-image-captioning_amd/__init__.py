@@ -31,6 +31,9 @@ def __getattr__(name):
                 "set_rng_state", "set_loaders", "dedup_columns"):
         from . import diffusion
         return getattr(diffusion, name)
+    if name == "GraphedTrainStep":
+        from .graph import GraphedTrainStep
+        return GraphedTrainStep
     if name in ("bleu", "harness"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")

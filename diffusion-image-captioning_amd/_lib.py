@@ -25,7 +25,7 @@ EXPORTS = [
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
-    "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep",
+    "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep", "dic_step_ctx_set", "dic_step_advance",
 ]
 
 
@@ -42,6 +42,7 @@ class GemmParams(C.Structure):
         ("tgt", C.c_void_p), ("lse", C.c_void_p), ("partial", C.c_void_p), ("tgt_logit", C.c_void_p),
         ("ce_rows_a", C.c_int), ("ce_scale_a", C.c_float), ("ce_scale_b", C.c_float),
         ("split_k", C.c_int), ("split_ws", C.c_void_p), ("tile", C.c_int), ("cu_cap", C.c_int), ("colsum_out", C.c_void_p),
+        ("step_ctr", C.c_void_p), ("step_ctr0", C.c_int64),          # reserved (filled by dic_gemm from the step context)
     ]
 
 
@@ -125,6 +126,8 @@ def lib():
         L.dic_step_prep.argtypes = [P, P, P, P, I, I, I, I, P, P, P, P, P, P, F, F, P]
         L.dic_cfg_prep.argtypes = [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, F, F, P, P, P]
         L.dic_randint.argtypes = [P, I, I, U64, P]
+        L.dic_step_ctx_set.argtypes = [P, I64, U64, P]
+        L.dic_step_advance.argtypes = [P, P]
         L.dic_zero.argtypes = [P, I64, P]
         L.dic_wgrad_group.argtypes = [C.POINTER(WgradItem), I, I, P, C.c_size_t, I, P]
         L.dic_wgrad_group_ws_bytes.argtypes = [C.POINTER(WgradItem), I, I, I]

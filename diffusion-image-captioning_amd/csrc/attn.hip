@@ -104,7 +104,8 @@ __device__ __forceinline__ f32x16 rowdot(const bf16_t* X, int ldx, const bf16_t*
 
 // ------------------------------------------------------------------------------------------------ bf16 forward
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* ctx, int N, int Tk, int H,
-                                                      float scale, float p_drop, unsigned long long seed) {
+                                                      float scale, float p_drop, SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 4 + wave;
@@ -200,7 +201,8 @@ __device__ __forceinline__ f32x16 rowdot_reg(const RowFrags& a, const RowFrags& 
 }
 
 __global__ __launch_bounds__(256, 3) void attn_bwd_bf16(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
-                                                      int H, float scale, float p_drop, unsigned long long seed, int tile_bytes) {
+                                                      int H, float scale, float p_drop, SeedArg seed_, int tile_bytes) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 4 + wave;
@@ -349,7 +351,8 @@ __device__ __forceinline__ void put_out(char* tile, const f32x16& o0, const f32x
 }
 
 __global__ __launch_bounds__(128) void attn_fwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, bf16_t* ctx, int N, int Tk, int H,
-                                                         float scale, float p_drop, unsigned long long seed) {
+                                                         float scale, float p_drop, SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 2 + wave;
@@ -434,7 +437,8 @@ __device__ __forceinline__ bf16x8 tr_frag_clamped64(const char* lds, int s, int 
 // and 3 of 4 k-steps remain; the kernel is VALU-bound on exactly that arithmetic).
 template <int R1>
 __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
-                                                         int H, float scale, float p_drop, unsigned long long seed, int tile_bytes) {
+                                                         int H, float scale, float p_drop, SeedArg seed_, int tile_bytes) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x;       // one wave per workgroup: LDS (27 KB at 34 tokens) is what bounds residency, five of these fit a CU
@@ -587,7 +591,8 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
 constexpr int TMAX = 64, PADW = 65;
 template <typename T>
 __global__ __launch_bounds__(64) void attn_fwd_f32(const T* qkv, const uint8_t* key_mask, T* ctx, int N, int Tk, int H, float scale,
-                                                    float p_drop, unsigned long long seed) {
+                                                    float p_drop, SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q = (float*)smem;
     float* k = q + Tk * PADW;
@@ -633,7 +638,8 @@ __global__ __launch_bounds__(64) void attn_fwd_f32(const T* qkv, const uint8_t* 
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_f32(const T* qkv, const uint8_t* key_mask, const T* dctx, T* dqkv, int N, int Tk, int H,
-                                                    float scale, float p_drop, unsigned long long seed) {
+                                                    float scale, float p_drop, SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q = (float*)smem;
     float* k = q + Tk * PADW;
@@ -712,12 +718,12 @@ extern "C" int dic_attn_fwd(int dtype, const void* qkv, const uint8_t* key_mask,
         DIC_REQUIRE((long long)N * H < (1ll << 21), "dic_attn: at most 2^21 (sequence, head) pairs per launch beyond 32 tokens (32-bit dropout index)");
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_t64, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * TILE); attr = true; }
-        hipLaunchKernelGGL(attn_fwd_bf16_t64, dim3((N * H + 1) / 2), dim3(128), 2 * 3 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        hipLaunchKernelGGL(attn_fwd_bf16_t64, dim3((N * H + 1) / 2), dim3(128), 2 * 3 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP));
     } else if (dtype == DIC_BF16) {
-        hipLaunchKernelGGL(attn_fwd_bf16, dim3((N * H + 3) / 4), dim3(256), 4 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        hipLaunchKernelGGL(attn_fwd_bf16, dim3((N * H + 3) / 4), dim3(256), 4 * TILE, st, (const bf16_t*)qkv, key_mask, (bf16_t*)ctx, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP));
     } else {
         size_t lds = (size_t)(3 * Tk * PADW + Tk * (Tk + 1)) * sizeof(float);
-        hipLaunchKernelGGL(attn_fwd_f32<float>, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (float*)ctx, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        hipLaunchKernelGGL(attn_fwd_f32<float>, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (float*)ctx, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP));
     }
     DIC_CHECK_LAUNCH();
     return 0;
@@ -736,7 +742,7 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
         const int tile_bytes = rows * VSTRIDE;
         const size_t lds = (size_t)(4 * tile_bytes + TILE + 768);
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
+            hipLaunchKernelGGL(kern, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP), tile_bytes);
         };
         if (Tk <= 40) go(attn_bwd_bf16_t64<4>); else if (Tk <= 48) go(attn_bwd_bf16_t64<8>); else go(attn_bwd_bf16_t64<16>);
     } else if (dtype == DIC_BF16) {
@@ -745,12 +751,12 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
         size_t lds = 4 * (size_t)(3 * tile_bytes + 512);
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * TILE + 512)); attr = true; }
-        hipLaunchKernelGGL(attn_bwd_bf16, dim3((N * H + 3) / 4), dim3(256), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed, tile_bytes);
+        hipLaunchKernelGGL(attn_bwd_bf16, dim3((N * H + 3) / 4), dim3(256), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP), tile_bytes);
     } else {
         size_t lds = (size_t)(4 * Tk * PADW + 2 * Tk * (Tk + 1)) * sizeof(float);
         static bool attr3 = false;
         if (!attr3) { (void)hipFuncSetAttribute((const void*)attn_bwd_f32<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4 * TMAX * PADW + 2 * TMAX * (TMAX + 1))); attr3 = true; }
-        hipLaunchKernelGGL(attn_bwd_f32<float>, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (const float*)dctx, (float*)dqkv, N, Tk, H, scale, p_drop, (unsigned long long)seed);
+        hipLaunchKernelGGL(attn_bwd_f32<float>, dim3(N * H), dim3(64), lds, st, (const float*)qkv, key_mask, (const float*)dctx, (float*)dqkv, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP));
     }
     DIC_CHECK_LAUNCH();
     return 0;

@@ -179,6 +179,27 @@ __device__ __forceinline__ float dropout1(float v, unsigned long long seed, unsi
     return (w >= drop_thr(p)) ? v * inv_keep : 0.f;
 }
 
+// ---- per-step seed indirection (hipGraph replay of the training step) ---------------------------------------------
+// A captured launch freezes its arguments, but the dropout / noise / timestep seeds, AdamW's bias corrections and the slot the step's
+// losses are written to change every step.  While a step context is set (dic_step_ctx_set, called by the capture code), every seeded
+// kernel receives the address of a device step counter and its value at capture time and shifts its seed by
+// (counter - counter_at_capture) * stride -- exactly what the host adds between two eager steps, so a replayed step draws the very
+// masks / noise / timesteps the eager step with the same number would.  Without a context (eager code): ctr == NULL, zero shift.
+struct DicStepCtx { const long long* ctr; long long ctr0; unsigned long long stride_noise; const float* adam_table; };
+DicStepCtx dic_step_ctx();
+struct SeedArg {
+    unsigned long long base, stride;
+    const long long* ctr;
+    long long ctr0;
+    __device__ __forceinline__ unsigned long long resolve() const { return ctr ? base + (unsigned long long)(ctr[0] - ctr0) * stride : base; }
+};
+enum { DIC_STRIDE_DROP = 64, DIC_STRIDE_T = 1 };          // what engine.encode / diffusion._next_t_seed add per step on the host
+inline SeedArg make_seed(unsigned long long seed, unsigned long long stride) {
+    const DicStepCtx c = dic_step_ctx();
+    return SeedArg{seed, stride, c.ctr, c.ctr0};
+}
+__device__ __forceinline__ long long step_delta(const long long* ctr, long long ctr0) { return ctr ? ctr[0] - ctr0 : 0; }
+
 // ---- error plumbing for the C-ABI ----------------------------------------------------------------
 extern "C" void dic_set_error(const char* msg);
 #define DIC_CHECK_LAUNCH()                                  \

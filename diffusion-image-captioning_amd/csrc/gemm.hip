@@ -269,6 +269,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const DicGemmParams
 
 template <typename T, bool AKM, bool BKM, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(DicGemmParams p) {   // v1: register-staged; fp32 parity path (and bf16 A/B reference)
+    if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int S = sizeof(T);
     constexpr int BK = KCfg<T>::BK;
@@ -1246,6 +1247,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 
 template <class C, bool AKM, bool BKM, int EPI, int CNT>
 __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
+    if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
     gemm_bf16_body<C, AKM, BKM, EPI, CNT, false>(p, nullptr);
 }
 __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmParams p, WgradGroupDev grp) {
@@ -1634,7 +1636,9 @@ extern "C" int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmPar
 }
 
 static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream) {
-    const DicGemmParams& p = *pp;
+    DicGemmParams p_ = *pp;
+    { const DicStepCtx c = dic_step_ctx(); p_.step_ctr = (const int64_t*)c.ctr; p_.step_ctr0 = c.ctr0; }     // (see common.h: seeds under hipGraph replay)
+    const DicGemmParams& p = p_;
     DIC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "dic_gemm: empty problem");
     const int es = dtype == DIC_BF16 ? 2 : 4;
     const int bk = dtype == DIC_BF16 ? 64 : 32;

@@ -503,6 +503,7 @@ __device__ __forceinline__ void gemm_pp_body(DicGemmParams& p, const WgradGroupD
 
 template <bool AKM, bool BKM, int EPI, int CNT>
 __global__ __launch_bounds__(Geo<T256>::NTH, 2) void gemm_pp_kernel(DicGemmParams p) {
+    if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
     gemm_pp_body<AKM, BKM, EPI, CNT, false>(p, nullptr);
 }
 __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_pp_kernel(DicGemmParams p, WgradGroupDev grp) {

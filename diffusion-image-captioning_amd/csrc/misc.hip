@@ -8,7 +8,22 @@
 static thread_local char g_err[256] = "";
 extern "C" void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* dic_last_error(void) { return g_err; }
-extern "C" int dic_version(void) { return 10; }
+extern "C" int dic_version(void) { return 11; }
+
+// ---- step context (see common.h): process-global, set by the code that captures a training step into a hipGraph --------------------
+static DicStepCtx g_step_ctx = {nullptr, 0, 0, nullptr};
+DicStepCtx dic_step_ctx() { return g_step_ctx; }
+extern "C" int dic_step_ctx_set(const int64_t* ctr, int64_t ctr0, uint64_t stride_noise, const float* adam_table) {
+    g_step_ctx = DicStepCtx{(const long long*)ctr, (long long)ctr0, (unsigned long long)stride_noise, adam_table};
+    return 0;
+}
+__global__ void step_advance_kernel(long long* ctr) { if (threadIdx.x == 0) ctr[0] += 1; }
+extern "C" int dic_step_advance(int64_t* ctr, void* stream) {
+    DIC_REQUIRE(ctr != nullptr, "dic_step_advance: counter missing");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)ctr);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
 
 static inline int grid_for(long long work_items, int per_block, int cap = 4096) {
     long long g = (work_items + per_block - 1) / per_block;
@@ -47,8 +62,9 @@ extern "C" int dic_embed_gather(const int64_t* ids, const float* E, float* out, 
 // ref CLIP-DDPM.py:356-362.  Each thread owns 4 consecutive elements of one [B][LD] slab position, draws (or
 // reads) its noise ONCE and writes the S noised copies (s-major output), so x0/eps are read once, not S times.
 __global__ void qsample_kernel(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out,
-                               float* noise_out, int S, long long BLD, int step_tot, unsigned long long seed) {
+                               float* noise_out, int S, long long BLD, int step_tot, SeedArg seed_) {
 #pragma clang fp contract(off)   // the reference rounds a*x, eps*b and their sum separately: no FMA contraction here
+    const unsigned long long seed = seed_.resolve();
     const long long n4 = BLD >> 2;
     for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
         f32x4 x = *(const f32x4*)(x0 + i4 * 4);
@@ -82,7 +98,7 @@ extern "C" int dic_qsample(const float* x0, const float* noise, const int64_t* t
     long long BLD = (long long)B * LD;
     DIC_REQUIRE(BLD % 4 == 0 && S > 0, "dic_qsample: B*L*D must be a multiple of 4");
     hipLaunchKernelGGL(qsample_kernel, dim3(grid_for(BLD / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
-                       sqrt_ac, sqrt_1mac, out, noise_out, S, BLD, step_tot, (unsigned long long)seed);
+                       sqrt_ac, sqrt_1mac, out, noise_out, S, BLD, step_tot, make_seed(seed, dic_step_ctx().stride_noise));
     DIC_CHECK_LAUNCH();
     return 0;
 }
@@ -155,7 +171,12 @@ extern "C" int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int T
 }
 
 // out[0] = scale_a * sum in[0:n_a], out[1] = scale_b * sum in[n_a:n], out[2] = out[0]+out[1]  (one workgroup, fixed order)
-__global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, int n_a, float sa, float sb, float* out2, const float* carry) {
+__global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, int n_a, float sa, float sb, float* out2, const float* carry,
+                                                      const long long* ctr, long long ctr0) {
+    // replayed step number k writes result slot k of the ring the captured step's slot starts (8 floats per slot, diffusion.LOSS_RING)
+    const long long slot = step_delta(ctr, ctr0) * 8;
+    out2 += slot;
+    if (carry) carry += slot;
     __shared__ double red[2][4];
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) { float v = in[i]; if (i < n_a) a += v; else b += v; }
@@ -170,7 +191,8 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const float* in, int n, in
     }
 }
 extern "C" int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out2, const float* carry, void* stream) {
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, n_a, scale_a, scale_b, out2, carry);
+    const DicStepCtx c = dic_step_ctx();
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, n_a, scale_a, scale_b, out2, carry, c.ctr, c.ctr0);
     DIC_CHECK_LAUNCH();
     return 0;
 }
@@ -286,13 +308,14 @@ extern "C" int dic_cfg_prep(const float* img, const float* txt, const int64_t* m
     return 0;
 }
 // out[i] = uniform integer in [0, hi) from Philox4x32-10 keyed by (seed, i): the step's timestep vector (ref :460-461 torch.randint)
-__global__ void randint_kernel(int64_t* out, int n, unsigned hi, unsigned long long seed) {
+__global__ void randint_kernel(int64_t* out, int n, unsigned hi, SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int64_t)(((unsigned long long)rng4(seed, (unsigned long long)i).x * hi) >> 32);
 }
 extern "C" int dic_randint(int64_t* out, int n, int hi, uint64_t seed, void* stream) {
     DIC_REQUIRE(n > 0 && hi > 0, "dic_randint: empty range");
-    hipLaunchKernelGGL(randint_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned)hi, (unsigned long long)seed);
+    hipLaunchKernelGGL(randint_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned)hi, make_seed(seed, DIC_STRIDE_T));
     DIC_CHECK_LAUNCH();
     return 0;
 }
@@ -545,7 +568,12 @@ extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int 
 // torch.optim.AdamW semantics (ref :335): p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  One pass over the flat buffers: 16 B/param read, 12(+2) B written.
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, uint16_t* shadow, long long n4, float lr, float b1,
-                             float b2, float eps, float wd, float bc1, float rsqrt_bc2, float gscale) {
+                             float b2, float eps, float wd, float bc1, float rsqrt_bc2, float gscale, const float* table, const long long* ctr,
+                             long long ctr0) {
+    if (table && ctr) {          // replayed step: this step's bias corrections from the table the capture code filled (host arithmetic, bit for bit)
+        const long long k = ctr[0] - ctr0;
+        bc1 = table[2 * k]; rsqrt_bc2 = table[2 * k + 1];
+    }
     const float step = lr / bc1, decay = 1.0f - lr * wd;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         f32x4 P = ((f32x4*)p)[i], G = ((const f32x4*)g)[i] * gscale, Mo = ((f32x4*)m)[i], Vo = ((f32x4*)v)[i];
@@ -566,7 +594,8 @@ extern "C" int dic_adamw(float* p, const float* g, float* m, float* v, uint16_t*
                          float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
     DIC_REQUIRE(n % 4 == 0 && n > 0, "dic_adamw: flat length must be a multiple of 4");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, (long long)(n / 4),
-                       lr, beta1, beta2, eps, weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), grad_scale);
+                       lr, beta1, beta2, eps, weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), grad_scale, dic_step_ctx().adam_table, dic_step_ctx().ctr,
+                       dic_step_ctx().ctr0);
     DIC_CHECK_LAUNCH();
     return 0;
 }

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void fuse_ln_fwd_kernel(int mode, const float*
                                                            const float* seg, const float* pos, const float* temb, const int* tidx,
                                                            const float* gamma, const float* beta, T* h,
                                                            float* mean, float* rstd, int N, int L, int Tk, float eps, float p_drop,
-                                                           unsigned long long seed) {
+                                                           SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     const int lane = threadIdx.x & 63;
     const int rows = N * Tk;
     f32x4 g[NCH], b[NCH];
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void fuse_ln_bwd_kernel(int mode, c
                                                            const float* seg, const float* pos, const float* temb, const int* tidx,
                                                            const float* gamma, const T* dh,
                                                            const float* mean, const float* rstd, float* dy, float* partial, int N, int L, int Tk,
-                                                           float p_drop, unsigned long long seed) {
+                                                           float p_drop, SeedArg seed_) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int rows = N * Tk;
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* y, const float* ga
 
 template <typename T>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
-                                                      float p_drop, unsigned long long seed, float* partial, int rows) {
+                                                      float p_drop, SeedArg seed_, float* partial, int rows) {
+    const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     f32x4 g[NCH];
@@ -349,8 +352,8 @@ extern "C" int dic_fuse_ln_fwd_x(int dtype, int mode, const float* x, int64_t x_
     hipStream_t st = (hipStream_t)stream;
     const long long xs = (long long)x_seq_stride;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed),
-               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, (unsigned long long)seed));
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<bf16_t>, grid, block, 0, st, mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (bf16_t*)h, mean, rstd, N, L, Tk, eps, p_drop, make_seed(seed, DIC_STRIDE_DROP)),
+               hipLaunchKernelGGL(fuse_ln_fwd_kernel<float>, grid, block, 0, st, mode, x, xs, img, txt, add_txt, seg, pos, temb, tidx, gamma, beta, (float*)h, mean, rstd, N, L, Tk, eps, p_drop, make_seed(seed, DIC_STRIDE_DROP)));
     DIC_CHECK_LAUNCH();
     return 0;
 }
@@ -369,8 +372,8 @@ extern "C" int dic_fuse_ln_bwd(int dtype, int mode, const float* x, const float*
     const size_t lds = LNB_WAVES * 2 * D * sizeof(float);            // 48 KB
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(fuse_ln_bwd_kernel<bf16_t>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, (const bf16_t*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed),
-               hipLaunchKernelGGL(fuse_ln_bwd_kernel<float>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, (const float*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, (unsigned long long)seed));
+               hipLaunchKernelGGL(fuse_ln_bwd_kernel<bf16_t>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, (const bf16_t*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, make_seed(seed, DIC_STRIDE_DROP)),
+               hipLaunchKernelGGL(fuse_ln_bwd_kernel<float>, grid, block, lds, st, mode, x, img, txt, add_txt, seg, pos, temb, tidx, gamma, (const float*)dh, mean, rstd, dy, partial, N, L, Tk, p_drop, make_seed(seed, DIC_STRIDE_DROP)));
     DIC_CHECK_LAUNCH();
     return 0;
 }
@@ -417,8 +420,8 @@ extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float*
     }
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, (unsigned long long)seed, partial, T),
-               hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, lds, st, (const float*)dh, (const float*)y, gamma, mean, rstd, (float*)dx, (float*)dx_drop, p_drop, (unsigned long long)seed, partial, T));
+               hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T),
+               hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, lds, st, (const float*)dh, (const float*)y, gamma, mean, rstd, (float*)dx, (float*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T));
     DIC_CHECK_LAUNCH();
     return 0;
 }

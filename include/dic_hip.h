@@ -71,6 +71,8 @@ typedef struct DicGemmParams {
                                    to a kernel on another stream */
     float* colsum_out;          /* bf16 (k-major,k-major) fp32-output GEMMs only: out[m] = sum_k A(m,k) -- the bias gradient that
                                    goes with a weight gradient dW = dY^T X (hf nn.Linear backward), taken from the LDS-resident A tile */
+    const int64_t* step_ctr;    /* RESERVED, leave 0: dic_gemm fills these two from the step context (dic_step_ctx_set) so that a launch */
+    int64_t step_ctr0;          /* replayed inside a hipGraph shifts `seed` by 64 x (steps since capture), as the host does between eager steps */
 } DicGemmParams;
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
@@ -106,6 +108,16 @@ size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
  * 256-column geometry runs.  0 (default) = the lock-step loop, 1 (env DIC_GEMM_PP=1) = the ping-pong loop of csrc/gemm_pp.h.  Results are
  * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
 int dic_gemm_set_variant(int pp);
+
+/* hipGraph support for the training step (PROCESS-GLOBAL state: one capture at a time).  Kernel arguments are frozen by a capture, but the
+ * dropout / noise / timestep seeds, AdamW's bias corrections and the slot the step's losses go to change every step.  While a context is set,
+ * every seeded launch additionally receives `ctr` (a device int64 step counter) and `ctr0` (its value during the captured step) and shifts
+ * its seed by (ctr[0] - ctr0) x the amount the host adds per eager step (dropout 64, timestep draw 1, q_sample `stride_noise`); dic_seg_sum
+ * writes result slot (ctr[0] - ctr0); dic_adamw takes its two bias-correction factors from adam_table[2k], [2k+1] (k = ctr[0] - ctr0; floats
+ * {1 - beta1^t, 1/sqrt(1 - beta2^t)} for the steps after the captured one).  dic_step_advance(ctr) is the graph's first node: ctr[0] += 1.
+ * dic_step_ctx_set(NULL, 0, 0, NULL) switches the indirection off (eager launches: plain seeds).                                            */
+int dic_step_ctx_set(const int64_t* ctr, int64_t ctr0, uint64_t stride_noise, const float* adam_table);
+int dic_step_advance(int64_t* ctr, void* stream);
 
 /* Measurement hooks for bench.py: between begin/end every dic_gemm launch is bracketed by hipEvents recorded on its own
  * stream; end() (after the caller synchronised) returns the summed kernel time, algorithmic flops (2*M*N*K) and count. */

@@ -454,6 +454,37 @@ def test_full_size_training_is_deterministic_and_descends():
     assert all(np.isfinite(runs[0])) and runs[0][-1] < runs[0][0]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_graphed_training_step_is_bit_identical_to_eager(dtype):
+    """The step captured once as a hipGraph and replayed (graph.GraphedTrainStep) against plain eager calls: dropout on, same seeds -- every loss
+    of 14 steps and every parameter afterwards bit-identical; eager steps continue seamlessly after graphed ones (host counters in step)."""
+    B, S, L, V, nl = 8, 2, 16, 1500, 2
+    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5, VOCAB_SIZE=V,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(V, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 1).items()}
+    x2 = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 2).items()}
+    def fresh():
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=nl, dropout=0.1, attention_dropout=0.1), dtype=dtype, seed=3)
+        trainer = dic.AdamW(model.parameters(), lr=1e-3)
+        dic.seed_noise(11)
+        dic.seed_timesteps(500)
+        return model, trainer
+    batch = lambda i: x if (i < 2 or i % 2 == 0) else x2          # (the graphed run's two warm-up steps use its construction batch)
+    model, trainer = fresh()
+    step = dic.GraphedTrainStep(model, trainer, x, warmup=2)       # steps 0, 1 eagerly
+    got = [[f(v) for v in step(batch(i))] for i in range(2, 12)]   # steps 2..11 replayed, batches alternating through the static input buffers
+    got += [[f(v) for v in dic.train_func(model, trainer, batch(i))] for i in range(12, 14)]      # and two eager steps behind them
+    assert step.captures == 1 and step.replays == 10
+    P_graph = model.params.P.clone()
+    model, trainer = fresh()
+    ref = [[f(v) for v in dic.train_func(model, trainer, batch(i))] for i in range(14)]
+    assert ref[2:] == got, "graphed losses differ from the eager ones"
+    assert torch.equal(model.params.P, P_graph)
+    assert len({tuple(r) for r in ref}) == 14                      # (every step drew fresh noise / masks / timesteps)
+
+
 def test_config5_seq32_guidance_bf16_matches_fp32():
     """Config 5 shape: seq_len 32 (+2 CLIP rows = 34 tokens, beyond one MFMA tile), classifier-free guidance p=0.2 w=0.3."""
     B, S, L, V = 8, 2, 32, 5000

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(dic._lib.EXPORTS) == declared
-    assert L.dic_version() >= 10
+    assert L.dic_version() >= 11
 
 
 def test_gemm_params_ctypes_mirror_matches_the_header_struct():
@@ -47,7 +47,7 @@ def test_gemm_params_ctypes_mirror_matches_the_header_struct():
         fields.append((name, ctype))
         for r in rest:
             fields.append((r.replace("*", " ").split()[-1], "ptr" if "*" in r else ctype))
-    kind = {"ptr": C.c_void_p, "int": C.c_int, "float": C.c_float, "uint64_t": C.c_uint64}
+    kind = {"ptr": C.c_void_p, "int": C.c_int, "float": C.c_float, "uint64_t": C.c_uint64, "int64_t": C.c_int64}
     mirror = dic._lib.GemmParams._fields_
     assert [n for n, _ in mirror] == [n for n, _ in fields]
     for (n, t), (_, ct) in zip(mirror, fields):
