@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller
- *   - kernels never allocate, never synchronise, launch on `stream` (a hipStream_t passed as void*)
+ *   - kernels never allocate, never synchronise, launch on `stream` (a hipStream_t passed as void*); no per-call state is kept (the
+ *     process-global exceptions -- last-error text, the bench timing hook, two measurement / replay switches -- say so where declared)
  *   - return value: 0 = ok, otherwise a hipError_t (or >= 1000 for argument errors); dic_last_error()
  *     gives the message
  *   - dtype: DIC_F32 (0) or DIC_BF16 (1) selects the activation/operand type `T`; statistics, losses,
@@ -120,7 +121,9 @@ int dic_step_ctx_set(const int64_t* ctr, int64_t ctr0, uint64_t stride_noise, co
 int dic_step_advance(int64_t* ctr, void* stream);
 
 /* Measurement hooks for bench.py: between begin/end every dic_gemm launch is bracketed by hipEvents recorded on its own
- * stream; end() (after the caller synchronised) returns the summed kernel time, algorithmic flops (2*M*N*K) and count. */
+ * stream; end() (after the caller synchronised) returns the summed kernel time, algorithmic flops (2*M*N*K) and count.
+ * PROCESS-GLOBAL state (one record table for the whole process, armed per calling thread): a measurement aid, not for concurrent
+ * use.  The only other shared state of the library: dic_last_error's message buffer, dic_gemm_set_variant, dic_step_ctx_set. */
 int dic_prof_begin(int max_launches);
 int dic_prof_end(double* total_ms, double* total_flops, int* n_launches);
 
