@@ -55,7 +55,7 @@ class WgradItem(C.Structure):
 def build(verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into one shared library, in-tree (it travels with the snapshot)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_pp.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_pp.h"), os.path.join(CSRC, "gemm_w4.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

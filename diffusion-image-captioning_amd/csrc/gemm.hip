@@ -1260,10 +1260,13 @@ __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmP
 // dic_gemm_set_variant(1).  Round 3 measured them equal within noise on the step's k-contiguous shapes and the ping-pong loop 10-20 %
 // slower with k-major operands (two ds_read_b64_tr_b16 per fragment in its load segments), so the lock-step loop stays the default.
 int g_pp = -1;
-bool pp_enabled() {
-    if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && e[0] == '1') ? 1 : 0; }
-    return g_pp == 1;
+int gemm_variant() {
+    if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
+    return g_pp;
 }
+bool pp_enabled() { return gemm_variant() == 1; }
+
+#include "gemm_w4.h"          // gemm_w4_kernel: 256 x 256 tiles on four waves (variant 2, k-contiguous operands only; measured alternative)
 // Fold of a grouped launch: tile t = sum of its K-slices' slabs in slice order (deterministic).  Block = (tile, 16-row chunk); 256 threads x
 // (4 rows x 4 columns).  The bias gradient rides in each slab's tail.
 __global__ __launch_bounds__(256) void wgrad_group_fold_kernel(WgradGroupDev grp) {
@@ -1396,6 +1399,17 @@ void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
     static bool attr_set[2][64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
+    if constexpr (std::is_same_v<C, T256> && !AKM && !BKM) {
+        if (gemm_variant() == 2) {
+            static bool attr_w4[64] = {};
+            if (dev >= 0 && dev < 64 && !attr_w4[dev]) {
+                (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+                attr_w4[dev] = true;
+            }
+            launch_timed(gemm_w4_kernel<E, CNT>, dim3(grid), dim3(256), (unsigned)G::LDS, st, q);
+            return;
+        }
+    }
     if constexpr (std::is_same_v<C, T256>) {
         if (pp_enabled()) {
             if (dev >= 0 && dev < 64 && !attr_set[1][dev]) {
@@ -1585,7 +1599,7 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
 }
 
 // measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry, 0 = the lock-step loop (default)
-extern "C" int dic_gemm_set_variant(int pp) { g_pp = pp ? 1 : 0; return 0; }
+extern "C" int dic_gemm_set_variant(int v) { g_pp = (v == 1 || v == 2) ? v : 0; return 0; }
 
 // ---- optional per-launch timing (bench.py roofline leg), see launch_timed above
 namespace {

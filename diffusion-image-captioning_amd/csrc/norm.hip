@@ -214,30 +214,14 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, con
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float inv_keep = drop_inv_keep(p_drop);
-    // Software-pipelined: the NEXT row's loads are issued before this row is computed and stored.  gfx950's single vmcnt makes a load wait also
-    // wait for every older store, so "load -> compute -> store -> load" is a load round trip PLUS a store round trip per row; with the next
-    // row's loads already in flight behind this row's stores the two overlap.  It does not matter while the tensors sit in the 256 MB infinity
-    // cache (17 408 tokens: 19 us per launch either way) and it is the difference at config 5's 48 756 tokens (300 MB per launch, from HBM):
-    // rocprofv3 223 us -> see profiles/r03_seq32_cfg_kernel_stats.csv.
-    const int stride = gridDim.x * LNB_WAVES;
-    int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
-    f32x4 vn[NCH], dn[NCH];
-    float mun = 0.f, rsn = 0.f;
-    if (row < rows) {
-        load_row<T>(y + (size_t)row * D, lane, vn);
-        load_row<T>(dh + (size_t)row * D, lane, dn);
-        mun = mean[row]; rsn = rstd[row];
-    }
-    for (; row < rows; row += stride) {
+    // (A software-pipelined variant -- next row's loads issued before this row's stores -- was measured in round 3: 24.5 us instead of 19.4 us per
+    // launch at 17 408 tokens, no gain at 48 756: the kernel alone already streams at 5.4 TB/s; what looked slow in a two-stream profile was CU
+    // contention with the weight-gradient GEMMs.)
+    for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         f32x4 v[NCH], d[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) { v[c] = vn[c]; d[c] = dn[c]; }
-        const float mu = mun, rs = rsn;
-        if (row + stride < rows) {
-            load_row<T>(y + (size_t)(row + stride) * D, lane, vn);
-            load_row<T>(dh + (size_t)(row + stride) * D, lane, dn);
-            mun = mean[row + stride]; rsn = rstd[row + stride];
-        }
+        load_row<T>(y + (size_t)row * D, lane, v);
+        load_row<T>(dh + (size_t)row * D, lane, d);
+        const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
