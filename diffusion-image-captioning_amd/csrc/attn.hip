@@ -420,8 +420,11 @@ __global__ __launch_bounds__(128) void attn_fwd_bf16_t64(const bf16_t* qkv, cons
 }
 
 // Backward, 33..64 tokens.  K, Q, dO are staged in LDS (Tk + 1 rows, the last one zero: the redirect target of token rows >= Tk) for the
-// k-major products; the score-shaped products take row fragments from HBM/L2.  Pass 1 per query tile (lane = query): P, delta, dS -> dQ.
-// Pass 2 per key tile (lane = key), accumulating over the query tiles: Pd -> dV, dS -> dK.
+// k-major products; the score-shaped products take row fragments -- K's and V's stay in registers from the one global read, Q's and dO's come
+// from the tiles.  Pass 1 per query tile (lane = query): P, delta, dS -> dQ.  Pass 2 per key tile (lane = key), accumulating over the query
+// tiles: Pd -> dV, dS -> dK.  LDS is what bounds residency (one wave per workgroup): three tiles + the row statistics = 21.5 KB at 34 tokens,
+// seven waves per CU (a first version also staged V and kept a separate output tile: 34.5 KB, four waves per CU, and the kernel is a chain of
+// dependent load / LDS / MFMA latencies that only other waves can hide).  Outputs are staged through K's tile once its last transposed read is done.
 __device__ __forceinline__ bf16x8 tr_frag_clamped64(const char* lds, int s, int db, int lane, int zero_row) {
     const int hi = lane >> 5, half = (lane >> 4) & 1, t = lane & 15;
     const int r0 = min(16 * s + 4 * hi + (t >> 2), zero_row), r1 = min(16 * s + 8 + 4 * hi + (t >> 2), zero_row);
@@ -436,7 +439,7 @@ __device__ __forceinline__ bf16x8 tr_frag_clamped64(const char* lds, int s, int 
 // on those registers and the MFMA k-steps made only of them are skipped at compile time (34 tokens = config 5: 20 of 32 score registers per lane
 // and 3 of 4 k-steps remain; the kernel is VALU-bound on exactly that arithmetic).
 template <int R1>
-__global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
+__global__ __launch_bounds__(64, 2) void attn_bwd_bf16_t64(const bf16_t* qkv, const uint8_t* key_mask, const bf16_t* dctx, bf16_t* dqkv, int N, int Tk,
                                                          int H, float scale, float p_drop, SeedArg seed_, int tile_bytes) {
     const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -456,25 +459,25 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
     char* kt_ = base;
     char* qt_ = base + tile_bytes;
     char* dot = base + 2 * tile_bytes;
-    char* vt_ = base + 3 * tile_bytes;
-    char* ot = base + 4 * tile_bytes;                      // one 32-row output tile
-    float* stats = (float*)(base + 4 * tile_bytes + TILE);  // [0..63] row max, [64..127] 1/rowsum, [128..191] delta
+    char* ot = kt_;                                        // 32-row output staging: K's tile, after pass 1's last transposed read of it
+    float* stats = (float*)(base + 3 * tile_bytes);        // [0..63] row max, [64..127] 1/rowsum, [128..191] delta
     const int zero_row = Tk < 64 ? Tk : 63;
     const int c = lane & 31, hi = lane >> 5;
     const float inv_keep = drop_inv_keep(p_drop);
     const unsigned thr = drop_thr(p_drop), mix = attn_seed_mix(seed);
     const unsigned long long mbits = __ballot(lane < Tk && key_mask[(size_t)n * Tk + (lane < Tk ? lane : 0)] != 0);
-    const int nt = Tk > 32 ? 2 : 1;
-    {   // stage K, Q, dO, V (rows 0 .. Tk, row Tk zero): the only HBM reads of the kernel, all in flight together.  Every later operand --
-        // row fragments for the score-shaped products, transpose-read fragments for the k-major ones -- comes from these tiles (a first
-        // version re-read row fragments from HBM/L2 in every phase: ~26 dependent load phases per head, 1.3 TB/s).
-        const RowFrags a0 = load_rows_at(K, ld, 0, Tk, lane), a1 = load_rows_at(K, ld, 32, Tk, lane), b0 = load_rows_at(Q, ld, 0, Tk, lane),
-                       b1 = load_rows_at(Q, ld, 32, Tk, lane), c0 = load_rows_at(dO, Dm, 0, Tk, lane), c1 = load_rows_at(dO, Dm, 32, Tk, lane),
-                       d0 = load_rows_at(V, ld, 0, Tk, lane), d1 = load_rows_at(V, ld, 32, Tk, lane);
-        store_rows_at(kt_, a0, 0, Tk, lane); store_rows_at(kt_, a1, 32, Tk, lane);
+    // the only HBM reads of the kernel, all in flight together: K and V row fragments stay in registers, K / Q / dO go to their tiles (rows
+    // 0 .. Tk, row Tk zero).  Every later operand -- Q / dO row fragments for the score-shaped products, transpose-read fragments for the
+    // k-major ones -- comes from these tiles (a first version re-read row fragments from HBM/L2 in every phase: ~26 dependent load phases
+    // per head, 1.3 TB/s).
+    const RowFrags fk0 = load_rows_at(K, ld, 0, Tk, lane), fk1 = load_rows_at(K, ld, 32, Tk, lane);
+    const RowFrags fv0 = load_rows_at(V, ld, 0, Tk, lane), fv1 = load_rows_at(V, ld, 32, Tk, lane);
+    {
+        const RowFrags b0 = load_rows_at(Q, ld, 0, Tk, lane), b1 = load_rows_at(Q, ld, 32, Tk, lane), c0 = load_rows_at(dO, Dm, 0, Tk, lane),
+                       c1 = load_rows_at(dO, Dm, 32, Tk, lane);
+        store_rows_at(kt_, fk0, 0, Tk, lane); store_rows_at(kt_, fk1, 32, Tk, lane);
         store_rows_at(qt_, b0, 0, Tk, lane); store_rows_at(qt_, b1, 32, Tk, lane);
         store_rows_at(dot, c0, 0, Tk, lane); store_rows_at(dot, c1, 32, Tk, lane);
-        store_rows_at(vt_, d0, 0, Tk, lane); store_rows_at(vt_, d1, 32, Tk, lane);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
     }
@@ -487,9 +490,9 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
     };
     // ---- pass 1 (query-major), one query tile at a time
     {
-        const RowFrags fk0 = rows_lds(kt_, 0), fk1 = rows_lds(kt_, 32);
-        const RowFrags fv0 = rows_lds(vt_, 0), fv1 = rows_lds(vt_, 32);
-        for (int qt = 0; qt < nt; ++qt) {
+        f32x16 oq[2][2];                               // dQ of both query tiles: staged through K's tile after the last read of it
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {               // (this kernel only runs beyond 32 tokens: always two tiles)
             const RowFrags fq = rows_lds(qt_, 32 * qt), fo = rows_lds(dot, 32 * qt);
             f32x16 st[2] = {rowdot_reg(fk0, fq), rowdot_reg(fk1, fq)};
             float mx = -INFINITY;
@@ -533,22 +536,24 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_t64(const bf16_t* qkv, const
                 for (int r = 0; r < 16; ++r) { if (kt == 1 && r >= R1) continue; st[kt][r] = st[kt][r] * (dpt[kt][r] - delta) * scale; }      // dS[query][key]
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
-            f32x16 o[2];
 #pragma unroll
             for (int db = 0; db < 2; ++db) {                                            // dQ^T[d][query] = sum_key K[key][d] dS[query][key]
-                o[db] = zero16();
+                oq[qt][db] = zero16();
 #pragma unroll
                 for (int s = 0; s < (R1 > 8 ? 4 : 3); ++s)          // 16-key steps; the last one is all padding up to 48 tokens
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(kt_, s, db, lane, zero_row), pack8(st[s >> 1], s & 1), o[db], 0, 0, 0);
+                    oq[qt][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_clamped64(kt_, s, db, lane, zero_row), pack8(st[s >> 1], s & 1), oq[qt][db], 0, 0, 0);
             }
-            put_out(ot, o[0], o[1], dQ, ld, 32 * qt, Tk, lane);
         }
+        put_out(ot, oq[0][0], oq[0][1], dQ, ld, 0, Tk, lane);
+        put_out(ot, oq[1][0], oq[1][1], dQ, ld, 32, Tk, lane);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     // ---- pass 2 (key-major), one key tile at a time, accumulating over the query tiles
-    for (int kt = 0; kt < nt; ++kt) {
-        const RowFrags fk = rows_lds(kt_, 32 * kt), fv = rows_lds(vt_, 32 * kt);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const RowFrags& fk = kt ? fk1 : fk0;
+        const RowFrags& fv = kt ? fv1 : fv0;
         const int key = 32 * kt + c;
         const bool kok = (mbits >> key) & 1ull;
         f32x16 ov[2] = {zero16(), zero16()}, ok_[2] = {zero16(), zero16()};
@@ -740,7 +745,7 @@ extern "C" int dic_attn_bwd(int dtype, const void* qkv, const uint8_t* key_mask,
         DIC_REQUIRE((long long)N * H < (1ll << 21), "dic_attn: at most 2^21 (sequence, head) pairs per launch beyond 32 tokens (32-bit dropout index)");
         const int rows = Tk < 64 ? ((Tk + 1 + 3) & ~3) : 64;          // valid rows + one zero row
         const int tile_bytes = rows * VSTRIDE;
-        const size_t lds = (size_t)(4 * tile_bytes + TILE + 768);
+        const size_t lds = (size_t)(3 * tile_bytes + 768);
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(N * H), dim3(64), lds, st, (const bf16_t*)qkv, key_mask, (const bf16_t*)dctx, (bf16_t*)dqkv, N, Tk, H, scale, p_drop, make_seed(seed, DIC_STRIDE_DROP), tile_bytes);
         };
