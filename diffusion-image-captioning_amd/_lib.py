@@ -16,10 +16,10 @@ _AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another bui
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
-EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS = range(5)
+EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP = range(6)
 
 EXPORTS = [
-    "dic_version", "dic_last_error", "dic_gemm", "dic_ce_combine", "dic_embed_gather", "dic_qsample",
+    "dic_version", "dic_last_error", "dic_gemm", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
@@ -122,6 +122,9 @@ def lib():
         L.dic_attn_bwd.argtypes = [I, P, P, P, P, I, I, I, I, F, U64, P]
         L.dic_emb_loss.argtypes = [I, I, P, P, I, P, P, P, P, I, I, I, I, P]
         L.dic_add_rows.argtypes = [P, P, I, I, I, I, P]
+        L.dic_add_rows_scaled.argtypes = [P, P, P, C.c_float, I, I, I, I, P]
+        L.dic_ce_target_logit.argtypes = [P, P, P, I, I, I, C.c_float, P, P, P]
+        L.dic_ce_exp_combine.argtypes = [P, I, P, P, P, I, I, P, I, P, P, P, P]
         L.dic_seg_sum.argtypes = [P, I, I, F, F, P, P, P]
         L.dic_step_prep.argtypes = [P, P, P, P, I, I, I, I, P, P, P, P, P, P, F, F, P]
         L.dic_cfg_prep.argtypes = [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, F, F, P, P, P]

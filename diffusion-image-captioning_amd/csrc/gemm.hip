@@ -665,6 +665,57 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             }
             put_lines(i, bC, P[0], P[1]);          // only rows < M are written
         }
+    } else if constexpr (EPI == DIC_EPI_CE_EXP) {
+        // Training forward of the rounding head: E = exp(logit - c_row) as bf16 (c_row = p.lse[m], the caller's per-row reference point; columns
+        // in [N, ldc) are written as zeros), the sum of the UNROUNDED values of this wave's 64 columns per row into partial[m][n_first / 64],
+        // and the fp32 logit of the target column into tgt_logit[m].  dic_ce_exp_combine turns E into the (unnormalised) gradient operand,
+        // so the backward needs no second pass over the vocabulary.
+        static_assert(G::WCOLS == 64, "one partial sum per 64-column wave slab");
+        float r_c[CNT];
+        long long r_tg[CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+            const bool ok = m < p.M;
+            r_c[i] = ok ? p.lse[m] : 0.f;
+            r_tg[i] = (ok && p.tgt) ? p.tgt[m] : -1;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        issue_next();
+        const LineBuf bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.ldc);
+        const int np = ((p.N + G::BN - 1) / G::BN) * G::WN, slot = n_first / G::WCOLS;
+        constexpr float L2E = 1.4426950408889634f;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const int m = m_first + 16 * i + t;
+            const float c2 = r_c[i] * L2E;
+            const int tg = (r_tg[i] >= 0 && r_tg[i] < (long long)p.N) ? (int)r_tg[i] : -1;
+            float sm = 0.f, tv = 0.f;
+            bool has_t = false;
+            i32x4 P[G::NP];
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
+                const int n = nc[q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r == tg) { tv = x0[r]; has_t = true; }
+                    if (n + 4 + r == tg) { tv = x1[r]; has_t = true; }
+                    const float e0 = (n + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], L2E, -c2)) : 0.f;
+                    const float e1 = (n + 4 + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x1[r], L2E, -c2)) : 0.f;
+                    sm += e0 + e1;
+                    x0[r] = e0; x1[r] = e1;
+                }
+                P[q] = pack8f(x0, x1);
+            }
+            put_lines(i, bC, P[0], P[1]);          // only rows < M are written
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            if (m < p.M) {
+                if (g == 0) p.partial[(size_t)m * np + slot] = sm;
+                if (has_t) p.tgt_logit[m] = tv;
+            }
+        }
     }
 }
 
@@ -1483,8 +1534,8 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
     // built combinations: every epilogue for (k-contiguous, k-contiguous) = nn.Linear forward and the rounding head; the affine and GELU
     // epilogues for a k-major B (input gradients); the affine one for (k-major, k-major) = weight gradients.  Nothing on the path
     // asks for the others.
-    if (epi < DIC_EPI_AFFINE || epi > DIC_EPI_CE_DLOGITS) { dic_set_error("dic_gemm: unknown epilogue"); return 1002; }
-    if ((AKM && epi != DIC_EPI_AFFINE) || (BKM && (epi == DIC_EPI_CE_PARTIAL || epi == DIC_EPI_CE_DLOGITS))) {
+    if (epi < DIC_EPI_AFFINE || epi > DIC_EPI_CE_EXP) { dic_set_error("dic_gemm: unknown epilogue"); return 1002; }
+    if ((AKM && epi != DIC_EPI_AFFINE) || (BKM && (epi == DIC_EPI_CE_PARTIAL || epi == DIC_EPI_CE_DLOGITS || epi == DIC_EPI_CE_EXP))) {
         dic_set_error("dic_gemm: this epilogue is not built for this operand layout (weight gradients: AFFINE only; k-major B: no rounding-head epilogues)");
         return 1005;
     }
@@ -1495,6 +1546,11 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
         case DIC_EPI_GELU_BWD: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(st, p); break;
         case DIC_EPI_CE_PARTIAL: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(st, p); break;
         case DIC_EPI_CE_DLOGITS: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_DLOGITS>(st, p); break;
+        case DIC_EPI_CE_EXP:                       // bf16 LDS-DMA kernels only (dic_gemm_impl checks)
+            if constexpr (!AKM && !BKM && sizeof(T) == 2) {
+                if (p.tile == 256) launch_bf16<T256, false, false, DIC_EPI_CE_EXP>(p, st); else launch_bf16<T128, false, false, DIC_EPI_CE_EXP>(p, st);
+            }
+            break;
 #endif
     }
     if (split > 1) {
@@ -1662,7 +1718,7 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (a_km) DIC_REQUIRE((long long)p.K * p.lda * es < 0x7FFFFFFFll && p.M % 8 == 0, "dic_gemm: k-major A too large for 32-bit buffer offsets");
     if (b_km) DIC_REQUIRE((long long)p.K * p.ldb * es < 0x7FFFFFFFll, "dic_gemm: k-major B too large for 32-bit buffer offsets");
     if (!a_km) DIC_REQUIRE((long long)BM * p.lda * es < 0x7FFFFFFFll, "dic_gemm: lda too large");
-    if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
+    if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS && epi != DIC_EPI_CE_EXP) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
     if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD))
         DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && (p.aux == nullptr || p.ldaux % 8 == 0), "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
     if (epi == DIC_EPI_GELU_BWD) DIC_REQUIRE(p.aux != nullptr, "dic_gemm: GELU_BWD needs the pre-activation (aux)");
@@ -1676,6 +1732,10 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (p.split_k > 1)
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
+    if (epi == DIC_EPI_CE_EXP)
+        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && p.C && p.lse && p.partial && p.tgt_logit && p.ldc % 8 == 0 && p.ldc >= p.N &&
+                    p.ldc <= ((p.N + BN - 1) / BN) * BN && p.split_k <= 1,
+                    "dic_gemm: CE_EXP is a bf16 epilogue (LDS-DMA kernels); needs C, lse (reference points), partial, tgt_logit and an ldc that covers N within the last tile");
     if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % (dtype == DIC_BF16 ? 8 : 4) == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DIC_BF16) return launch_layout<bf16_t>(p, a_km, b_km, epi, st);

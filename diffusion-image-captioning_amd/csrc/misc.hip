@@ -8,7 +8,7 @@
 static thread_local char g_err[256] = "";
 extern "C" void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* dic_last_error(void) { return g_err; }
-extern "C" int dic_version(void) { return 11; }
+extern "C" int dic_version(void) { return 12; }
 
 // ---- step context (see common.h): process-global, set by the code that captures a training step into a hipGraph --------------------
 static DicStepCtx g_step_ctx = {nullptr, 0, 0, nullptr};
@@ -162,6 +162,22 @@ __global__ void add_rows_kernel(float* dx_out, const float* dxr, long long n4_to
         f32x4* d = (f32x4*)dx_out + n * TkD4 + r;
         *d = *d + ((const f32x4*)dxr)[i];
     }
+}
+__global__ void add_rows_scaled_kernel(float* dx_out, const float* dxr, const float* inv_z, float scale, long long n4_total, int LD4, int TkD4, int D4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4_total; i += (long long)gridDim.x * blockDim.x) {
+        long long n = i / LD4, r = i - n * LD4;
+        const float f = inv_z[i / D4] * scale;
+        f32x4* d = (f32x4*)dx_out + n * TkD4 + r;
+        const f32x4 v = ((const f32x4*)dxr)[i];
+        *d = *d + f32x4{v[0] * f, v[1] * f, v[2] * f, v[3] * f};
+    }
+}
+extern "C" int dic_add_rows_scaled(float* dx_out, const float* dxr, const float* inv_z, float scale, int N, int L, int Tk, int D, void* stream) {
+    DIC_REQUIRE(D % 4 == 0 && N > 0 && inv_z, "dic_add_rows_scaled: bad arguments");
+    long long n4 = (long long)N * L * D / 4;
+    hipLaunchKernelGGL(add_rows_scaled_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx_out, dxr, inv_z, scale, n4, L * D / 4, Tk * D / 4, D / 4);
+    DIC_CHECK_LAUNCH();
+    return 0;
 }
 extern "C" int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int Tk, int D, void* stream) {
     long long n4 = (long long)N * L * D / 4;
@@ -362,6 +378,64 @@ __global__ void ce_combine_kernel(const float* partial, const float* tgt_logit, 
             if (nll) nll[m] = l - tgt_logit[m];
         }
     }
+}
+// ---- rounding loss, training form (include/dic_hip.h: dic_ce_target_logit -> dic_gemm(CE_EXP) -> dic_ce_exp_combine)
+// one wave per row: t = <xr[m], W[tgt[m]]>, c = t + shift
+__global__ void ce_target_logit_kernel(const bf16_t* xr, const bf16_t* W, const int64_t* tgt, int M, int V, int D, float shift, float* t_out, float* c_out) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int m = blockIdx.x * wpb + (threadIdx.x >> 6); m < M; m += gridDim.x * wpb) {
+        const long long tg = tgt[m];
+        float a = 0.f;
+        if (tg >= 0 && tg < V) {
+            const bf16_t* x = xr + (size_t)m * D;
+            const bf16_t* w = W + (size_t)tg * D;
+            for (int d = lane * 8; d < D; d += 512) {
+                const bf16x8 xv = *(const bf16x8*)(x + d), wv = *(const bf16x8*)(w + d);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a = __builtin_fmaf((float)xv[k], (float)wv[k], a);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) { t_out[m] = a; c_out[m] = a + shift; }
+    }
+}
+extern "C" int dic_ce_target_logit(const void* xr, const void* W, const int64_t* tgt, int M, int V, int D, float shift, float* t, float* c, void* stream) {
+    DIC_REQUIRE(M > 0 && D % 8 == 0 && xr && W && tgt && t && c, "dic_ce_target_logit: bad arguments");
+    hipLaunchKernelGGL(ce_target_logit_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xr, (const bf16_t*)W, tgt, M, V, D, shift, t, c);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+// one wave per row: Z = sum of the slab sums (lane-strided, then a fixed xor tree: deterministic), the row's statistics, and the target entry of E
+__global__ void ce_exp_combine_kernel(const float* partial, int np, const float* c, const float* tgt_logit, const int64_t* tgt, int M, int V, bf16_t* E,
+                                      int ldE, float* lse, float* nll, float* inv_z) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int m = blockIdx.x * wpb + (threadIdx.x >> 6); m < M; m += gridDim.x * wpb) {
+        const float* pr = partial + (size_t)m * np;
+        float z = 0.f;
+        for (int i = lane; i < np; i += 64) z += pr[i];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) z += __shfl_xor(z, o, 64);
+        if (lane == 0) {
+            const float cm = c[m], l = logf(z) + cm;
+            const long long tg = tgt[m];
+            const bool ok = tg >= 0 && tg < V;
+            const float tl = ok ? tgt_logit[m] : 0.f;
+            lse[m] = l;
+            if (nll) nll[m] = l - tl;
+            inv_z[m] = 1.0f / z;
+            // (the same fma + v_exp the epilogue applied to this logit: bit-identical to the term inside z, so the difference is exactly the
+            //  other columns' sum)
+            if (ok) E[(size_t)m * ldE + tg] = f2bf(__builtin_amdgcn_exp2f(__builtin_fmaf(tl, 1.4426950408889634f, -(cm * 1.4426950408889634f))) - z);
+        }
+    }
+}
+extern "C" int dic_ce_exp_combine(const float* partial, int n_partials, const float* c, const float* tgt_logit, const int64_t* tgt, int M, int V,
+                                  void* E, int ldE, float* lse, float* nll, float* inv_z, void* stream) {
+    DIC_REQUIRE(M > 0 && n_partials > 0 && partial && c && tgt_logit && tgt && E && lse && inv_z && ldE >= V, "dic_ce_exp_combine: bad arguments");
+    hipLaunchKernelGGL(ce_exp_combine_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, partial, n_partials, c, tgt_logit, tgt, M, V, (bf16_t*)E, ldE, lse, nll, inv_z);
+    DIC_CHECK_LAUNCH();
+    return 0;
 }
 extern "C" int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_partials, float* lse, int64_t* argmax,
                               float* nll, void* stream) {

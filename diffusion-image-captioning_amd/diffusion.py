@@ -389,7 +389,11 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
             ids = idx.to(dev, torch.int64)
             cw["tgt"][:Nt * L].copy_(ids.repeat(S, 1).reshape(-1))
             cw["tgt"][Nt * L:].copy_(ids.reshape(-1))
-        model.rounding(cw["xr"], M, cw["tgt"], cw)
+        fused_ce = want_grad and model.ce_fused
+        if fused_ce:
+            model.rounding_train(cw["xr"], M, cw["tgt"], cw)
+        else:
+            model.rounding(cw["xr"], M, cw["tgt"], cw)
         ca = (1.0 / Nt) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         cb = (1.0 / B) if kind in (0, 2) else (1.0 / cfg.BATCH_SIZE)
         rw = float(cfg.ROUNDING_WEIGHT)
@@ -397,8 +401,13 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
         model._last_total = out[7]                       # x_t_loss + x_1_loss + prob_loss, summed by the kernel (ref :481)
         if want_grad:
             dxr = model.rounding_backward(cw, M, Nt * L, rw * ca, rw * cb)
-            _lib.check(lib.dic_add_rows(_p(dx), _p(dxr), Nt, L, Tk, 768, st), "add_rows")
-            _lib.check(lib.dic_add_rows(_p(dx) + off, _p(dxr) + Nt * L * 768 * 4, B, L, Tk, 768, st), "add_rows")
+            if fused_ce:                  # dxr lacks the per-row factor row_scale / Z (engine.rounding_train): applied while it is added
+                _lib.check(lib.dic_add_rows_scaled(_p(dx), _p(dxr), _p(cw["inv_z"]), rw * ca, Nt, L, Tk, 768, st), "add_rows_scaled")
+                _lib.check(lib.dic_add_rows_scaled(_p(dx) + off, _p(dxr) + Nt * L * 768 * 4, _p(cw["inv_z"]) + Nt * L * 4, rw * cb, B, L, Tk, 768, st),
+                           "add_rows_scaled")
+            else:
+                _lib.check(lib.dic_add_rows(_p(dx), _p(dxr), Nt, L, Tk, 768, st), "add_rows")
+                _lib.check(lib.dic_add_rows(_p(dx) + off, _p(dxr) + Nt * L * 768 * 4, B, L, Tk, 768, st), "add_rows")
         prob = out[6]
     else:
         prob = torch.zeros((), dtype=torch.float32, device=dev)

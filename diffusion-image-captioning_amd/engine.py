@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import DIC_BF16, DIC_F32, EPI_AFFINE, EPI_BIAS_GELU, EPI_CE_DLOGITS, EPI_CE_PARTIAL, EPI_GELU_BWD, GemmParams
+from ._lib import DIC_BF16, DIC_F32, EPI_AFFINE, EPI_BIAS_GELU, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_CE_PARTIAL, EPI_GELU_BWD, GemmParams
 from .config import LOSS_KINDS, cfg
 from .params import ParamStore
 
@@ -68,6 +68,7 @@ _TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "au
 _WGRAD_CU_CAP = int(_os.environ.get("DIC_WGRAD_CU_CAP", "0"))   # >0: weight-gradient GEMMs keep to this many CUs (A/B switch)
 _WGRAD_TILE = _os.environ.get("DIC_WGRAD_TILE", "auto")    # tile of the weight-gradient GEMMs (A/B switch)
 _V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the register-staged v1 kernel (128-tiles only)
+_CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
 
 
@@ -327,7 +328,8 @@ class Denoiser:
                       tgt_logit=torch.zeros(M, dtype=torch.float32, device=dev), lse=torch.empty(M, dtype=torch.float32, device=dev),
                       argmax=torch.empty(M, dtype=torch.int64, device=dev), nll=torch.empty(M, dtype=torch.float32, device=dev),
                       tgt=torch.empty(M, dtype=torch.int64, device=dev), dxr=torch.empty(M, 768, dtype=torch.float32, device=dev),
-                      dlogits=None)
+                      dlogits=None, cref=torch.empty(M, dtype=torch.float32, device=dev), inv_z=torch.empty(M, dtype=torch.float32, device=dev),
+                      fused=False)
             self._ce_ws[M] = ws
         return ws
 
@@ -619,6 +621,7 @@ class Denoiser:
     def rounding(self, xr, M, tgt=None, ce_ws=None, dtype=None):
         """xr [M,768] (compute dtype) -> (lse[M], argmax[M], nll[M] or None) without materialising the logits."""
         cw = ce_ws or self._ce_workspace(M)
+        cw["fused"] = False
         o = self.ops
         o.begin()
         W = self.W_lm_c if dtype is None else (self.W_lm if dtype == DIC_F32 else self.W_lm_c)
@@ -631,15 +634,49 @@ class Denoiser:
                                       _p(cw["nll"]) if tgt is not None else 0, o.stream), "ce_combine")
         return cw["lse"], cw["argmax"], (cw["nll"] if tgt is not None else None)
 
+    # shift of the per-row reference point of rounding_train's exponentials above the target logit (include/dic_hip.h, dic_ce_target_logit)
+    CE_REF_SHIFT = 40.0
+
+    @property
+    def ce_fused(self):
+        """bf16 engine: the training forward of the rounding loss leaves exp(logit - c) behind, so the backward needs no second logits GEMM
+        (DIC_CE_FUSED=0: the recompute path, kept as the A/B partner and for the fp32 engine)."""
+        return self.bf16 and not _V1_BF16 and _CE_FUSED
+
+    def rounding_train(self, xr, M, tgt, ce_ws=None):
+        """Training form of `rounding` (ref :323, 436-437 with their backward in mind): one GEMM over the vocabulary writes
+        E = exp(logit - c) in bf16 (1 GB at M = 16 384, the buffer the recompute path uses for dlogits) + per-slab sums; lse / nll come from the
+        sums, and E with its target entries patched is (softmax - onehot) up to the per-row factor 1/Z that `rounding_backward`'s caller
+        applies.  Saves the backward's recompute of the logits (0.7 ms of a 14.7 ms step)."""
+        cw = ce_ws or self._ce_workspace(M)
+        o = self.ops
+        o.begin()
+        if cw["dlogits"] is None:
+            cw["dlogits"] = torch.empty(M, self.vpad, dtype=self.tdtype, device=self.device)
+        L = o.L
+        tile = choose_tile(M, self.vocab, 1, EPI_CE_EXP)
+        np_ = L.dic_ce_n_partials(self.vocab, tile)
+        _lib.check(L.dic_ce_target_logit(_p(xr), _p(self.W_lm_c), _p(tgt), M, self.vocab, 768, self.CE_REF_SHIFT, _p(cw["tgt_logit"]), _p(cw["cref"]),
+                                         o.stream), "ce_target_logit")
+        o.gemm(_p(xr), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_EXP, tgt=_p(tgt), lse=_p(cw["cref"]),
+               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), tile=tile)
+        _lib.check(L.dic_ce_exp_combine(_p(cw["partial"]), np_, _p(cw["cref"]), _p(cw["tgt_logit"]), _p(tgt), M, self.vocab, _p(cw["dlogits"]), self.vpad,
+                                        _p(cw["lse"]), _p(cw["nll"]), _p(cw["inv_z"]), o.stream), "ce_exp_combine")
+        cw["fused"] = True
+        return cw["lse"], None, cw["nll"]
+
     def rounding_backward(self, cw, M, rows_a, scale_a, scale_b):
-        """dxr = ((softmax - onehot) * row_scale) @ W  via a recompute GEMM with the dlogits epilogue + one (KC,KM) GEMM."""
+        """dxr = ((softmax - onehot) * row_scale) @ W  via a recompute GEMM with the dlogits epilogue + one (KC,KM) GEMM.  After
+        `rounding_train` (cw["fused"]) the first GEMM is skipped and dxr comes back WITHOUT the per-row factor row_scale / Z: the caller
+        folds it into the add of dxr to the encoder-output gradient (dic_add_rows_scaled with cw["inv_z"])."""
         o = self.ops
         o.begin()
         if cw["dlogits"] is None:
             cw["dlogits"] = torch.empty(M, self.vpad, dtype=self.tdtype, device=self.device)
         ws_split = self._saved["splitk"]
-        o.gemm(_p(cw["xr"]), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_DLOGITS,
-               tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b)
+        if not cw.get("fused"):
+            o.gemm(_p(cw["xr"]), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_DLOGITS,
+                   tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b)
         # 64 x 3 = 192 256-tiles are 0.75 of a round and x2 slices 1.5 rounds: four slices of the 30592-deep contraction fill
         # three rounds exactly (measured at M = 16384: 862 us vs 1064 us for two slices, 1032 us unsplit)
         sk = next((k for k in (4, 2) if M * 768 * k <= ws_split.numel() and M >= 2048), 1)

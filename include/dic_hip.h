@@ -43,12 +43,18 @@ const char* dic_last_error(void);
  *               -- streaming form of softmax/gather/argmax over the 30522-wide logits (ref:323,436-437,620)
  *   CE_DLOGITS  C = (exp(acc - lse[m]) - [n == tgt[m]]) * (m < ce_rows_a ? ce_scale_a : ce_scale_b),
  *               zero for N <= n < ldc                                        -- backward of the rounding loss
+ *   CE_EXP      C = exp(acc - lse[m]) (bf16; `lse` holds the caller's per-row REFERENCE POINT c[m], see dic_ce_target_logit), zero for
+ *               N <= n < ldc; partial[m][n/64] = sum of the unrounded values over that 64-column slab (np floats per row, np =
+ *               dic_ce_n_partials(N, tile)); tgt_logit[m] = acc[m][tgt[m]].  The training forward of the rounding loss: dic_ce_exp_combine
+ *               then turns C into the gradient operand, so the backward is ONE GEMM (C x W) and no second pass over the vocabulary
+ *               (bf16 LDS-DMA kernels only)
  */
 #define DIC_EPI_AFFINE 0
 #define DIC_EPI_BIAS_GELU 1
 #define DIC_EPI_GELU_BWD 2
 #define DIC_EPI_CE_PARTIAL 3
 #define DIC_EPI_CE_DLOGITS 4
+#define DIC_EPI_CE_EXP 5
 
 typedef struct DicGemmParams {
     const void* A; const void* B; void* C;
@@ -132,6 +138,20 @@ int dic_prof_end(double* total_ms, double* total_flops, int* n_launches);
 int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_partials,
                    float* lse, int64_t* argmax, float* nll, void* stream);
 
+/* Rounding loss, training form (ref:323, 436-437 forward AND the backward autograd derives from them), three steps around two GEMMs:
+ *  1. dic_ce_target_logit: t[m] = <xr[m], W[tgt[m]]> (fp32 accumulate over the bf16 operands), c[m] = t[m] + shift -- the reference point of
+ *     row m's exponentials.  With shift = 40: exp(logit - c) overflows only if some logit exceeds the target's by 128 (a per-token loss
+ *     > 128), and what underflows is < e^-47 of the row's sum.  A target outside [0, V) gives t = 0.
+ *  2. dic_gemm(CE_EXP) with lse = c: E [M][ldE] bf16, the slab sums, tgt_logit.
+ *  3. dic_ce_exp_combine: Z[m] = sum of the slab sums (fixed order); lse[m] = log Z + c[m]; nll[m] = lse[m] - tgt_logit[m]; inv_z[m] = 1/Z;
+ *     and E[m][tgt[m]] = exp(tgt_logit[m] - c[m]) - Z[m], so that  inv_z[m] * E[m][:]  ==  softmax(logits[m]) - onehot(tgt[m])  to bf16
+ *     rounding per element -- what CE_DLOGITS writes after a second GEMM.
+ *  The gradient w.r.t. xr is then  row_scale[m] * inv_z[m] * (E @ W)[m]:  dic_gemm (k-contiguous A = E, k-major B = W, fp32 out) followed by
+ *  dic_add_rows_scaled.                                                                                                            */
+int dic_ce_target_logit(const void* xr_bf16, const void* W_bf16, const int64_t* tgt, int M, int V, int D, float shift, float* t, float* c, void* stream);
+int dic_ce_exp_combine(const float* partial, int n_partials, const float* c, const float* tgt_logit, const int64_t* tgt, int M, int V,
+                       void* E_bf16, int ldE, float* lse, float* nll, float* inv_z, void* stream);
+
 /* ---------------------------------------------------------------- embedding + q_sample (ref:459, 347-362) */
 /* out[i] = E[ids[i]].  An id outside [0, V) (where nn.Embedding raises) zero-fills its row and is REPORTED through `err` (optional;
  * two ints zeroed by the caller, device memory or device-visible pinned host memory): err[0] += 1, err[1] = max(err[1], i + 1).      */
@@ -214,6 +234,8 @@ int dic_emb_loss(int dtype, int kind, const float* x_out, const float* target, i
                  float* dx_out, const float* grad_scale, void* xr, int N, int L, int Tk, int D, void* stream);
 /* dx_out[n][t<L][:] += dxr[n*L+t][:]   (adds the rounding-loss gradient)                                           */
 int dic_add_rows(float* dx_out, const float* dxr, int N, int L, int Tk, int D, void* stream);
+/* the same with a per-row factor: dx_out row (n, l) += inv_z[n*L + l] * scale * dxr row (n*L + l)   (inv_z as written by dic_ce_exp_combine) */
+int dic_add_rows_scaled(float* dx_out, const float* dxr, const float* inv_z, float scale, int N, int L, int Tk, int D, void* stream);
 /* out4[0] = scale_a*sum in[0:n_a), out4[1] = scale_b*sum in[n_a:n), out4[2] = out4[0]+out4[1] (fp64 accumulate)      */
 int dic_seg_sum(const float* in, int n, int n_a, float scale_a, float scale_b, float* out4, const float* carry, void* stream);
 /* (out4[0..2] as above; out4[3] = out4[2] + *carry (carry optional): the step's total l = x_t_loss + x_1_loss + prob_loss, ref:481) */

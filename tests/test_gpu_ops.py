@@ -331,6 +331,59 @@ def test_rounding_ce_partial_combine_and_backward(L, dtype, V, tile):
     assert relerr(dxr, xx.grad) < (1e-5 if dtype == F32 else 2e-2)
 
 
+@pytest.mark.parametrize("V,tile,M", [(30522, 256, 300), (30522, 128, 40), (1000, 256, 300), (1000, 128, 75)])
+def test_rounding_training_form_exp_epilogue_equals_softmax_minus_onehot(L, V, tile, M):
+    """dic_ce_target_logit -> dic_gemm(CE_EXP) -> dic_ce_exp_combine (bf16): lse / nll as the streaming form gives them, inv_z * E equal to
+    softmax - onehot per element to bf16 rounding (what CE_DLOGITS writes after a second GEMM), padding columns zero, and the gradient
+    inv_z * row_scale * (E @ W) against autograd of the oracle's rounding loss on the same bf16 operands.  One row's logits are shifted far
+    from its target's (a confidently wrong row) and one target is made dominant: the reference point keeps both finite."""
+    K = 768
+    g = torch.Generator().manual_seed(V + tile)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(V, K, generator=g) * 0.05
+    tgt = torch.randint(0, V, (M,), generator=g)
+    x[1] = 18.0 * W[(int(tgt[1]) + 5) % V] / W[(int(tgt[1]) + 5) % V].norm() * 4        # another token wins by a wide margin (nll ~ 50)
+    x[2] = 18.0 * W[int(tgt[2])] / W[int(tgt[2])].norm() * 4                            # the target wins by a wide margin (nll ~ 0)
+    vpad = (V + 127) // 128 * 128
+    Wp = torch.zeros(vpad, K)
+    Wp[:V] = W
+    xd, Wd, td = dev(x, DT[BF16]), dev(Wp, DT[BF16]), dev(tgt)
+    npart = L.dic_ce_n_partials(V, tile)
+    part = torch.full((M, npart), float("nan"), device="cuda")
+    t0, cref, tl = (torch.zeros(M, device="cuda") for _ in range(3))
+    lse, nll, inv_z = (torch.zeros(M, device="cuda") for _ in range(3))
+    E = torch.full((M, vpad), float("nan"), dtype=DT[BF16], device="cuda")
+    ok(L.dic_ce_target_logit(p(xd), p(Wd), p(td), M, V, K, 40.0, p(t0), p(cref), stream()), L)
+    gemm(L, BF16, 0, 0, 5, A=p(xd), B=p(Wd), C=p(E), M=M, N=V, K=K, lda=K, ldb=K, ldc=vpad, tgt=p(td), lse=p(cref), partial=p(part), tgt_logit=p(tl), tile=tile)
+    ok(L.dic_ce_exp_combine(p(part), npart, p(cref), p(tl), p(td), M, V, p(E), vpad, p(lse), p(nll), p(inv_z), stream()), L)
+    torch.cuda.synchronize()
+    xx = xd.float().cpu().double().requires_grad_(True)
+    W64 = Wd.float().cpu().double()[:V]
+    lg = xx @ W64.t()
+    ref_lse = torch.logsumexp(lg, -1)
+    ref_t = lg.gather(1, tgt.unsqueeze(1)).squeeze(1)
+    assert float(ref_lse[1] - ref_t[1]) > 30 and float(ref_lse[2] - ref_t[2]) < 1e-3            # the two planted rows are what they claim
+    np.testing.assert_allclose(t0.cpu().numpy(), ref_t.detach().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(tl.cpu().numpy(), ref_t.detach().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(nll.cpu().numpy(), (ref_lse - ref_t).detach().numpy(), rtol=1e-4, atol=3e-5)
+    assert float(E[:, V:].float().abs().max()) == 0.0, "padding columns must be zero"
+    dl = E[:, :V].float().cpu().double() * inv_z.cpu().double().unsqueeze(1)
+    ref_dl = torch.softmax(lg.detach(), -1)
+    ref_dl[torch.arange(M), tgt] -= 1.0
+    err = (dl - ref_dl).abs()
+    assert float((err / (ref_dl.abs() + 1e-6)).max()) < 6e-3, "every element within bf16 rounding (2^-8) of softmax - onehot"
+    rows_a, sa, sb = M * 3 // 5, 0.5 / 3, 0.5 / 2
+    dxr = torch.zeros(M, K, dtype=torch.float32, device="cuda")
+    gemm(L, BF16, 0, 1, 0, A=p(E), B=p(Wd), C=p(dxr), M=M, N=K, K=vpad, lda=vpad, ldb=K, ldc=K, out_f32=1)
+    dx = torch.zeros(M, 1, K, device="cuda")                     # [N = M sequences][Tk = 1][768], L = 1: add_rows' layout with one row each
+    ok(L.dic_add_rows_scaled(p(dx), p(dxr), p(inv_z), sa, rows_a, 1, 1, K, stream()), L)
+    ok(L.dic_add_rows_scaled(p(dx) + rows_a * K * 4, p(dxr) + rows_a * K * 4, p(inv_z) + rows_a * 4, sb, M - rows_a, 1, 1, K, stream()), L)
+    nl = ref_lse - ref_t
+    (nl[:rows_a].sum() * sa + nl[rows_a:].sum() * sb).backward()
+    assert relerr(dx.reshape(M, K), xx.grad) < 2e-2
+
+
 # ------------------------------------------------------------------------------------------------ embedding + q_sample
 def test_embed_gather_reports_out_of_range_ids(L):
     """nn.Embedding raises for ids outside [0, V); the kernel reports them (count + last position) and zero-fills the row -- no clamping."""
