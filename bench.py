@@ -296,9 +296,12 @@ def main():
                 "launches_per_step": n.value // max(args.steps, 1), "gemm_ms_per_step": round(ms.value / args.steps, 3),
                 "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
         if args.dtype == "bf16" and w == 0.0:
-            # the backward recomputes the rounding logits instead of storing them: that GEMM is executed work, not algorithmic work
-            rec = 2.0 * ((S + 1) * B * L) * 30592 * 768
-            roof["frac_excluding_logits_recompute"] = round((fl.value / args.steps - rec) / (ms.value / args.steps * 1e-3) / 1e12 / peak, 4)
+            if model.ce_fused:
+                roof["logits_recompute"] = "none: the training forward of the rounding loss keeps exp(logit - c) (dic_gemm CE_EXP), every GEMM flop counted is algorithmic"
+            else:
+                # DIC_CE_FUSED=0: the backward recomputes the rounding logits instead of storing them: that GEMM is executed work, not algorithmic work
+                rec = 2.0 * ((S + 1) * B * L) * 30592 * 768
+                roof["frac_excluding_logits_recompute"] = round((fl.value / args.steps - rec) / (ms.value / args.steps * 1e-3) / 1e12 / peak, 4)
     barrier()
 
     extras = rank == 0 and world == 1 and not args.quick
