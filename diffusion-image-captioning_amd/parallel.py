@@ -43,8 +43,10 @@ def init_from_env(backend: str | None = None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DIC_DIST_SHARE_GPU", "0") == "1":
+        local = 0                  # test rig: every rank on GPU 0 (with DIC_DIST_BACKEND=gloo -- RCCL refuses two ranks on one device)
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("DIC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)

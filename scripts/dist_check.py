@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Data-parallel step of the REAL engine on ranks that share one GPU (launch under torch.distributed.run with DIC_DIST_SHARE_GPU=1
+DIC_DIST_BACKEND=gloo -- RCCL refuses two ranks on one device, and a 1-GPU box is what the test pool has).  Every rank
+  1. takes a plain single-process step on the FULL batch (before the process group exists): reference gradients and loss;
+  2. joins the group, takes the same step on ITS shard through parallel.GradReducer (slices issued from the backward, streamed AdamW) or,
+     with DIC_DP_SINGLE=1, through the one-collective exchange;
+and checks: mean of the shard losses == full-batch loss, exchanged gradient x 1/world == full-batch gradient, and after a second step the
+parameters are bit-identical on every rank.  Prints one line per rank; exit code 0 = all checks passed."""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dic = importlib.import_module("diffusion-image-captioning_amd")
+dtype = os.environ.get("DTYPE", "fp32")
+NL, B, S, L, V = int(os.environ.get("LAYERS", "4")), 8, 2, 16, 1000
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+E = dic.synth.vocab_embedding(V, 768, 0)
+
+
+def configure(b):
+    dic.cfg.update(BATCH_SIZE=b, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=V, CLASSIFIER_FREE_WEIGHT=0.0,
+                   CLIP_ADDING_METHOD="concat", LOSS_FUNC="series_sum_sample_mean", X_0_PREDICTION=True, ROUNDING_WEIGHT=0.5)
+
+
+def build():
+    return dic.DistilBertModel(E, E, config=dict(n_layers=NL, dropout=0.0, attention_dropout=0.0), dtype=dtype, device=dev, seed=0)
+
+
+full = {k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, V, seed=1).items()}
+t = torch.from_numpy(dic.synth.timesteps(S, 100, 3))
+noise = [torch.from_numpy(dic.synth.noise((B, L, 768), 5, f"eps{i}")).to(dev) for i in range(2)]
+
+# 1. single process, full batch
+configure(B)
+m0 = build()
+tr0 = dic.AdamW(m0.parameters(), lr=1e-4)
+l0 = float(dic.train_func(m0, tr0, full, t=t, noises=noise)[0])
+g0 = m0.params.G.clone()
+del m0, tr0
+
+# 2. data parallel, this rank's shard
+r, w, _ = dic.parallel.init_from_env()
+assert (r, w) == (rank, world) and B % world == 0
+configure(B // world)
+m = build()
+dic.parallel.configure_model_for_rank(m)
+tr = dic.AdamW(m.parameters(), lr=1e-4)
+mine = dic.parallel.shard(full)
+nz = [n[rank * (B // world):(rank + 1) * (B // world)].contiguous() for n in noise]
+l1 = dic.train_func(m, tr, mine, t=t, noises=nz)[0]
+ls = torch.tensor([float(l1)], dtype=torch.float64)
+torch.distributed.all_reduce(ls)
+l_dp = float(ls) / world
+g = m.params.G * (1.0 / world)
+tol_l, tol_g = (2e-5, 2e-4) if dtype == "fp32" else (3e-3, 5e-2)
+err_l = abs(l_dp - l0) / abs(l0)
+err_g = float((g - g0).abs().max() / g0.abs().max())
+red = dic.parallel.GradReducer.last
+ncoll = red.n_collectives if red is not None else -1
+dic.train_func(m, tr, mine, t=t, noises=nz)           # second step: the optimizer state took the exchanged gradients on every rank
+torch.cuda.synchronize()
+chk = torch.tensor([float(m.params.P.double().sum()), float(m.params.P.double().abs().sum())], dtype=torch.float64)
+allc = [torch.zeros_like(chk) for _ in range(world)]
+torch.distributed.all_gather(allc, chk)
+same = all(torch.equal(allc[0], c) for c in allc)
+single = os.environ.get("DIC_DP_SINGLE", "0") == "1"
+want_coll = 1 if single else None
+ok = err_l < tol_l and err_g < tol_g and same and (want_coll is None or ncoll == want_coll) and ncoll >= 1
+print(f"rank {rank}/{world} {dtype} layers={NL} collectives/step={ncoll} loss full {l0:.6f} dp-mean {l_dp:.6f} (rel {err_l:.1e})  "
+      f"grad max-rel err {err_g:.1e}  params identical across ranks: {same}  -> {'OK' if ok else 'FAILED'}", flush=True)
+torch.distributed.barrier()
+sys.exit(0 if ok else 1)

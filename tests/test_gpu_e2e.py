@@ -4,6 +4,8 @@ reference itself (tests/golden, made by oracle/gen_golden.py) and the CPU oracle
 Tolerances: fp32 mode -- losses 1e-4 relative (north_star), hidden states 2e-4 absolute, token ids bit-exact;
 bf16 mode -- losses 3e-3 relative (bf16 operands, fp32 accumulation/statistics), reported in DESIGN.md."""
 import importlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -694,3 +696,25 @@ def test_optional_timestep_embedding_end_to_end_fp32():
         assert float((xa - xb).abs().max()) > 1e-3
     finally:
         dic.cfg.update(TIMESTEP_EMBEDDING=False)
+
+
+@pytest.mark.parametrize("world,dtype,layers,single", [(2, "fp32", 4, "0"), (2, "bf16", 4, "1"), (4, "bf16", 12, "0")])
+def test_data_parallel_step_of_the_real_engine_on_ranks_sharing_one_gpu(world, dtype, layers, single):
+    """SURVEY section 8e with the HIP engine instead of the oracle: `world` processes (gloo; RCCL refuses two ranks on one device) take
+    the step on their shards through parallel.GradReducer -- slices issued from the backward + streamed AdamW, or the one-collective exchange --
+    and must reproduce the single-process full-batch loss and gradient; after a second step every rank holds bit-identical parameters
+    (scripts/dist_check.py does the comparisons and exits non-zero on a mismatch)."""
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, DIC_DIST_SHARE_GPU="1", DIC_DIST_BACKEND="gloo", DTYPE=dtype, LAYERS=str(layers), DIC_DP_SINGLE=single,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in (r.stdout + r.stderr).splitlines() if ln.startswith("rank ")]
+    assert r.returncode == 0 and len(lines) >= 1 and all("-> OK" in ln for ln in lines), (r.stdout + r.stderr)[-3000:]
