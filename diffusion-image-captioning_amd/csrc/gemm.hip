@@ -422,6 +422,9 @@ __device__ __forceinline__ i32x4 take8(const i32x4& keep, const i32x4& from_part
 // waits for and BEFORE its first store: a wait for the bias / residual / pre-activation loads is a `vmcnt(0)` and would otherwise also
 // wait ~2.4 k cycles for that DMA (the s_memtime trace showed it in front of every epilogue), while behind the wait the DMA's latency
 // hides under the stores.
+#ifndef DIC_CE_EXP_ABL
+#define DIC_CE_EXP_ABL 0      // timing ablations of the CE_EXP epilogue (scripts/experiments/ce_exp_ablate.*): 1 no slab sums, 2 no target pick, 4 __expf(x - c), 8 no sum accumulation
+#endif
 template <class C, int EPI, bool PF, int CNT, bool BIAS_IN_ACC, class IssueNext, class Stamp>
 __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first, int lane, IssueNext&& issue_next_,
                                                 Stamp&& stamp) {
@@ -670,28 +673,32 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
         // in [N, ldc) are written as zeros), the sum of the UNROUNDED values of this wave's 64 columns per row into partial[m][n_first / 64],
         // and the fp32 logit of the target column into tgt_logit[m].  dic_ce_exp_combine turns E into the (unnormalised) gradient operand,
         // so the backward needs no second pass over the vocabulary.
+        // The store-bound part (exp + 1 GB of E) is the loop; everything else is kept out of it: the row sums are reduced over the four lanes
+        // of a row with v_permlane16/32_swap (no LDS round trip, no lgkmcnt wait) and stored through a buffer descriptor (no exec-mask branches),
+        // and the target logit is picked in a branch that a wave takes for 3 % of its fragments (a first version compared every element's
+        // column with the target: SGPR-mask bookkeeping spilled, 950 us against 780 us for the CE_DLOGITS epilogue that writes the same bytes).
         static_assert(G::WCOLS == 64, "one partial sum per 64-column wave slab");
         float r_c[CNT];
-        long long r_tg[CNT];
+        int r_tg[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int m = m_first + 16 * i + t;
-            const bool ok = m < p.M;
-            r_c[i] = ok ? p.lse[m] : 0.f;
-            r_tg[i] = (ok && p.tgt) ? p.tgt[m] : -1;
+            // (unconditional loads from a clamped row: a load inside an `m < M` branch gets its own vmcnt(0) when the compiler sinks the
+            //  first use into the branch -- eight serialised round trips per tile, measured +120 us on this launch)
+            const int m = m_first + 16 * i + t, mc = m < p.M ? m : p.M - 1;
+            r_c[i] = p.lse[mc];
+            const long long tg = p.tgt ? p.tgt[mc] : -1;
+            r_tg[i] = (m < p.M && tg >= 0 && tg < (long long)p.N) ? (int)tg : -0x40000000;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         issue_next();
         const LineBuf bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.ldc);
         const int np = ((p.N + G::BN - 1) / G::BN) * G::WN, slot = n_first / G::WCOLS;
         constexpr float L2E = 1.4426950408889634f;
+        float sums[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int m = m_first + 16 * i + t;
             const float c2 = r_c[i] * L2E;
-            const int tg = (r_tg[i] >= 0 && r_tg[i] < (long long)p.N) ? (int)r_tg[i] : -1;
-            float sm = 0.f, tv = 0.f;
-            bool has_t = false;
+            float sm = 0.f;
             i32x4 P[G::NP];
 #pragma unroll
             for (int q = 0; q < G::NP; ++q) {
@@ -699,23 +706,61 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 const int n = nc[q];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (n + r == tg) { tv = x0[r]; has_t = true; }
-                    if (n + 4 + r == tg) { tv = x1[r]; has_t = true; }
+#if DIC_CE_EXP_ABL & 4
+                    const float e0 = (n + r < p.N) ? __expf(x0[r] - r_c[i]) : 0.f;
+                    const float e1 = (n + 4 + r < p.N) ? __expf(x1[r] - r_c[i]) : 0.f;
+#else
                     const float e0 = (n + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], L2E, -c2)) : 0.f;
                     const float e1 = (n + 4 + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x1[r], L2E, -c2)) : 0.f;
+#endif
+#if !(DIC_CE_EXP_ABL & 8)
                     sm += e0 + e1;
+#endif
                     x0[r] = e0; x1[r] = e1;
                 }
                 P[q] = pack8f(x0, x1);
             }
             put_lines(i, bC, P[0], P[1]);          // only rows < M are written
-            sm += __shfl_xor(sm, 16, 64);
-            sm += __shfl_xor(sm, 32, 64);
-            if (m < p.M) {
-                if (g == 0) p.partial[(size_t)m * np + slot] = sm;
-                if (has_t) p.tgt_logit[m] = tv;
+            sums[i] = sm;
+        }
+        // row sums over the four lanes (g = 0..3) that share a row: lanes 16 and 32 apart
+        const long long pbytes = (long long)(p.M - m_first) * np * 4;
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.partial + (size_t)m_first * np), 0,
+                                                                             (int)(pbytes < 0 ? 0 : (pbytes > 0x7FFFFFFFll ? 0x7FFFFFFFll : pbytes)), 0x00020000);
+        const unsigned poff = g == 0 ? ((unsigned)t * (unsigned)np + (unsigned)slot) * 4u : 0x80000000u;
+#if !(DIC_CE_EXP_ABL & 1)
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            // (inline asm: with the same value passed for both operands of __builtin_amdgcn_permlane32_swap this compiler adds result 0 to
+            //  itself -- seen in the ISA, and in the sums.  The s_nop covers the VALU-write -> permlane-swap wait states the asm hides.)
+            float a0 = sums[i], a1 = sums[i];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));      // a0 = [lo, lo], a1 = [hi, hi] (lane halves)
+            float b0 = a0 + a1, b1 = b0;
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(b0), "+v"(b1));      // rows 0<->1, 2<->3
+            const float s4 = b0 + b1;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s4), rsP, (int)(poff + (unsigned)(16 * i) * (unsigned)np * 4u), 0, 0);
+        }
+#endif
+        // the target's logit: a lane owns columns nc[0]..+7 and nc[1]..+7 of row t
+#if !(DIC_CE_EXP_ABL & 2)
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            const unsigned d0 = (unsigned)(r_tg[i] - nc[0]), d1 = (unsigned)(r_tg[i] - nc[1]);
+            if (d0 < 8u || d1 < 8u) {
+                const unsigned d = d0 < 8u ? d0 : d1;
+                const int q2 = d0 < 8u ? 0 : 2;
+                float tv = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a0 = acc[i][j][r], a1 = acc[i][2 + j][r];
+                        tv = (d == (unsigned)(4 * j + r)) ? (q2 == 0 ? a0 : a1) : tv;
+                    }
+                p.tgt_logit[m_first + 16 * i + t] = tv;
             }
         }
+#endif
     }
 }
 
