@@ -710,8 +710,10 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                     const float e0 = (n + r < p.N) ? __expf(x0[r] - r_c[i]) : 0.f;
                     const float e1 = (n + 4 + r < p.N) ? __expf(x1[r] - r_c[i]) : 0.f;
 #else
-                    const float e0 = (n + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x0[r], L2E, -c2)) : 0.f;
-                    const float e1 = (n + 4 + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x1[r], L2E, -c2)) : 0.f;
+                    // (exponent capped at 2^100: a logit more than 69 + shift nats above its row's reference point -- a per-token loss beyond ~109 with
+                    //  the shift of 40 the engine uses -- saturates instead of overflowing the fp32 sums of this row and of E @ W)
+                    const float e0 = (n + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fminf(__builtin_fmaf(x0[r], L2E, -c2), 100.f)) : 0.f;
+                    const float e1 = (n + 4 + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fminf(__builtin_fmaf(x1[r], L2E, -c2), 100.f)) : 0.f;
 #endif
 #if !(DIC_CE_EXP_ABL & 8)
                     sm += e0 + e1;

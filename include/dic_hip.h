@@ -140,8 +140,9 @@ int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_pa
 
 /* Rounding loss, training form (ref:323, 436-437 forward AND the backward autograd derives from them), three steps around two GEMMs:
  *  1. dic_ce_target_logit: t[m] = <xr[m], W[tgt[m]]> (fp32 accumulate over the bf16 operands), c[m] = t[m] + shift -- the reference point of
- *     row m's exponentials.  With shift = 40: exp(logit - c) overflows only if some logit exceeds the target's by 128 (a per-token loss
- *     > 128), and what underflows is < e^-47 of the row's sum.  A target outside [0, V) gives t = 0.
+ *     row m's exponentials.  With shift = 40 everything up to a per-token loss of ~109 nats is exact to fp32/bf16 rounding; beyond, CE_EXP
+ *     saturates the exponential at 2^100 (the loss of such a row reads ~109, its gradient stays finite) instead of overflowing; what
+ *     underflows is < e^-47 of the row's sum.  A target outside [0, V) gives t = 0.
  *  2. dic_gemm(CE_EXP) with lse = c: E [M][ldE] bf16, the slab sums, tgt_logit.
  *  3. dic_ce_exp_combine: Z[m] = sum of the slab sums (fixed order); lse[m] = log Z + c[m]; nll[m] = lse[m] - tgt_logit[m]; inv_z[m] = 1/Z;
  *     and E[m][tgt[m]] = exp(tgt_logit[m] - c[m]) - Z[m], so that  inv_z[m] * E[m][:]  ==  softmax(logits[m]) - onehot(tgt[m])  to bf16

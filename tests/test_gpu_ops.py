@@ -382,6 +382,19 @@ def test_rounding_training_form_exp_epilogue_equals_softmax_minus_onehot(L, V, t
     nl = ref_lse - ref_t
     (nl[:rows_a].sum() * sa + nl[rows_a:].sum() * sb).backward()
     assert relerr(dx.reshape(M, K), xx.grad) < 2e-2
+    # saturation instead of overflow: a row whose winning logit is ~190 nats above its target's still gives finite statistics and a finite gradient
+    x2 = x.clone()
+    x2[1] = x[1] * 1.9
+    xd2 = dev(x2, DT[BF16])
+    ok(L.dic_ce_target_logit(p(xd2), p(Wd), p(td), M, V, K, 40.0, p(t0), p(cref), stream()), L)
+    gemm(L, BF16, 0, 0, 5, A=p(xd2), B=p(Wd), C=p(E), M=M, N=V, K=K, lda=K, ldb=K, ldc=vpad, tgt=p(td), lse=p(cref), partial=p(part), tgt_logit=p(tl), tile=tile)
+    ok(L.dic_ce_exp_combine(p(part), npart, p(cref), p(tl), p(td), M, V, p(E), vpad, p(lse), p(nll), p(inv_z), stream()), L)
+    gemm(L, BF16, 0, 1, 0, A=p(E), B=p(Wd), C=p(dxr), M=M, N=K, K=vpad, lda=vpad, ldb=K, ldc=K, out_f32=1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(nll).all()) and bool(torch.isfinite(dxr * inv_z.unsqueeze(1)).all()) and 100 < float(nll[1]) < 115
+    lg2 = xd2.float().cpu().double() @ W64.t()
+    keep = torch.ones(M, dtype=torch.bool); keep[1] = False
+    np.testing.assert_allclose(nll.cpu().numpy()[keep.numpy()], (torch.logsumexp(lg2, -1) - lg2.gather(1, tgt.unsqueeze(1)).squeeze(1)).numpy()[keep.numpy()], rtol=1e-4, atol=3e-5)
 
 
 # ------------------------------------------------------------------------------------------------ embedding + q_sample
