@@ -434,6 +434,37 @@ def test_full_size_gradient_is_mean_of_shard_gradients(dtype, n_layers, tol):
     assert err < tol and np.isfinite(l_full)
 
 
+def test_rounding_loss_training_form_equals_the_recompute_path_at_the_bench_shape(monkeypatch):
+    """Config 2 (B=512, 12 layers, bf16): the step whose rounding loss keeps exp(logit - c) in the forward (the default) against
+    the step that recomputes the logits in the backward (DIC_CE_FUSED=0) on the same weights / batch / noise / timesteps: the same losses and,
+    tensor by tensor, the same gradients up to the bf16 rounding both forms apply to their 16 384 x 30 522 gradient operand."""
+    engine = importlib.import_module("diffusion-image-captioning_amd.engine")
+    B, L, V, NL = 512, 16, 30522, 12
+    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=1, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True, VOCAB_SIZE=V)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(V, 768, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 3).items()}
+    t = torch.tensor([[[37]]])
+    nz = [torch.from_numpy(synth.noise((B, L, 768), 11, f"eps{i}")) for i in range(2)]
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "_CE_FUSED", fused)
+        model = dic.DistilBertModel(E, E, config=dict(n_layers=NL, dropout=0.0, attention_dropout=0.0), dtype="bf16")
+        model.load_state(synth.denoiser_state(NL, 0))
+        assert model.ce_fused == fused
+        out = dic.train_func(model, _NoStep(model), x, t=t, noises=nz)
+        res[fused] = ([f(v) for v in out], model.params.G.clone(), {n: p.grad.float().norm().item() for n, p in zip(model.params.names, model.parameters())})
+        del model
+    (la, ga, na), (lb, gb, nb) = res[True], res[False]
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-6 * abs(b), (la, lb)
+    err = float((ga - gb).norm() / gb.norm())
+    worst = max(abs(na[k] - nb[k]) / (nb[k] + 1e-12) for k in nb if nb[k] > 1e-6 and "k_lin.bias" not in k)
+    print("fused vs recompute: losses", la, "gradient rel err", err, "worst per-tensor norm rel diff", worst)
+    assert err < 2e-3 and worst < 2e-3
+
+
 def test_full_size_training_is_deterministic_and_descends():
     """Config 2: B=512, 12 layers, bf16, dropout 0.1: same seeds -> bit-identical losses; loss decreases over steps."""
     B, L, V = 512, 16, 30522
