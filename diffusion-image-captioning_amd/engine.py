@@ -68,6 +68,7 @@ _TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "au
 _WGRAD_CU_CAP = int(_os.environ.get("DIC_WGRAD_CU_CAP", "0"))   # >0: weight-gradient GEMMs keep to this many CUs (A/B switch)
 _WGRAD_TILE = _os.environ.get("DIC_WGRAD_TILE", "auto")    # tile of the weight-gradient GEMMs (A/B switch)
 _V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the register-staged v1 kernel (128-tiles only)
+_GELU_FWD_TILE = _os.environ.get("DIC_GELU_FWD_TILE", "256")   # tile of the bias+GELU forward GEMM (A/B switch)
 _GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GELU' input-gradient GEMM (A/B switch; 128 measured faster in rounds 2 and 3)
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
@@ -80,7 +81,7 @@ def choose_tile(M, N, split_k=1, epi=EPI_AFFINE):
     input) measured faster on 128-tiles (145 vs 154 us); bias+GELU (two 113 MB outputs) on 256-tiles (136 vs 162 us)."""
     if _TILE_MODE in ("128", "256"):
         return int(_TILE_MODE) if (M >= 256 and N >= 256) else 128
-    if M < 256 or N < 256 or (epi == EPI_GELU_BWD and _GELU_BWD_TILE != "256"):
+    if M < 256 or N < 256 or (epi == EPI_GELU_BWD and _GELU_BWD_TILE != "256") or (epi == EPI_BIAS_GELU and _GELU_FWD_TILE == "128"):
         return 128
     units = ((M + 255) // 256) * ((N + 255) // 256) * max(split_k, 1)
     return 256 if units >= int(0.75 * N_CU) else 128
