@@ -113,11 +113,14 @@ __device__ __forceinline__ float row_scale(const DicGemmParams& p, int m) { retu
 // ---- block -> (tile, K-slice) ----------------------------------------------------------------------
 // XCD-aware order: consecutive logical ids (same A row-panel, then the K-slices of one tile) share one XCD's L2.
 struct TileId { int bm, bn, nbn, kz, kt0, kt1; };
-__device__ __forceinline__ int total_units(const DicGemmParams& p, int bm_ = BM, int bn_ = BN) {
-    return ((p.N + bn_ - 1) / bn_) * ((p.M + bm_ - 1) / bm_) * (p.split_k > 1 ? p.split_k : 1);
+// (mrows: the number of rows the units cover when that is a row range of the problem instead of all p.M rows -- the two-height launch)
+__device__ __forceinline__ int total_units(const DicGemmParams& p, int bm_ = BM, int bn_ = BN, int mrows = -1) {
+    const int M_ = mrows >= 0 ? mrows : p.M;
+    return ((p.N + bn_ - 1) / bn_) * ((M_ + bm_ - 1) / bm_) * (p.split_k > 1 ? p.split_k : 1);
 }
-__device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, int pid, int bm_ = BM, int bn_ = BN) {
-    const int nbn = (p.N + bn_ - 1) / bn_, nbm = (p.M + bm_ - 1) / bm_;
+__device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, int pid, int bm_ = BM, int bn_ = BN, int mrows = -1) {
+    const int M_ = mrows >= 0 ? mrows : p.M;
+    const int nbn = (p.N + bn_ - 1) / bn_, nbm = (M_ + bm_ - 1) / bm_;
     const int split = p.split_k > 1 ? p.split_k : 1;
     const int nwg = nbm * nbn * split;
     {
@@ -895,7 +898,9 @@ struct WgradGroupDev {
 };
 
 template <class C, bool AKM, bool BKM, int EPI, int CNT, bool GROUP>
-__device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGroupDev* grp) {
+__device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGroupDev* grp, int row_base = 0, int row_cnt = -1) {
+    // row_base / row_cnt: this call covers rows [row_base, row_base + row_cnt) of the problem (row_cnt < 0: all of it) -- gemm_bf16_kernel2 runs
+    // the body twice with two tile heights
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Geo<C>;
     using T = bf16_t;
@@ -973,7 +978,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     // both waves of a SIMD: 25 % slower on the K = 768 GEMMs.)
     unsigned voA[G::PA], voB[G::PB];
     auto setup = [&](const TileId& tl) {          // descriptors anchored at the tile origin: OOB rows/k read as zero
-        const int m0 = tl.bm * tile_rows, n0 = tl.bn * G::BN;
+        const int m0 = row_base + tl.bm * tile_rows, n0 = tl.bn * G::BN;
         const T* Ab = (const T*)p.A + (AKM ? (size_t)m0 : (size_t)m0 * p.lda);
         const T* Bb = (const T*)p.B + (BKM ? (size_t)n0 : (size_t)n0 * p.ldb);
         long long a_bytes = AKM ? ((long long)(p.K - 1) * p.lda + (p.M - m0)) * S : ((long long)(p.M - m0 - 1) * p.lda + p.K) * S;
@@ -1148,7 +1153,8 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 
     // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
     // addressing set-up is paid once per workgroup and the tail of the launch is balanced by unit order, not dispatch order.
-    const int total = GROUP ? 0 : total_units(p, tile_rows, G::BN);
+    const int total = GROUP ? 0 : total_units(p, tile_rows, G::BN, row_cnt);
+    if (!GROUP && (int)blockIdx.x >= total) return;          // (only the second call of a two-height launch has fewer units than workgroups)
     int unit = blockIdx.x;
     // grouped launch: unit u of split * tiles, slice-slowest after the XCD-aware remap (consecutive logical units share an XCD's L2)
     int slab = 0;
@@ -1209,7 +1215,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     if constexpr (GROUP) {
         tl = group_unit(unit);
     } else {
-        tl = tile_of_unit(p, BK, unit, tile_rows, G::BN);
+        tl = tile_of_unit(p, BK, unit, tile_rows, G::BN, row_cnt);
     }
     setup(tl);
     if (tl.kt0 < tl.kt1) issue(0);
@@ -1229,7 +1235,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         bool more_next = false;
         if constexpr (!GROUP) {
             more_next = unit + (int)gridDim.x < total;
-            if (more_next) tl_next = tile_of_unit(p, BK, unit + (int)gridDim.x, tile_rows, G::BN);
+            if (more_next) tl_next = tile_of_unit(p, BK, unit + (int)gridDim.x, tile_rows, G::BN, row_cnt);
         } else {
             more_next = unit + (int)gridDim.x < grp->split * grp->tiles;
         }
@@ -1324,7 +1330,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
                 barrier_lds_only();
             }
         }
-        const int m_first = (GROUP ? 0 : done.bm * tile_rows) + row0_w, n_first = (GROUP ? 0 : done.bn * G::BN) + wn * G::WCOLS;
+        const int m_first = (GROUP ? 0 : row_base + done.bm * tile_rows) + row0_w, n_first = (GROUP ? 0 : done.bn * G::BN) + wn * G::WCOLS;
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
             epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn, issue_next);
         } else {
@@ -1347,6 +1353,18 @@ template <class C, bool AKM, bool BKM, int EPI, int CNT>
 __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
     if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
     gemm_bf16_body<C, AKM, BKM, EPI, CNT, false>(p, nullptr);
+}
+// TWO TILE HEIGHTS IN ONE LAUNCH.  A persistent grid runs its units in rounds of `slots` workgroups; with one tile height the last round is
+// usually partial (17 408 x 2304: 702 units of 224 rows = 2.74 rounds; 34 816 x 768: 1.83).  Here the first `row_split` rows -- whole rounds of
+// CA-fragment tiles -- are followed by ONE round of shorter CB-fragment tiles over the remaining rows, so that round costs (CB + fixed) / (CA +
+// fixed) of a full one instead of leaving CUs idle.  Each workgroup simply runs the body twice; tiles are independent, so nothing but the
+// reuse of its own LDS orders the two calls.
+template <class C, bool BKM, int EPI, int CA, int CB>
+__global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel2(DicGemmParams p, int row_split) {
+    if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
+    gemm_bf16_body<C, false, BKM, EPI, CA, false>(p, nullptr, 0, row_split);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    gemm_bf16_body<C, false, BKM, EPI, CB, false>(p, nullptr, row_split, p.M - row_split);
 }
 __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmParams p, WgradGroupDev grp) {
     gemm_bf16_body<T256, true, true, DIC_EPI_AFFINE, Geo<T256>::FM, true>(p, &grp);
@@ -1525,6 +1543,55 @@ void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
     launch_timed(gemm_bf16_kernel<C, AKM, BKM, E, CNT>, dim3(grid), dim3(G::NTH), (unsigned)G::LDS, st, q);
 }
 
+// Two tile heights (gemm_bf16_kernel2): R whole rounds of cA-fragment tiles + one round of cB-fragment tiles over the rest, if that beats the best
+// single height by 3 % in the cost model of pick_tile_rows.  OFF by default, ON inside diffusion.sample() (dic_gemm_set_two_heights; env
+// DIC_GEMM_TWO_HEIGHTS=1 turns it on everywhere).  Measured (profiles/r03_gemm_two_heights_ab.txt): FFN-1 at 17 408 rows 108.0 -> 105.2 us, QKV
+// unchanged, a sampling pass 7.56 -> 7.47 ms -- but the TRAINING step gets 0.8 % slower (13.78 -> 13.91 ms): there the CUs a partial round leaves
+// idle are not idle, they run the weight-gradient stream's kernels.
+struct TwoHeights { int cA = 0, cB = 0, row_split = 0; };
+int g_two_heights = -1;
+bool two_heights_enabled() {
+    if (g_two_heights < 0) { const char* e = getenv("DIC_GEMM_TWO_HEIGHTS"); g_two_heights = (e && e[0] == '1') ? 1 : 0; }
+    return g_two_heights == 1;
+}
+TwoHeights plan_two_heights(int M, int nbn, int slots, int K, int rows_single, bool ignore_switch = false) {
+    TwoHeights best;
+    if ((!ignore_switch && !two_heights_enabled()) || !rows_enabled() || nbn > slots) return best;
+    double fixed = 2.0 * 768.0 / (K > 0 ? K : 768);
+    fixed = fixed < 0.25 ? 0.25 : (fixed > 3.0 ? 3.0 : fixed);
+    const int c1 = rows_single / 32;
+    const long long units1 = ((long long)M + rows_single - 1) / rows_single * nbn;
+    if (units1 <= slots) return best;                                   // a single round: nothing to balance
+    double best_cost = 0.97 * (double)((units1 + slots - 1) / slots) * (c1 + fixed);
+    const int per_round = slots / nbn;                                  // row tiles one round can hold
+    for (int cA = 7; cA <= 8; ++cA)
+        for (int R = 1; R <= 64; ++R) {
+            const long long nA = (long long)R * slots / nbn;
+            const long long rowsA = nA * 32 * cA;
+            if (nA < 1) continue;
+            if (rowsA >= M) break;
+            const long long Mr = M - rowsA;
+            int cB = (int)((Mr + 32ll * per_round - 1) / (32ll * per_round));
+            if (cB > 7) continue;                                       // the rest does not fit one round of shorter tiles
+            if (cB < 4) cB = 4;
+            const double cost = R * (cA + fixed) + (cB + fixed);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best.cA = cA; best.cB = cB; best.row_split = (int)rowsA; }
+        }
+    return best;
+}
+template <class C, bool BKM, int E, int CA, int CB>
+void launch_bf16_two(const DicGemmParams& q, hipStream_t st, int grid, int row_split) {
+    using G = Geo<C>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel2<C, BKM, E, CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        attr_set[dev] = true;
+    }
+    launch_timed(gemm_bf16_kernel2<C, BKM, E, CA, CB>, dim3(grid), dim3(G::NTH), (unsigned)G::LDS, st, q, row_split);
+}
+
 template <class C, bool AKM, bool BKM, int E>
 void launch_bf16(const DicGemmParams& q, hipStream_t st) {
     using G = Geo<C>;
@@ -1535,6 +1602,18 @@ void launch_bf16(const DicGemmParams& q, hipStream_t st) {
     const int rows = AKM ? G::BM : pick_tile_rows(q.M, nbn_split, resident, G::BM, q.K);
     const int units = nbn_split * ((q.M + rows - 1) / rows);
     const int grid = ((persist_enabled() || q.cu_cap > 0) && units > resident) ? resident : units;
+#ifndef DIC_GEMM_MIN
+    if constexpr (std::is_same_v<C, T256> && !AKM && !BKM && (E == DIC_EPI_AFFINE || E == DIC_EPI_BIAS_GELU)) {
+        if (q.split_k <= 1 && persist_enabled() && gemm_variant() == 0) {
+            const TwoHeights th = plan_two_heights(q.M, nbn_split, resident, q.K, rows);
+            if (th.cA) {
+#define DIC_TWO(A_, B_) if (th.cA == A_ && th.cB == B_) { launch_bf16_two<C, BKM, E, A_, B_>(q, st, resident, th.row_split); return; }
+                DIC_TWO(7, 4) DIC_TWO(7, 5) DIC_TWO(7, 6) DIC_TWO(7, 7) DIC_TWO(8, 4) DIC_TWO(8, 5) DIC_TWO(8, 6) DIC_TWO(8, 7)
+#undef DIC_TWO
+            }
+        }
+    }
+#endif
     if constexpr (AKM) {
         launch_bf16_cnt<C, AKM, BKM, E, G::FM>(q, st, grid);
     } else if constexpr (G::FM == 8) {
@@ -1703,6 +1782,23 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
 
 // measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry, 0 = the lock-step loop (default)
 extern "C" int dic_gemm_set_variant(int v) { g_pp = (v == 1 || v == 2) ? v : 0; return 0; }
+// process-global measurement / test switch: 1 = launches may use two tile heights (default), 0 = one height per launch.  Returns the previous value.
+extern "C" int dic_gemm_set_two_heights(int on) {
+    const int prev = two_heights_enabled() ? 1 : 0;
+    g_two_heights = on ? 1 : 0;
+    return prev;
+}
+
+// host-only query: what dic_gemm would do with a forward (k-contiguous) bf16 problem of the 256-column geometry on this device --
+// out[0] = fragments per wave of the tall tiles (0: one height), out[1] = of the last round's tiles, out[2] = rows covered by the tall tiles
+extern "C" int dic_gemm_two_heights_plan(int M, int N, int K, int cu_cap, int* out) {
+    int cus = device_cus();
+    if (cu_cap > 0 && cu_cap < cus) cus = cu_cap;
+    const int nbn = (N + Geo<T256>::BN - 1) / Geo<T256>::BN;
+    const TwoHeights th = plan_two_heights(M, nbn, cus, K, pick_tile_rows(M, nbn, cus, Geo<T256>::BM, K), true);     // (whatever the switch says)
+    out[0] = th.cA; out[1] = th.cB; out[2] = th.row_split;
+    return 0;
+}
 
 // ---- optional per-launch timing (bench.py roofline leg), see launch_timed above
 namespace {

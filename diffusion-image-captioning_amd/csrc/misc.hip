@@ -8,7 +8,7 @@
 static thread_local char g_err[256] = "";
 extern "C" void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* dic_last_error(void) { return g_err; }
-extern "C" int dic_version(void) { return 12; }
+extern "C" int dic_version(void) { return 13; }
 
 // ---- step context (see common.h): process-global, set by the code that captures a training step into a hipGraph --------------------
 static DicStepCtx g_step_ctx = {nullptr, 0, 0, nullptr};

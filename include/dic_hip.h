@@ -115,6 +115,15 @@ size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
  * 256-column geometry runs.  0 (default) = the lock-step loop, 1 (env DIC_GEMM_PP=1) = the ping-pong loop of csrc/gemm_pp.h.  Results are
  * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
 int dic_gemm_set_variant(int pp);
+/* Measurement / test switch (PROCESS-GLOBAL): 1 (default 0; env DIC_GEMM_TWO_HEIGHTS=1 turns it on everywhere) lets a forward GEMM of the 256-column
+ * geometry run whole rounds of tall tiles followed by ONE round of shorter tiles over the remaining rows, when its units would otherwise end
+ * in a partly filled round of the persistent grid; 0 = one tile height per launch.  Results are identical (a tile's arithmetic does not
+ * depend on its height).  Returns the previous setting.  Pays on single-stream forward passes (the sampling loop turns it on), costs on the
+ * two-stream training step, where another stream's kernels use the CUs a partial round leaves idle.                                 */
+int dic_gemm_set_two_heights(int on);
+/* host-only: the plan for an M x N x K forward problem on this device -- out[0] / out[1] = 16-row fragments per wave of the tall / the
+ * last-round tiles (out[0] == 0: one height), out[2] = rows covered by the tall tiles */
+int dic_gemm_two_heights_plan(int M, int N, int K, int cu_cap, int* out3);
 
 /* hipGraph support for the training step (PROCESS-GLOBAL state: one capture at a time).  Kernel arguments are frozen by a capture, but the
  * dropout / noise / timestep seeds, AdamW's bias corrections and the slot the step's losses go to change every step.  While a context is set,

@@ -279,6 +279,42 @@ def test_gemm_gelu_epilogues_and_dropout(L, dtype):
     assert relerr(C1[kept], full[kept] / 0.75) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(17408, 2304, 768, 0), (17408, 3072, 768, 1), (34816, 768, 768, 0), (34816, 3072, 768, 1), (29920, 768, 3072, 0),
+                                       (38080, 768, 768, 0), (20000, 1024, 192, 0)])
+def test_gemm_two_tile_heights_in_one_launch(L, M, N, K, epi):
+    """A forward GEMM whose units would end in a partly filled round of the persistent grid runs whole rounds of tall tiles + one round of
+    shorter tiles (gemm_bf16_kernel2): bit-identical to the one-height launch -- output, GELU pre-activation, and the dropout mask, which is
+    keyed by the global row -- and equal to torch on the plain product.  The bench / sampling shapes must actually take the two-height path."""
+    plan = (C.c_int * 3)()
+    ok(L.dic_gemm_two_heights_plan(M, N, K, 0, plan), L)
+    if (M, N, K) in ((17408, 2304, 768), (17408, 3072, 768), (34816, 768, 768), (34816, 3072, 768)):
+        assert plan[0] in (7, 8) and 4 <= plan[1] <= 7 and 0 < plan[2] < M and plan[2] % (32 * plan[0]) == 0, list(plan)
+    g = torch.Generator().manual_seed(M + N)
+    A = dev(torch.randn(M, K, generator=g), DT[BF16]); B = dev(torch.randn(N, K, generator=g) * 0.05, DT[BF16])
+    bias = dev(torch.randn(N, generator=g))
+    R = dev(torch.randn(M, N, generator=g), DT[BF16]) if epi == 0 else None
+    outs = []
+    for on in (0, 1):
+        prev = L.dic_gemm_set_two_heights(on)
+        Cc = torch.full((M, N), float("nan"), dtype=DT[BF16], device="cuda")
+        U = torch.full((M, N), float("nan"), dtype=DT[BF16], device="cuda") if epi == 1 else None
+        kw = dict(A=p(A), B=p(B), C=p(Cc), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(bias), tile=256)
+        if epi == 0:
+            kw.update(R=p(R), ldr=N, p_drop=0.1, seed=77)
+        else:
+            kw.update(aux=p(U), ldaux=N)
+        gemm(L, BF16, 0, 0, epi, **kw)
+        outs.append((Cc, U))
+        L.dic_gemm_set_two_heights(prev)
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epi == 1:
+        assert torch.equal(outs[0][1], outs[1][1])
+        ref = A[:4096].float() @ B.float().t() + bias
+        assert relerr(outs[1][1][:4096].float(), ref) < 1e-2
+        tail = A[-2048:].float() @ B.float().t() + bias
+        assert relerr(outs[1][1][-2048:].float(), tail) < 1e-2
+
+
 # ------------------------------------------------------------------------------------------------ rounding head
 @pytest.mark.parametrize("dtype,V,tile", [(F32, 30522, 128), (BF16, 30522, 128), (F32, 1000, 128), (BF16, 30522, 256), (BF16, 1000, 256)])
 def test_rounding_ce_partial_combine_and_backward(L, dtype, V, tile):

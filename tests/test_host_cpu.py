@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(dic._lib.EXPORTS) == declared
-    assert L.dic_version() >= 12
+    assert L.dic_version() >= 13
 
 
 def test_gemm_params_ctypes_mirror_matches_the_header_struct():
