@@ -22,7 +22,8 @@ from .config import LOSS_KINDS, cfg
 from .params import ParamStore
 
 LN_EPS = 1e-12
-NPART = 512          # persistent blocks (= partial rows) of the LayerNorm backward kernels (2 per CU)
+import os as _os0
+NPART = int(_os0.environ.get("DIC_LN_NPART", "512"))          # persistent blocks (= partial rows) of the LayerNorm backward kernels (2 per CU; A/B switch)
 
 
 def _p(t):
