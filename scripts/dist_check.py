@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dic = importlib.import_module("diffusion-image-captioning_amd")
 dtype = os.environ.get("DTYPE", "fp32")
 NL, B, S, L, V = int(os.environ.get("LAYERS", "4")), 8, 2, 16, 1000
+CFG_W = float(os.environ.get("CFG", "0"))          # > 0: classifier-free guidance with injected draws (rows 0/1 of the GLOBAL batch are the forced ones)
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -19,7 +20,7 @@ E = dic.synth.vocab_embedding(V, 768, 0)
 
 
 def configure(b):
-    dic.cfg.update(BATCH_SIZE=b, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=V, CLASSIFIER_FREE_WEIGHT=0.0,
+    dic.cfg.update(BATCH_SIZE=b, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=V, CLASSIFIER_FREE_WEIGHT=CFG_W, CLASSIFIER_FREE_PROB=0.2,
                    CLIP_ADDING_METHOD="concat", LOSS_FUNC="series_sum_sample_mean", X_0_PREDICTION=True, ROUNDING_WEIGHT=0.5)
 
 
@@ -30,12 +31,17 @@ def build():
 full = {k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, V, seed=1).items()}
 t = torch.from_numpy(dic.synth.timesteps(S, 100, 3))
 noise = [torch.from_numpy(dic.synth.noise((B, L, 768), 5, f"eps{i}")).to(dev) for i in range(2)]
+u_full = None
+if CFG_W > 0:                # one uniform per (sample copy, caption): rows alternate unguided / guided, as tests/test_host_cpu.py does
+    u_full = torch.from_numpy(dic.synth.uniform(dic.synth.stream_id("cfg", 9), (S * B, 1))).clone()
+    u_full[0::2] = 0.05 + 0.1 * u_full[0::2]
+    u_full[1::2] = 0.3 + 0.6 * u_full[1::2]
 
 # 1. single process, full batch
 configure(B)
 m0 = build()
 tr0 = dic.AdamW(m0.parameters(), lr=1e-4)
-l0 = float(dic.train_func(m0, tr0, full, t=t, noises=noise)[0])
+l0 = float(dic.train_func(m0, tr0, full, t=t, noises=noise, cfg_uniform=u_full)[0])
 g0 = m0.params.G.clone()
 del m0, tr0
 
@@ -48,7 +54,11 @@ dic.parallel.configure_model_for_rank(m)
 tr = dic.AdamW(m.parameters(), lr=1e-4)
 mine = dic.parallel.shard(full)
 nz = [n[rank * (B // world):(rank + 1) * (B // world)].contiguous() for n in noise]
-l1 = dic.train_func(m, tr, mine, t=t, noises=nz)[0]
+u_mine = None
+if u_full is not None:       # the stacked x_t rows are s-major: row s*B + b  ->  this rank's captions b in [rank*Bl, (rank+1)*Bl) of every copy s
+    Bl = B // world
+    u_mine = u_full.reshape(S, B, 1)[:, rank * Bl:(rank + 1) * Bl].reshape(S * Bl, 1).contiguous()
+l1 = dic.train_func(m, tr, mine, t=t, noises=nz, cfg_uniform=u_mine)[0]
 ls = torch.tensor([float(l1)], dtype=torch.float64)
 torch.distributed.all_reduce(ls)
 l_dp = float(ls) / world
@@ -58,7 +68,7 @@ err_l = abs(l_dp - l0) / abs(l0)
 err_g = float((g - g0).abs().max() / g0.abs().max())
 red = dic.parallel.GradReducer.last
 ncoll = red.n_collectives if red is not None else -1
-dic.train_func(m, tr, mine, t=t, noises=nz)           # second step: the optimizer state took the exchanged gradients on every rank
+dic.train_func(m, tr, mine, t=t, noises=nz, cfg_uniform=u_mine)           # second step: the optimizer state took the exchanged gradients on every rank
 torch.cuda.synchronize()
 chk = torch.tensor([float(m.params.P.double().sum()), float(m.params.P.double().abs().sum())], dtype=torch.float64)
 allc = [torch.zeros_like(chk) for _ in range(world)]
@@ -67,7 +77,7 @@ same = all(torch.equal(allc[0], c) for c in allc)
 single = os.environ.get("DIC_DP_SINGLE", "0") == "1"
 want_coll = 1 if single else None
 ok = err_l < tol_l and err_g < tol_g and same and (want_coll is None or ncoll == want_coll) and ncoll >= 1
-print(f"rank {rank}/{world} {dtype} layers={NL} collectives/step={ncoll} loss full {l0:.6f} dp-mean {l_dp:.6f} (rel {err_l:.1e})  "
+print(f"rank {rank}/{world} {dtype} layers={NL} cfg={CFG_W} collectives/step={ncoll} loss full {l0:.6f} dp-mean {l_dp:.6f} (rel {err_l:.1e})  "
       f"grad max-rel err {err_g:.1e}  params identical across ranks: {same}  -> {'OK' if ok else 'FAILED'}", flush=True)
 torch.distributed.barrier()
 sys.exit(0 if ok else 1)

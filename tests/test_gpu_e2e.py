@@ -729,19 +729,21 @@ def test_optional_timestep_embedding_end_to_end_fp32():
         dic.cfg.update(TIMESTEP_EMBEDDING=False)
 
 
-@pytest.mark.parametrize("world,dtype,layers,single", [(2, "fp32", 4, "0"), (2, "bf16", 4, "1"), (4, "bf16", 12, "0")])
-def test_data_parallel_step_of_the_real_engine_on_ranks_sharing_one_gpu(world, dtype, layers, single):
+@pytest.mark.parametrize("world,dtype,layers,single,cfg_w", [(2, "fp32", 4, "0", "0"), (2, "bf16", 4, "1", "0"), (4, "bf16", 12, "0", "0"),
+                                                             (4, "bf16", 4, "0", "0.3"), (2, "fp32", 4, "0", "0.3")])
+def test_data_parallel_step_of_the_real_engine_on_ranks_sharing_one_gpu(world, dtype, layers, single, cfg_w):
     """SURVEY section 8e with the HIP engine instead of the oracle: `world` processes (gloo; RCCL refuses two ranks on one device) take
     the step on their shards through parallel.GradReducer -- slices issued from the backward + streamed AdamW, or the one-collective exchange --
     and must reproduce the single-process full-batch loss and gradient; after a second step every rank holds bit-identical parameters
-    (scripts/dist_check.py does the comparisons and exits non-zero on a mismatch)."""
+    (scripts/dist_check.py does the comparisons and exits non-zero on a mismatch).  cfg_w > 0: with classifier-free guidance (injected
+    draws; the forced rows 0/1 of the global batch live on rank 0)."""
     import socket
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
-    env = dict(os.environ, DIC_DIST_SHARE_GPU="1", DIC_DIST_BACKEND="gloo", DTYPE=dtype, LAYERS=str(layers), DIC_DP_SINGLE=single,
+    env = dict(os.environ, DIC_DIST_SHARE_GPU="1", DIC_DIST_BACKEND="gloo", DTYPE=dtype, LAYERS=str(layers), DIC_DP_SINGLE=single, CFG=cfg_w,
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
