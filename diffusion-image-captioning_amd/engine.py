@@ -69,6 +69,7 @@ _TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "au
 _WGRAD_CU_CAP = int(_os.environ.get("DIC_WGRAD_CU_CAP", "0"))   # >0: weight-gradient GEMMs keep to this many CUs (A/B switch)
 _WGRAD_TILE = _os.environ.get("DIC_WGRAD_TILE", "auto")    # tile of the weight-gradient GEMMs (A/B switch)
 _V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the register-staged v1 kernel (128-tiles only)
+_WGRAD_MAX_SPLIT = int(_os.environ.get("DIC_WGRAD_MAX_SPLIT", "32"))     # cap of the weight-gradient GEMMs' split-K factor (A/B switch)
 _GELU_FWD_TILE = _os.environ.get("DIC_GELU_FWD_TILE", "256")   # tile of the bias+GELU forward GEMM (A/B switch)
 _GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GELU' input-gradient GEMM (A/B switch; 128 measured faster in rounds 2 and 3)
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
@@ -101,7 +102,7 @@ def pick_split_k(M, N, K, bk=64, max_split=32):
         big = _WGRAD_TILE == "256" and M % 256 == 0 and N >= 256
     tile, resident = (256, N_CU) if big else (128, 2 * N_CU)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
-    return max(1, min(max_split, resident // max(tiles, 1), nk // 8)), tile
+    return max(1, min(max_split, _WGRAD_MAX_SPLIT, resident // max(tiles, 1), nk // 8)), tile
 
 
 class Denoiser:
