@@ -173,7 +173,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=16)
     ap.add_argument("--cfg-weight", type=float, default=0.0, help="classifier-free guidance weight (configs[4]: 0.3 with --seq-len 32)")
     ap.add_argument("--passes", type=int, default=100, help="denoising passes of --mode sample")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16w", "fp32"],
+                    help="bf16w: bf16 activations with hi+lo bf16 weights in the forward GEMMs (the fast mode inside the 1e-4 loss tolerance)")
+    ap.add_argument("--sustained", type=int, default=500, help="steps of the extra sustained leg of the default line (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline + roofline only (no CPU legs, no sampling / seq32 / dtype-delta extras)")
@@ -274,6 +276,18 @@ def main():
                    "allreduce_note": "sum over the step's collectives of issue -> completion on the compute stream, rank 0 (they overlap the backward)",
                    "gradient_bytes": int(model.params.numel) * 4, "per_rank_captions_per_s": [round(float(v), 1) for v in allr]}
 
+    # ---- sustained leg: the same step for --sustained more steps (the 20-step headline is 0.3 s of GPU time; this one says what a run holds)
+    sustained = None
+    if world == 1 and rank == 0 and args.sustained > 0 and not args.quick:
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(args.sustained):
+            step()
+        torch.cuda.synchronize()
+        ds = time.perf_counter() - c0
+        sustained = {"steps": args.sustained, "value": round(B * args.sustained / ds, 1), "unit": "captions/s", "ms_per_step": round(ds / args.sustained * 1e3, 3),
+                     "seconds": round(ds, 2)}
+
     # ---- roofline leg: the same K steps again with every GEMM launch bracketed by hipEvents on its stream
     roof = None
     if not args.no_roofline:
@@ -286,15 +300,17 @@ def main():
         ms, fl, n = C.c_double(), C.c_double(), C.c_int()
         Lh.dic_prof_end(C.byref(ms), C.byref(fl), C.byref(n))
         model.wgrad_stream_enabled = True
-        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        peak = 2500.0 if args.dtype != "fp32" else 157.3
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         traffic, traffic_src = (None, "PMC traffic is collected for the default workload only")
         if (B, S, L, args.layers, args.dtype, w) == (512, 1, 16, 12, "bf16", 0.0):
             traffic, traffic_src = pmc_traffic()
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)" if args.dtype == "bf16" else "gemm_kernel<float>", "achieved": round(ach, 2),
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)" if args.dtype != "fp32" else "gemm_kernel<float>", "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_src,
                 "launches_per_step": n.value // max(args.steps, 1), "gemm_ms_per_step": round(ms.value / args.steps, 3),
                 "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
+        if args.dtype == "bf16w":
+            roof["note"] = "executed flops: the forward Linears run their K loop twice (hi + lo weight halves); algorithmic flops per step are those of the bf16 line"
         if args.dtype == "bf16" and w == 0.0:
             if model.ce_fused:
                 roof["logits_recompute"] = "none: the training forward of the rounding loss keeps exp(logit - c) (dic_gemm CE_EXP), every GEMM flop counted is algorithmic"
@@ -326,8 +342,35 @@ def main():
                 del m2
                 torch.cuda.empty_cache()
         dtype_delta = {k: round(abs(a - b) / abs(b), 8) for k, a, b in zip(("total", "x_t", "x_1", "prob"), vals["bf16"], vals["fp32"])}
-        dtype_delta["note"] = ("bf16 activations drift ~1.2e-2 rms from the fp32 encoder over 12 layers; the streaming CE kernel itself is exact to 3e-8 "
-                               "(profiles/r03_ce_gap_probe.txt); the fp32 engine is the parity mode (losses within 1e-4 of the reference)")
+        dtype_delta["note"] = ("what separates the bf16 engine from fp32 is the bf16 rounding of the WEIGHTS: one perturbation shared by every sample, whose first-order "
+                               "effect a batch-mean loss does not average out; with bf16-representable weights the two engines agree to < 5e-5 "
+                               "(profiles/r04_weight_rounding_probe.txt).  parity_fast_mode (hi+lo weights in the forward GEMMs) removes it")
+        fp32_eval_losses = vals["fp32"]
+    parity_fast = None
+    if extras and args.dtype == "bf16":
+        # THE FAST MODE INSIDE north_star's 1e-4: bf16 activations and backward, hi+lo bf16 weights in the forward Linears (dtype "bf16w")
+        mw = dic.DistilBertModel(E, E, config=dict(n_layers=args.layers, dropout=0.1, attention_dropout=0.1), dtype="bf16w", device=dev, seed=0)
+        mw.load_state_dict(state)
+        mw.eval()
+        with torch.no_grad():
+            rw = [float(v) for v in dic.train_func(mw, None, x, train=False, t=from_t, noises=nz, cfg_uniform=u)]
+        mw.train()
+        trw = dic.AdamW(mw.parameters(), lr=1e-4)
+        for _ in range(3):
+            dic.train_func(mw, trw, x)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        nw = 20
+        for _ in range(nw):
+            ow = dic.train_func(mw, trw, x)
+        torch.cuda.synchronize()
+        dw = (time.perf_counter() - c0) / nw
+        parity_fast = {"dtype": "bf16w: bf16 activations / gradients, hi+lo bf16 weight halves in the forward GEMMs (two K-loop passes), fp32 master weights and optimizer",
+                       "value": round(B / dw, 1), "unit": "captions/s", "ms_per_step": round(dw * 1e3, 3), "steps": nw, "loss": round(float(ow[0]), 4),
+                       "loss_rel_vs_fp32": {k: round(abs(a - b) / abs(b), 8) for k, a, b in zip(("total", "x_t", "x_1", "prob"), rw, fp32_eval_losses)},
+                       "tolerance": 1e-4}
+        del mw, trw
+        torch.cuda.empty_cache()
     fp32_mode = None
     if extras and args.dtype == "bf16":
         # the parity dtype's throughput on the same workload (fp32 MFMA peak is 1/16 of bf16's): a few steps are enough
@@ -346,6 +389,8 @@ def main():
                      "algorithmic_tflop_per_s": round(B / d32 * gflop_per_seq(L, args.layers) * (S + 1) / 1e3, 2), "mfma_f32_peak_tflops": 157.3}
         del m32, tr32
         torch.cuda.empty_cache()
+        if parity_fast is not None:
+            parity_fast["x_fp32_mode"] = round(parity_fast["value"] / fp32_mode["value"], 2)
     del trainer, model
     torch.cuda.empty_cache()
     if extras:
@@ -392,7 +437,8 @@ def main():
                        "parallelism": f"dp{world}", "loss": round(loss_val, 4), "launch": graph_note,
                        "algorithmic_tflop_per_s": round(value * gf / 1e3, 2),
                        "executed_tflop_per_s": round(value * gflop_per_seq(L, args.layers, L + 1 if w <= 0 else L + 2) * (S + 1) / 1e3, 2)},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, "bf16_vs_fp32_loss_rel": dtype_delta, "fp32_mode": fp32_mode,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, "sustained": sustained, "bf16_vs_fp32_loss_rel": dtype_delta,
+            "parity_fast_mode": parity_fast, "fp32_mode": fp32_mode,
             "sampling": sampling, "seq32_cfg": seq32, "data_parallel": dp_info,
         }
         print(json.dumps(line))

@@ -22,7 +22,7 @@ EXPORTS = [
     "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
-    "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_cast_bf16", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
+    "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
     "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep", "dic_step_ctx_set", "dic_step_advance",
@@ -42,6 +42,7 @@ class GemmParams(C.Structure):
         ("tgt", C.c_void_p), ("lse", C.c_void_p), ("partial", C.c_void_p), ("tgt_logit", C.c_void_p),
         ("ce_rows_a", C.c_int), ("ce_scale_a", C.c_float), ("ce_scale_b", C.c_float),
         ("split_k", C.c_int), ("split_ws", C.c_void_p), ("tile", C.c_int), ("cu_cap", C.c_int), ("colsum_out", C.c_void_p),
+        ("B2", C.c_void_p),                                          # low-order half of a split weight (bf16 forward GEMMs) or NULL
         ("step_ctr", C.c_void_p), ("step_ctr0", C.c_int64),          # reserved (filled by dic_gemm from the step context)
     ]
 
@@ -52,12 +53,20 @@ class WgradItem(C.Structure):
                 ("M", C.c_int), ("N", C.c_int)]
 
 
-def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into one shared library, in-tree (it travels with the snapshot)."""
+LAST_BUILD = None        # "compiled" | "reused": what the last build() call did (printed by __graft_entry__.build)
+
+
+def build(verbose: bool = False, force: bool = False, variants: bool = False) -> str:
+    """Compile every HIP source for gfx950 into one shared library, in-tree (it travels with the snapshot).
+    force: compile even when the library is newer than every source (the driver's "does it build" check must compile, not trust mtimes).
+    variants: -DDIC_GEMM_VARIANTS, the measurement build that also carries the round-3 K-loop alternatives (gemm_pp.h, gemm_w4.h)."""
+    global LAST_BUILD
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_pp.h"), os.path.join(CSRC, "gemm_w4.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
+    if not force and not variants and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        LAST_BUILD = "reused"
         return LIB_PATH
+    LAST_BUILD = "compiled"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -65,6 +74,8 @@ def build(verbose: bool = False) -> str:
         o = s[:-4] + ".o"
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+        if variants:
+            cmd.insert(3, "-DDIC_GEMM_VARIANTS")
         if s.endswith("misc.hip"):
             # q_sample must round a*x, eps*b and their sum separately to be bit-exact with the reference (ref :360-362);
             # everything in misc.hip is HBM-bound, so no FMA contraction in this file costs nothing
@@ -141,6 +152,8 @@ def lib():
         L.dic_colsum.argtypes = [I, P, I, I, I, P, I, P, P]
         L.dic_adamw.argtypes = [P, P, P, P, P, I64, F, F, F, F, F, F, F, F, P]
         L.dic_cast_bf16.argtypes = [P, P, I64, P]
+        L.dic_adamw_hl.argtypes = [P, P, P, P, P, P, I64, F, F, F, F, F, F, F, F, P]
+        L.dic_cast_bf16_hl.argtypes = [P, P, P, I64, P]
         L.dic_probe_tr16.argtypes = [P, P, P]
         L.dic_gemm_set_variant.argtypes = [I]
         L.dic_prof_begin.argtypes = [I]

@@ -953,6 +953,15 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     // overlapping (measured: 1.58 us per K-step = 1.21 us of LDS reads + MFMA plus most of the 0.90 us DMA).  Hidden from the
     // pass, the DMA is ordered by the explicit `s_waitcnt vmcnt(0)` + `s_barrier` that publishes a stage (dma_barrier below).
     i32x4 rsA, rsB;                                   // buffer resource words: base, base_hi (stride 0), num_records, flags
+    // SPLIT WEIGHTS (p.B2, forward Linears only): C = A (B + B2)^T with B2 = bf16(W - bf16(W)), the low-order half of an fp32 weight whose
+    // bf16 rounding is B.  The K loop simply runs twice over the tile's K range -- pass 1 against B, pass 2 against B2, same A -- into the
+    // same accumulators: at the pass boundary the DMA cursors rewind and B's descriptor is swapped, nothing else changes.  Why it exists:
+    // the bf16 rounding of the WEIGHTS is one fixed perturbation shared by every sample, so its first-order effect on a batch-mean loss does
+    // not average out (2.6e-4 relative at the bench shape), while activation roundings are independent per element and do (< 4e-5;
+    // profiles/r04_weight_rounding_probe.txt).  With hi + lo the weights carry 16 mantissa bits and the bf16 engine's losses sit within
+    // north_star's 1e-4 of the fp32 engine's at twice the forward-GEMM K loop.
+    constexpr bool TWO_PASS = !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU);
+    i32x4 rsB2 = {0, 0, 0, 0};
     auto make_rsrc = [](const void* base, long long bytes) {
         const unsigned long long b = (unsigned long long)base;
         i32x4 r;
@@ -987,6 +996,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         if (b_bytes > 0xFFFFFFF0ll) b_bytes = 0xFFFFFFF0ll;
         rsA = make_rsrc(Ab, a_bytes);
         rsB = make_rsrc(Bb, b_bytes);
+        if constexpr (TWO_PASS) { if (p.B2) rsB2 = make_rsrc((const T*)p.B2 + (size_t)n0 * p.ldb, b_bytes); }
         const unsigned ka = (unsigned)tl.kt0 * stepA, kb = (unsigned)tl.kt0 * stepB;
 #pragma unroll
         for (int j = 0; j < G::PA; ++j) {
@@ -1258,14 +1268,26 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
             cs0 = f32x4{0.f, 0.f, 0.f, 0.f}; cs1 = cs0;
         }
         const int nk = tl.kt1;
+        // (split weights: a second pass over the same K range; K-step kt >= nk reads A's step kt - (nk - kt0) again, against B2)
+        const int kend = (TWO_PASS && p.B2) ? nk + (nk - tl.kt0) : nk;
         const TileId done = tl;
         const int slab_done = slab;
         DicGemmParams pe = p;                        // (grouped launches: group_unit() below re-points p at the next problem)
         bool next_set = false, next_k0 = false;      // next unit's addressing is set up / its first K-step is in flight or landed
         // (A software-pipelined variant -- barrier before the last MFMA group, first fragments of the next stage prefetched across it,
         // DMA re-armed 1.75 K-steps ahead -- was measured in round 1: +2-5 % on isolated GEMMs, -2 % on the training step; not kept.)
-        for (int kt = tl.kt0; kt < nk; ++kt) {       // ONE loop body (a hand-unrolled pair with an early exit made the
-            bool do_issue = kt + 1 < nk;               //  register allocator keep two copies of the accumulator tile); issues the next K-step's DMA
+        for (int kt = tl.kt0; kt < kend; ++kt) {     // ONE loop body (a hand-unrolled pair with an early exit made the
+            bool do_issue = kt + 1 < kend;             //  register allocator keep two copies of the accumulator tile); issues the next K-step's DMA
+            if constexpr (TWO_PASS) {
+                if (kt + 1 == nk && kend > nk) {       // the next DMA is pass 2's first K-step: rewind both cursors, B -> B2
+                    const unsigned backA = (unsigned)(nk - tl.kt0) * stepA, backB = (unsigned)(nk - tl.kt0) * stepB;
+#pragma unroll
+                    for (int j = 0; j < G::PA; ++j) voA[j] -= backA;
+#pragma unroll
+                    for (int j = 0; j < G::PB; ++j) voB[j] -= backB;
+                    rsB = rsB2;
+                }
+            }
             if (do_issue) { if (k1_issued && kt == tl.kt0) do_issue = false; }
             else if (XT && more_next) {
                 if constexpr (GROUP) tl_next = group_unit(unit + (int)gridDim.x);
@@ -1370,19 +1392,21 @@ __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmP
     gemm_bf16_body<T256, true, true, DIC_EPI_AFFINE, Geo<T256>::FM, true>(p, &grp);
 }
 
-#include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (measured alternative)
-
-// Which K loop the 256-column geometry runs: the lock-step one above, or the ping-pong one of gemm_pp.h with DIC_GEMM_PP=1 /
-// dic_gemm_set_variant(1).  Round 3 measured them equal within noise on the step's k-contiguous shapes and the ping-pong loop 10-20 %
-// slower with k-major operands (two ds_read_b64_tr_b16 per fragment in its load segments), so the lock-step loop stays the default.
+// The two K-loop alternatives measured in round 3 (ping-pong loop, four-wave 256 x 256 kernel: equal or slower) are
+// compiled only into measurement builds (-DDIC_GEMM_VARIANTS, scripts/gemm_pp_check.py): the shipped library carries ONE K loop.
+#ifdef DIC_GEMM_VARIANTS
+#include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (variant 1)
 int g_pp = -1;
 int gemm_variant() {
     if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
     return g_pp;
 }
-bool pp_enabled() { return gemm_variant() == 1; }
-
-#include "gemm_w4.h"          // gemm_w4_kernel: 256 x 256 tiles on four waves (variant 2, k-contiguous operands only; measured alternative)
+#include "gemm_w4.h"          // gemm_w4_kernel: 256 x 256 tiles on four waves (variant 2, k-contiguous operands only)
+#else
+int g_pp = 0;
+constexpr int gemm_variant() { return 0; }
+#endif
+inline bool pp_enabled() { return gemm_variant() == 1; }
 // Fold of a grouped launch: tile t = sum of its K-slices' slabs in slice order (deterministic).  Block = (tile, 16-row chunk); 256 threads x
 // (4 rows x 4 columns).  The bias gradient rides in each slab's tail.
 __global__ __launch_bounds__(256) void wgrad_group_fold_kernel(WgradGroupDev grp) {
@@ -1515,6 +1539,7 @@ void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
     static bool attr_set[2][64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
+#ifdef DIC_GEMM_VARIANTS
     if constexpr (std::is_same_v<C, T256> && !AKM && !BKM) {
         if (gemm_variant() == 2) {
             static bool attr_w4[64] = {};
@@ -1536,6 +1561,7 @@ void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
             return;
         }
     }
+#endif
     if (dev >= 0 && dev < 64 && !attr_set[0][dev]) {           // per device: one process may drive several GPUs
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AKM, BKM, E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr_set[0][dev] = true;
@@ -1765,14 +1791,20 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+#ifdef DIC_GEMM_VARIANTS
         (void)hipFuncSetAttribute((const void*)wgrad_group_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+#endif
         attr_set[dev] = true;
     }
     DicGemmParams q{};
     q.K = T; q.out_f32 = 1; q.split_k = 1; q.tile = 256;
     hipStream_t st = (hipStream_t)stream;
     tl_prof = prof_slot([&] { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * items[i].M * items[i].N * T; return f; }());
-    launch_timed(pp_enabled() ? wgrad_group_pp_kernel : wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
+#ifdef DIC_GEMM_VARIANTS
+    if (pp_enabled()) launch_timed(wgrad_group_pp_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
+    else
+#endif
+    launch_timed(wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
     const int tiles = pl.dev.tiles;
     launch_timed(wgrad_group_fold_kernel, dim3(tiles, G::BM / 16), dim3(256), 0u, st, pl.dev);
     tl_prof = nullptr;
@@ -1781,7 +1813,16 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
 }
 
 // measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry, 0 = the lock-step loop (default)
-extern "C" int dic_gemm_set_variant(int v) { g_pp = (v == 1 || v == 2) ? v : 0; return 0; }
+extern "C" int dic_gemm_set_variant(int v) {
+#ifdef DIC_GEMM_VARIANTS
+    g_pp = (v == 1 || v == 2) ? v : 0;
+    return 0;
+#else
+    if (v == 0) return 0;
+    dic_set_error("dic_gemm_set_variant: this library was built without -DDIC_GEMM_VARIANTS (the alternative K loops are measurement-build only)");
+    return 1006;
+#endif
+}
 // process-global measurement / test switch: 1 = launches may use two tile heights (default), 0 = one height per launch.  Returns the previous value.
 extern "C" int dic_gemm_set_two_heights(int on) {
     const int prev = two_heights_enabled() ? 1 : 0;
@@ -1842,7 +1883,7 @@ static ProfRec* prof_slot(double flops) {
 }
 static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream);
 extern "C" int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream) {
-    tl_prof = prof_slot(2.0 * pp->M * pp->N * pp->K);
+    tl_prof = prof_slot(2.0 * pp->M * pp->N * pp->K * (pp->B2 ? 2.0 : 1.0));          // (executed flops: a split-weight launch runs its K loop twice)
     const int rc = dic_gemm_impl(dtype, a_km, b_km, epi, pp, stream);
     tl_prof = nullptr;
     return rc;
@@ -1875,6 +1916,10 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (p.split_k > 1)
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
+    if (p.B2)
+        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && !b_km && (epi == DIC_EPI_AFFINE || epi == DIC_EPI_BIAS_GELU) && p.split_k <= 1 &&
+                    ((uintptr_t)p.B2 % 16) == 0 && gemm_variant() == 0,
+                    "dic_gemm: B2 (low-order weight half) is an option of the bf16 forward GEMMs (k-contiguous A and B, AFFINE / BIAS_GELU, no split-K)");
     if (epi == DIC_EPI_CE_EXP)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && p.C && p.lse && p.partial && p.tgt_logit && p.ldc % 8 == 0 && p.ldc >= p.N &&
                     p.ldc <= ((p.N + BN - 1) / BN) * BN && p.split_k <= 1,

@@ -641,7 +641,20 @@ extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int 
 // ------------------------------------------------------------------------------------------------ K15 AdamW
 // torch.optim.AdamW semantics (ref :335): p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  One pass over the flat buffers: 16 B/param read, 12(+2) B written.
-__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, uint16_t* shadow, long long n4, float lr, float b1,
+// (shadow_lo, optional: bf16(p - bf16(p)), the low-order half the split-weight forward GEMMs add back -- DicGemmParams.B2)
+__device__ __forceinline__ void store_bf16_hi_lo(uint16_t* hi, uint16_t* lo, long long i4, const f32x4& P) {
+    uint2 u;
+    u.x = pack2bf(P[0], P[1]);
+    u.y = pack2bf(P[2], P[3]);
+    *(uint2*)(hi + i4 * 4) = u;
+    if (lo) {
+        f32x4 H;                                                  // the rounded values, back in fp32
+        H[0] = __uint_as_float(u.x << 16); H[1] = __uint_as_float(u.x & 0xffff0000u);
+        H[2] = __uint_as_float(u.y << 16); H[3] = __uint_as_float(u.y & 0xffff0000u);
+        Elem<bf16_t>::st4(lo + i4 * 4, P - H);
+    }
+}
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, uint16_t* shadow, uint16_t* shadow_lo, long long n4, float lr, float b1,
                              float b2, float eps, float wd, float bc1, float rsqrt_bc2, float gscale, const float* table, const long long* ctr,
                              long long ctr0) {
     if (table && ctr) {          // replayed step: this step's bias corrections from the table the capture code filled (host arithmetic, bit for bit)
@@ -661,28 +674,34 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, uint1
             Mo[k] = mk; Vo[k] = vk;
         }
         ((f32x4*)p)[i] = P; ((f32x4*)m)[i] = Mo; ((f32x4*)v)[i] = Vo;
-        if (shadow) Elem<bf16_t>::st4(shadow + i * 4, P);
+        if (shadow) store_bf16_hi_lo(shadow, shadow_lo, i, P);
     }
 }
-extern "C" int dic_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, int64_t n, float lr, float beta1, float beta2,
-                         float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+extern "C" int dic_adamw_hl(float* p, const float* g, float* m, float* v, uint16_t* shadow, uint16_t* shadow_lo, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
     DIC_REQUIRE(n % 4 == 0 && n > 0, "dic_adamw: flat length must be a multiple of 4");
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, (long long)(n / 4),
+    DIC_REQUIRE(shadow != nullptr || shadow_lo == nullptr, "dic_adamw_hl: a low-order shadow needs the bf16 shadow it is the remainder of");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, shadow_lo, (long long)(n / 4),
                        lr, beta1, beta2, eps, weight_decay, bias_corr1, 1.0f / sqrtf(bias_corr2), grad_scale, dic_step_ctx().adam_table, dic_step_ctx().ctr,
                        dic_step_ctx().ctr0);
     DIC_CHECK_LAUNCH();
     return 0;
 }
-__global__ void cast_bf16_kernel(const float* in, uint16_t* out, long long n4) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
-        Elem<bf16_t>::st4(out + i * 4, ((const f32x4*)in)[i]);
+extern "C" int dic_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+    return dic_adamw_hl(p, g, m, v, shadow, nullptr, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale, stream);
 }
-extern "C" int dic_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {
+__global__ void cast_bf16_kernel(const float* in, uint16_t* out, uint16_t* out_lo, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        store_bf16_hi_lo(out, out_lo, i, ((const f32x4*)in)[i]);
+}
+extern "C" int dic_cast_bf16_hl(const float* in, uint16_t* out, uint16_t* out_lo, int64_t n, void* stream) {
     DIC_REQUIRE(n % 4 == 0 && n > 0, "dic_cast_bf16: length must be a multiple of 4");
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, in, out, (long long)(n / 4));
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, in, out, out_lo, (long long)(n / 4));
     DIC_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int dic_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream) { return dic_cast_bf16_hl(in, out, nullptr, n, stream); }
 
 // ------------------------------------------------------------------------------------------------ layout probe
 // out[lane*4+j] = element j returned to `lane` by ds_read_b64_tr_b16 when lane supplies address lds + lane*8 over

@@ -452,9 +452,10 @@ class AdamW:
         s = self.store
         st = torch.cuda.current_stream().cuda_stream
         sh = (_p(s.Pb) + 2 * lo) if s.Pb is not None else 0
-        _lib.check(_lib.lib().dic_adamw(_p(s.P) + 4 * lo, _p(s.G) + 4 * lo, _p(self.m) + 4 * lo, _p(self.v) + 4 * lo, sh, hi - lo,
-                                        float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
-                                        self.grad_scale, st), "adamw")
+        sl = (_p(s.Pl) + 2 * lo) if s.Pl is not None else 0          # split weights: the low-order bf16 half, refreshed in the same pass
+        _lib.check(_lib.lib().dic_adamw_hl(_p(s.P) + 4 * lo, _p(s.G) + 4 * lo, _p(self.m) + 4 * lo, _p(self.v) + 4 * lo, sh, sl, hi - lo,
+                                           float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                                           self.grad_scale, st), "adamw")
 
     # Streamed stepping (single-GPU training): the update of an encoder layer's slice is an HBM-bound pass that can run on the
     # weight-gradient stream as soon as that layer's gradients are final, under the MFMA-bound backward of the layers below it.
@@ -500,7 +501,7 @@ class AdamW:
 def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, cfg_uniform=None):
     """ref :458-486.  Returns (l, x_t_loss, x_1_loss, prob_loss) as 0-dim device tensors.  LIFETIME: they are views into a ring of
     LOSS_RING (4096) result slots per encoder workspace, written by the loss kernels themselves (no ATen kernel on the step): a value stays
-    valid for the next 4095 calls.  Accumulating (`acc += l`, what the reference's epoch loop does, ref :530-533) or reading them is always
+    valid for at least the next LOSS_RING // 2 calls (4095 unless a graph.GraphedTrainStep re-captures in between and restarts at the ring's head).  Accumulating (`acc += l`, what the reference's epoch loop does, ref :530-533) or reading them is always
     fine; a caller that keeps per-step tensors for longer than that must `.clone()` them."""
     from . import parallel
     dev = model.device

@@ -46,7 +46,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0, B2=0):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -54,7 +54,7 @@ class Ops:
         g.p_drop, g.seed, g.out_f32, g.accumulate = p_drop, seed, out_f32, accumulate
         g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
         g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
-        g.split_k, g.split_ws, g.colsum_out = split_k, split_ws, colsum_out
+        g.split_k, g.split_ws, g.colsum_out, g.B2 = split_k, split_ws, colsum_out, B2
         dt = self.dt if dtype is None else dtype
         if tile is None:
             tile = choose_tile(M, N, split_k, epi) if (dt == DIC_BF16 and epi != EPI_CE_PARTIAL and (not a_km or M % 256 == 0)) else 128
@@ -113,7 +113,7 @@ class Denoiser:
     `n_layers`, `dropout`, `attention_dropout`.
     """
 
-    def __init__(self, embedding=None, projection=None, config=None, *, dtype="bf16", device="cuda:0", seed=0):
+    def __init__(self, embedding=None, projection=None, config=None, *, dtype="bf16", device="cuda:0", seed=0, split_weights=None):
         _lib.require_gpu()
         get = (lambda k, d: config.get(k, d)) if isinstance(config, dict) else (lambda k, d: getattr(config, k, d))
         self.n_layers = int(get("n_layers", 6)) if config is not None else 6
@@ -121,7 +121,14 @@ class Denoiser:
         self.p_attn = float(get("attention_dropout", 0.1)) if config is not None else 0.1
         self.n_heads, self.dim, self.hidden = 12, 768, 3072
         self.device = torch.device(device)
-        self.bf16 = dtype in ("bf16", torch.bfloat16)
+        self.bf16 = dtype in ("bf16", "bf16w", torch.bfloat16)
+        # SPLIT WEIGHTS (dtype="bf16w" / split_weights=True / DIC_SPLIT_W=1; bf16 engine only): the forward Linears multiply by hi + lo bf16 halves
+        # of the fp32 master weights (two passes of the GEMM's K loop, include/dic_hip.h DicGemmParams.B2) instead of by their bf16 rounding.
+        # This is the fast mode that meets north_star's 1e-4 loss tolerance: the weights' rounding error is the same for every sample and does
+        # not average out of a batch-mean loss, the activations' does (profiles/r04_weight_rounding_probe.txt).  The backward is unchanged.
+        if split_weights is None:
+            split_weights = dtype == "bf16w" or _os0.environ.get("DIC_SPLIT_W", "0") == "1"
+        self.split_w = bool(split_weights) and self.bf16
         self.dt = DIC_BF16 if self.bf16 else DIC_F32
         self.tdtype = torch.bfloat16 if self.bf16 else torch.float32
         self.es = 2 if self.bf16 else 4
@@ -139,7 +146,7 @@ class Denoiser:
                                       "timestep): the table would silently stay untrained")
         if self.temb:
             te_kw["timestep_embedding"] = int(cfg.STEP_TOT)
-        self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16, **te_kw)
+        self.params = ParamStore(self.n_layers, self.device, concat=self.concat, bf16_shadow=self.bf16, split_shadow=self.split_w, **te_kw)
         self.params.init_like_reference(seed)
         if self.te:
             assert cfg.IN_CHANNEL % 4 == 0 and cfg.IN_CHANNEL <= 32, "TRAIN_EMBEDDING: IN_CHANNEL must be a multiple of 4, at most 32"
@@ -195,7 +202,7 @@ class Denoiser:
         """bf16 copies of the parameters for the MFMA operands (dic_adamw keeps them fresh itself)."""
         if self.bf16:
             self.ops.begin()
-            _lib.check(self.ops.L.dic_cast_bf16(_p(self.params.P), _p(self.params.Pb), self.params.numel, self.ops.stream), "cast")
+            _lib.check(self.ops.L.dic_cast_bf16_hl(_p(self.params.P), _p(self.params.Pb), _p(self.params.Pl), self.params.numel, self.ops.stream), "cast")
 
     # ------------------------------------------------------------------ reference-shaped API
     def parameters(self):
@@ -271,8 +278,11 @@ class Denoiser:
     # ------------------------------------------------------------------ workspace
     @staticmethod
     def _evict(cache, keep):
-        while len(cache) > keep:
-            cache.pop(next(iter(cache)))
+        """Drop the oldest workspaces beyond `keep` -- never one a captured hipGraph points into (graph.GraphedTrainStep pins them)."""
+        for k in [k for k, w in cache.items() if not w.get("pinned")]:
+            if len(cache) <= keep:
+                break
+            cache.pop(k)
 
     def _workspace(self, N, L, drop_txt=False, cap=None):
         """Activations + backward scratch for a stacked batch of N sequences.  Buffers are sized for `cap` >= N sequences and cached by
@@ -361,6 +371,7 @@ class Denoiser:
         self._seed += 64
         seed = self._seed
         ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
+        lo = (lambda slot: P.ptr(slot, "Pl")) if self.split_w else (lambda slot: 0)       # low-order weight halves (split-weight mode)
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
         ws["has_u"] = keep_u
         if x_ptr is None:
@@ -395,20 +406,20 @@ class Denoiser:
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
             # K5: q|k|v projections as one GEMM
-            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=P.ptr(pre + "bqkv"))
+            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=P.ptr(pre + "bqkv"), B2=lo(pre + "Wqkv"))
             # K6: attention
             _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
             # K7: out-proj + bias + residual, then LayerNorm
-            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(h), ldr=D)
+            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(h), ldr=D, B2=lo(pre + "Wo"))
             _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             # K8: FFN
             o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU, bias=P.ptr(pre + "b1"),
-                   aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
+                   aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd, B2=lo(pre + "W1"))
             o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa"]), ldr=D,
-                   p_drop=ph, seed=seed + 4 * i + 2)
+                   p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"))
             _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
         # K9: MLM-head transform: Linear -> GELU -> LayerNorm
-        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"))
+        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"), B2=lo("Wvt"))
         _lib.check(lib.dic_gelu_ln_fwd(self.dt, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
         self._saved = ws
         return ws["x_out"][:N]

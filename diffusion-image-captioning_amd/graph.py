@@ -6,7 +6,11 @@ What a capture would freeze but a step must vary is read from device memory inst
 counter, bumped by the graph's first node, shifts every dropout / noise / timestep seed by exactly what the host adds between two eager
 steps, selects AdamW's bias corrections from a table of host-computed factors, and picks the result slot the step's losses are written
 to.  A graphed run is therefore BIT-IDENTICAL to the eager run with the same seeds (tests/test_gpu_e2e.py), and the host-side counters are
-advanced alongside, so eager and graphed steps can be mixed freely.
+advanced alongside.  Eager and graphed steps can be mixed in either order: every call compares the host counters (dropout / noise / timestep
+seeds, optimizer step, result slot) with what the last replay left behind, and anything that moved them in between -- an eager `train_func`,
+a `validate`, a restored checkpoint -- makes the call RE-CAPTURE from the current counters instead of replaying stale seeds.  The captured
+graph holds raw pointers into the encoder / rounding workspaces: both are pinned against the model's workspace eviction for as long as this
+object lives (`release()` unpins them).
 
 Scope: one GPU, fused `AdamW`, no classifier-free guidance (its stacked batch changes size every step), fixed batch shape.  The learning rate
 is a kernel argument: changing `param_groups[0]["lr"]` (per epoch in the reference, ref :520-522) re-captures.
@@ -44,8 +48,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self._capture()
 
-    # one replay may run HORIZON steps past the captured one: result slots and the AdamW table are sized for it
-    HORIZON = diffusion.LOSS_RING - 4
+    # one capture is replayed for at most HORIZON steps: result slots and the AdamW table are sized for it.  Half the ring, so that a
+    # capture can always continue from the current result slot or wrap to slot 0 without touching a slot younger than LOSS_RING / 2 calls
+    HORIZON = diffusion.LOSS_RING // 2 - 4
 
     def _capture(self):
         model, tr = self.model, self.trainer
@@ -65,8 +70,14 @@ class GraphedTrainStep:
         B, L_ = self.x["input_ids"].shape
         ws = model._workspace((cfg.SAMPLE_SIZE + 1) * B, L_, model.concat and cfg.DROP_UNUSED_TEXT_ROW)
         sc = ws["loss_sc"]
-        sc["slot"] = 0
+        if sc["slot"] + self.HORIZON + 3 >= diffusion.LOSS_RING:
+            sc["slot"] = 0                  # replays write slots slot0 .. slot0 + HORIZON without wrapping: restart at the ring's (oldest) head
         self.sc = sc
+        # the graph bakes in the addresses of these workspaces: keep them out of Denoiser._evict's reach
+        ws["pinned"] = True
+        cw = model._ce_workspace((cfg.SAMPLE_SIZE + 1) * B * L_)
+        cw["pinned"] = True
+        self._pinned = (ws, cw)
         self.stride_noise = (2 if cfg.X_0_PREDICTION else 3) * 0x9E3779B1          # diffusion._next_seed per q_sample call
         torch.cuda.synchronize()
         _lib.check(L.dic_step_ctx_set(self.ctr.data_ptr(), self.n + 1, self.stride_noise, self.table.data_ptr()), "step_ctx_set")
@@ -81,6 +92,17 @@ class GraphedTrainStep:
         self.slot0 = sc["slot"]
         self.k = 0                          # replays since this capture
         self.captures += 1
+        self._expect = self._host_state()   # (the capture advanced the host counters by one step: replay 1 IS that step)
+
+    def _host_state(self):
+        return (int(self.model._seed), int(diffusion._state["noise_seed"]), int(diffusion._state.get("t_seed", 0)), int(self.trainer.t),
+                int(self.sc["slot"]), bool(self.model.training))
+
+    def release(self):
+        """Unpin the workspaces (the graph must not be replayed afterwards)."""
+        for w in getattr(self, "_pinned", ()):
+            w.pop("pinned", None)
+        self.graph = None
 
     def _advance_host(self):
         """What one eager train_func call adds on the host, so that eager steps can follow graphed ones (and the checkpointed rng state is right)."""
@@ -95,7 +117,11 @@ class GraphedTrainStep:
             for k, v in x.items():
                 if torch.is_tensor(v):
                     self.x[k].copy_(v, non_blocking=True)
-        if self.k > self.HORIZON or float(self.trainer.param_groups[0]["lr"]) != self.lr:
+        if self.graph is None:
+            raise RuntimeError("GraphedTrainStep: called after release()")
+        # anything that moved the host counters since the last replay (an eager step, validate(), a restored checkpoint) consumed seeds /
+        # optimizer steps / result slots the device counter knows nothing about: re-capture from the counters as they are now
+        if self.k >= self.HORIZON or float(self.trainer.param_groups[0]["lr"]) != self.lr or self._host_state() != self._expect:
             self._capture()
         if self.k > 0:
             self._advance_host()
@@ -103,5 +129,6 @@ class GraphedTrainStep:
         self.k += 1
         self.n += 1
         self.replays += 1
+        self._expect = self._host_state()
         o = self.sc["ring"][self.slot0 + self.k - 1]
         return o[7], o[0], o[1], o[6]

@@ -2,7 +2,7 @@
 
 All trainable tensors of `DistilBertModel` (ref CLIP-DDPM.py:227-269; 108 tensors / 44.3 M elements at 6 layers)
 live in ONE contiguous fp32 buffer `P`, with gradients `G` and the AdamW moments `M`, `V` in three more buffers of
-the same layout, plus (bf16 mode) a bf16 shadow `Pb` that the GEMMs read.  Consequences:
+the same layout, plus (bf16 mode) a bf16 shadow `Pb` that the GEMMs read and (split-weight mode) its remainder `Pl = bf16(P - Pb)`.  Consequences:
   * AdamW is ONE kernel launch over the flat range (dic_adamw) and writes the shadow in the same pass;
   * the data-parallel gradient exchange is ONE RCCL all-reduce of `G` (SURVEY.md section 8e);
   * q/k/v projection weights are stored stacked ([2304][768]) so the three Linears run as one GEMM, and
@@ -24,7 +24,7 @@ ALIGN = 64  # floats (256 B)
 class ParamStore:
     def __init__(self, n_layers: int, device, concat: bool = True, dim: int = 768, hidden: int = 3072,
                  max_pos: int = 512, clip_dim: int = 512, bf16_shadow: bool = True, train_embedding_vocab: int | None = None,
-                 in_channel: int = 16, timestep_embedding: int | None = None):
+                 in_channel: int = 16, timestep_embedding: int | None = None, split_shadow: bool = False):
         self.n_layers, self.dim, self.hidden, self.concat = n_layers, dim, hidden, concat
         self.te_vocab, self.in_channel = train_embedding_vocab, in_channel
         self.device = torch.device(device)
@@ -66,6 +66,8 @@ class ParamStore:
         self.P = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.G = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if bf16_shadow else None
+        # split weights (engine.Denoiser(split_weights=True)): Pl = bf16(P - Pb), the half the forward GEMMs add back as DicGemmParams.B2
+        self.Pl = torch.zeros(off, dtype=torch.bfloat16, device=self.device) if (bf16_shadow and split_shadow) else None
 
         # reference-named views, in the order of CLIP-DDPM.py:258-269
         te = dict(train_embedding_vocab=train_embedding_vocab, in_channel=in_channel) if train_embedding_vocab is not None else {}
@@ -85,7 +87,7 @@ class ParamStore:
         return self._slots[slot][0]
 
     def ptr(self, slot, which="P"):
-        buf = {"P": self.P, "G": self.G, "Pb": self.Pb}[which]
+        buf = {"P": self.P, "G": self.G, "Pb": self.Pb, "Pl": self.Pl}[which]
         return buf.data_ptr() + self._slots[slot][0] * buf.element_size()
 
     def slot_view(self, buf, slot):

@@ -78,6 +78,10 @@ typedef struct DicGemmParams {
                                    to a kernel on another stream */
     float* colsum_out;          /* bf16 (k-major,k-major) fp32-output GEMMs only: out[m] = sum_k A(m,k) -- the bias gradient that
                                    goes with a weight gradient dW = dY^T X (hf nn.Linear backward), taken from the LDS-resident A tile */
+    const void* B2;             /* bf16 forward GEMMs (k-contiguous A and B, AFFINE / BIAS_GELU, no split-K) or NULL: the LOW-ORDER half of a
+                                   split fp32 weight, same shape / ldb as B: C = A (B + B2)^T, computed as two passes of the K loop into one
+                                   accumulator (B = bf16(W), B2 = bf16(W - B): 16 mantissa bits; dic_adamw_hl / dic_cast_bf16_hl produce the pair).
+                                   Replaces nn.Linear's fp32 weight in hf:183-185, 201, 221-223, 510 at bf16 MFMA rate x 1/2 */
     const int64_t* step_ctr;    /* RESERVED, leave 0: dic_gemm fills these two from the step context (dic_step_ctx_set) so that a launch */
     int64_t step_ctr0;          /* replayed inside a hipGraph shifts `seed` by 64 x (steps since capture), as the host does between eager steps */
 } DicGemmParams;
@@ -288,6 +292,11 @@ int dic_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, in
               float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
               void* stream);
 int dic_cast_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+/* Split-weight forms (DicGemmParams.B2): shadow_lo / out_lo (bf16, optional) additionally receives bf16(p - bf16(p)), so that
+ * shadow + shadow_lo carries 16 mantissa bits of the fp32 master weight the reference's nn.Linear multiplies by (hf:183-185, 201, 221-223, 510). */
+int dic_adamw_hl(float* p, const float* g, float* m, float* v, uint16_t* shadow, uint16_t* shadow_lo, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+int dic_cast_bf16_hl(const float* in, uint16_t* out, uint16_t* out_lo, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------- probe (layout self-test used by the GPU tests) */
 int dic_probe_tr16(const uint16_t* in, uint16_t* out, void* stream);

@@ -153,6 +153,48 @@ def test_gemm_tile256_all_layouts_and_epilogues(L, layout):
             assert relerr(Cs, acc) < 2e-6 and relerr(cs, Ad.float().cpu().double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("tile,M,N,K,epi", [(256, 600, 768, 768, 0), (256, 17408 // 8, 3072, 768, 1), (128, 300, 776, 64, 0), (256, 520, 768, 3072, 0)])
+def test_gemm_split_weight_second_pass(L, tile, M, N, K, epi):
+    """DicGemmParams.B2: C = A (B + B2)^T, the forward Linear against hi + lo bf16 halves of an fp32 weight (hf nn.Linear with its fp32 weight,
+    hf:183-185, 201, 221-223, 510), as two passes of the K loop.  Checked against float64 on the SAME operands (A bf16, W_hi + W_lo): the only
+    error left is the fp32 accumulation; and against the fp32 weight itself: 2^-16, where the single-pass bf16 product is 2^-8 away."""
+    g = torch.Generator().manual_seed(31 + K)
+    A = torch.randn(M, K, generator=g) * 0.5
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias, Rr = torch.randn(N, generator=g) * 0.1, torch.randn(M, N, generator=g)
+    Ad, Wd = dev(A, torch.bfloat16), dev(W)
+    hi, lo = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda"), torch.full((N, K), 7.0, dtype=torch.bfloat16, device="cuda")
+    ok(L.dic_cast_bf16_hl(p(Wd), p(hi), p(lo), N * K, stream()), L)
+    torch.cuda.synchronize()
+    assert torch.equal(hi.cpu(), W.to(torch.bfloat16)) and torch.equal(lo.cpu(), (W - W.to(torch.bfloat16).float()).to(torch.bfloat16))
+    A64 = Ad.float().cpu().double()
+    exact = A64 @ (hi.float().cpu().double() + lo.float().cpu().double()).t() + bias.double()
+    full = A64 @ W.double().t() + bias.double()
+    if epi == 0:
+        Rd = dev(Rr, torch.bfloat16)
+        Cf = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(hi), B2=p(lo), C=p(Cf), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), out_f32=1, tile=tile)
+        assert relerr(Cf, exact) < 2e-6
+        assert relerr(Cf, full) < 3e-5, "hi + lo must carry ~16 mantissa bits of the fp32 weight"
+        C1 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(hi), C=p(C1), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), out_f32=1, tile=tile)
+        assert relerr(C1, full) > 10 * relerr(Cf, full)            # what the second pass buys
+        Cb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")   # the engine's form: bf16 output with residual
+        gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(hi), B2=p(lo), C=p(Cb), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), R=p(Rd), ldr=N, tile=tile)
+        assert relerr(Cb.float(), exact + Rd.float().cpu().double()) < 6e-3
+    else:
+        U = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        G_ = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        gemm(L, BF16, 0, 0, 1, A=p(Ad), B=p(hi), B2=p(lo), C=p(G_), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), aux=p(U), ldaux=N, tile=tile)
+        assert torch.equal(U.cpu(), exact.float().to(torch.bfloat16)) or relerr(U.float(), exact) < 4e-3
+        assert relerr(G_.float(), R.gelu(exact)) < 8e-3
+    # refused where it is not built: k-major operands, split-K
+    gp = dic._lib.GemmParams()
+    for k, v in dict(A=p(Ad), B=p(hi), B2=p(lo), C=p(hi), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile).items():
+        setattr(gp, k, v)
+    assert L.dic_gemm(BF16, 0, 1, 0, C.byref(gp), stream()) != 0
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 def test_gemm_bf16_epilogue_general_path(L, tile):
     """The rarely used epilogue combinations that need loads inside the row loop: accumulate into an fp32 C, and a residual
@@ -745,6 +787,17 @@ def test_adamw_matches_oracle_and_writes_bf16_shadow(L):
         torch.cuda.synchronize()
         np.testing.assert_allclose(P.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=1e-6)
     assert torch.equal(sh.cpu(), P.cpu().to(torch.bfloat16))
+    # split-weight form: the same update, plus lo = bf16(p - bf16(p))
+    P2, M2, V2 = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    P1, M1, V1 = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh2, lo2 = torch.zeros(n, dtype=torch.bfloat16, device="cuda"), torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    grad = dev(torch.randn(n, generator=g))
+    ok(L.dic_adamw_hl(p(P2), p(grad), p(M2), p(V2), p(sh2), p(lo2), n, 1e-4, 0.9, 0.999, 1e-8, 0.01, 0.1, 0.001, 1.0, stream()), L)
+    ok(L.dic_adamw(p(P1), p(grad), p(M1), p(V1), 0, n, 1e-4, 0.9, 0.999, 1e-8, 0.01, 0.1, 0.001, 1.0, stream()), L)
+    torch.cuda.synchronize()
+    assert torch.equal(P1, P2) and torch.equal(M1, M2) and torch.equal(V1, V2)
+    assert torch.equal(sh2.cpu(), P2.cpu().to(torch.bfloat16)) and torch.equal(lo2.cpu(), (P2.cpu() - sh2.cpu().float()).to(torch.bfloat16))
+    assert float((sh2.float() + lo2.float() - P2).abs().max() / P2.abs().max()) < 2e-5
 
 
 def test_step_prep_randint_zero(L):
