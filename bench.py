@@ -86,7 +86,7 @@ def pmc_traffic():
     return None, f"no PMC collection for csrc {sha} under profiles/ (rocprofv3 --pmc needs its own passes: scripts/pmc_traffic.sh)"
 
 
-def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_batch=256):
+def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_batch=256, oracle_captions=64):
     """BASELINE.json configs[3]: x0-prediction sampling loop (ref :611-621), logits/argmax only after the last pass."""
     dic.cfg.update(MAX_LENGTH=16, CLASSIFIER_FREE_WEIGHT=0.0, CLIP_ADDING_METHOD="concat", VOCAB_SIZE=30522)
     model = dic.DistilBertModel(E, E, config=dict(n_layers=layers), dtype=dtype, device=dev)
@@ -118,7 +118,7 @@ def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_
     os.environ.pop("DIC_SAMPLE_GRAPH_OFF", None)
     dms, dfl, dn = (acc[8][k] - acc[2][k] for k in range(3))
     if dms > 0:
-        peak = 2500.0 if dtype == "bf16" else 157.3
+        peak = 2500.0 if dtype != "fp32" else 157.3
         ach = dfl / (dms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "forward GEMMs of one denoising pass (QKV, out-proj, FFN1+GELU, FFN2 per layer + the MLM-head transform)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "gemm_ms_per_pass": round(dms / 6, 3),
@@ -135,6 +135,27 @@ def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_
         out["bleu4_bf16_vs_fp32_ids"] = round(dic.bleu.corpus_bleu([r.tolist() for r in ids16], [[r.tolist()] for r in ids32]), 4)
         out["token_agreement"] = round(float((ids16 == ids32).float().mean()), 4)
         out["bleu_captions"] = bleu_batch
+        if oracle_captions > 0:
+            # BASELINE configs[3] "BLEU-4 vs ref": the SAME loop run by the CPU oracle (oracle/ref_model.py::sample -- the checker, on the host cores)
+            # from the same start noise, on the first `oracle_captions` images; agreement bucketed by the oracle's own top-1 / top-2 logit margin
+            from oracle import ref_model as R
+            nb = min(oracle_captions, bleu_batch)
+            c0 = time.perf_counter()
+            om = R.build(R.Config(MAX_LENGTH=16, n_layers=layers, vocab=30522), {k: v.cpu().numpy() for k, v in model.state_dict().items()}, E, requires_grad=False)
+            oids, ohid = R.sample(om, img[:nb].cpu(), steps=passes, start=start[:nb].cpu())
+            lg = ohid[:, :16].double() @ torch.from_numpy(E).double().t()
+            top2 = lg.topk(2, -1).values
+            margin = (top2[..., 0] - top2[..., 1])
+            ref = [[r.tolist()] for r in oids]
+            vs = {"captions": nb, "passes": passes, "oracle_seconds": round(time.perf_counter() - c0, 1)}
+            for name, ids in (("fp32", ids32[:nb]), ("bf16", ids16[:nb])):
+                same = ids == oids
+                vs[f"bleu4_{name}_vs_oracle_ids"] = round(dic.bleu.corpus_bleu([r.tolist() for r in ids], ref), 4)
+                vs[f"token_agreement_{name}"] = round(float(same.float().mean()), 4)
+                vs[f"agreement_by_oracle_margin_{name}"] = {f"[{lo},{hi})": [int(((margin >= lo) & (margin < hi)).sum()), round(float(same[(margin >= lo) & (margin < hi)].float().mean()), 4)]
+                                                            for lo, hi in ((0, 0.01), (0.01, 0.03), (0.03, 0.1), (0.1, 1e9)) if bool(((margin >= lo) & (margin < hi)).any())}
+            out["vs_oracle"] = vs
+            del om
         del m32
     del model
     torch.cuda.empty_cache()

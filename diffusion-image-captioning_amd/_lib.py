@@ -16,7 +16,7 @@ _AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another bui
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
-EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP = range(6)
+EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [
     "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",

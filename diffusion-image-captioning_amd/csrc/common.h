@@ -109,6 +109,17 @@ template <class V4> __device__ __forceinline__ void gelu_fast4(V4& v) {         
         v[2 * h] = y[0]; v[2 * h + 1] = y[1];
     }
 }
+template <class V4> __device__ __forceinline__ void gelu_fast_with_grad4(V4& v, V4& d) {  // v <- gelu(v), d <- gelu'(v): one erf / exp evaluation for both
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2_t x{v[2 * h], v[2 * h + 1]};
+        f32x2_t c, g; gelu_fast_parts2(x, c, g);
+        const f32x2_t y = x * c;
+        const f32x2_t dd = pk_fma(x * pk_splat(0.3989422804014327f), g, c);
+        v[2 * h] = y[0]; v[2 * h + 1] = y[1];
+        d[2 * h] = dd[0]; d[2 * h + 1] = dd[1];
+    }
+}
 template <class V4> __device__ __forceinline__ void gelu_grad_mul4(V4& v, const V4& u) { // v <- v * gelu'(u), four elements
 #pragma unroll
     for (int h = 0; h < 2; ++h) {

@@ -445,7 +445,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     // XCD's L2 between rounds of the persistent grid (PMC: 149 MB fetched for 31 MB of operands); with nt the launch is 14 % faster
     // (130 -> 112 us, cold operands).  NOT for the other outputs: split-K slabs are re-read by the fold right away (nt: +20-50 %), the
     // GELU' and residual epilogues measured 0-6 % slower with nt.
-    constexpr bool NT = EPI == DIC_EPI_BIAS_GELU;
+    constexpr bool NT = EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D;
     static_assert(G::NP == 2, "line stores pair the two 8-column groups of a 64-column wave slab");
     const int lrow = t & 7, lcol = 8 * (g + 4 * (t >> 3));          // row within an 8-row half fragment; column of this lane's chunk in line order
     // Buffer addressing (32-bit lane offsets against a descriptor anchored at the wave's first row): no 64-bit address arithmetic and no
@@ -498,7 +498,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     bool v0[G::NP], v1[G::NP];
 #pragma unroll
     for (int q = 0; q < G::NP; ++q) { nc[q] = n_first + 32 * q + 8 * g; v0[q] = nc[q] < p.N; v1[q] = nc[q] + 4 < p.N; }
-    if constexpr ((EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU) && !BIAS_IN_ACC) {       // (forward Linears: the accumulators started from the bias)
+    if constexpr ((EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D) && !BIAS_IN_ACC) {       // (forward Linears: the accumulators started from the bias)
         if (p.bias) {
 #pragma unroll
             for (int q = 0; q < G::NP; ++q) {
@@ -595,6 +595,45 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                     }
                 }
             }
+        }
+    } else if constexpr (EPI == DIC_EPI_BIAS_GELU_D) {               // g = gelu(u) -> C, gelu'(u) -> aux (what the backward multiplies by)
+        issue_next();
+        const bool keep_d = p.aux != nullptr;
+        const LineBuf bD = line_buf(keep_d ? p.aux : p.C, keep_d ? p.ldaux : p.ldc, 2, n_first + lcol, p.N), bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            i32x4 Dq[G::NP], A[G::NP];
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1], d0, d1;
+                gelu_fast_with_grad4(x0, d0); gelu_fast_with_grad4(x1, d1);
+                Dq[q] = pack8f(d0, d1);
+                A[q] = pack8f(x0, x1);
+            }
+            if (keep_d) put_lines(i, bD, Dq[0], Dq[1]);
+            put_lines(i, bC, A[0], A[1]);
+        }
+    } else if constexpr (EPI == DIC_EPI_MUL_AUX) {                   // dU = acc * aux  (aux = gelu'(u) left by BIAS_GELU_D)
+        i32x4 pre[CNT][G::NP];
+        const LineBuf bU = line_buf(p.aux, p.ldaux, 2, n_first + lcol, p.N), bC = line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
+        constexpr bool EARLY = CNT * G::FN * 4 + CNT * G::NP * 4 >= 192;          // (as for the residual epilogue: registers of the set-up vs the side tile)
+        if constexpr (EARLY) issue_next();
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) get_lines_issue(i, bU, pre[i][0], pre[i][1]);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if constexpr (!EARLY) issue_next();
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            get_lines_finish(pre[i][0], pre[i][1]);
+            i32x4 P[G::NP];
+#pragma unroll
+            for (int q = 0; q < G::NP; ++q) {
+                f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1], u0, u1;
+                unpack8(pre[i][q], u0, u1);
+                x0 *= u0; x1 *= u1;
+                P[q] = pack8f(x0, x1);
+            }
+            put_lines(i, bC, P[0], P[1]);
         }
     } else if constexpr (EPI == DIC_EPI_BIAS_GELU) {                 // N % 8 == 0 is required for this epilogue
         issue_next();
@@ -960,7 +999,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     // not average out (2.6e-4 relative at the bench shape), while activation roundings are independent per element and do (< 4e-5;
     // profiles/r04_weight_rounding_probe.txt).  With hi + lo the weights carry 16 mantissa bits and the bf16 engine's losses sit within
     // north_star's 1e-4 of the fp32 engine's at twice the forward-GEMM K loop.
-    constexpr bool TWO_PASS = !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU);
+    constexpr bool TWO_PASS = !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D);
     i32x4 rsB2 = {0, 0, 0, 0};
     auto make_rsrc = [](const void* base, long long bytes) {
         const unsigned long long b = (unsigned long long)base;
@@ -1205,7 +1244,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #define DIC_GEMM_XT 0          // measured in round 3 (profiles/r03_gemm_xt_ab.txt): 3-7 % SLOWER on every shape, K loop included -- off
 #endif
     constexpr bool XT = DIC_GEMM_XT != 0;
-    constexpr bool BIAS_INIT = !XT && !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU);
+    constexpr bool BIAS_INIT = !XT && !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D);
     f32x4 binit[BIAS_INIT ? G::FN : 1];
     auto load_bias = [&](const TileId& t_) {
         if constexpr (BIAS_INIT) {
@@ -1629,7 +1668,7 @@ void launch_bf16(const DicGemmParams& q, hipStream_t st) {
     const int units = nbn_split * ((q.M + rows - 1) / rows);
     const int grid = ((persist_enabled() || q.cu_cap > 0) && units > resident) ? resident : units;
 #ifndef DIC_GEMM_MIN
-    if constexpr (std::is_same_v<C, T256> && !AKM && !BKM && (E == DIC_EPI_AFFINE || E == DIC_EPI_BIAS_GELU)) {
+    if constexpr (std::is_same_v<C, T256> && !AKM && !BKM && (E == DIC_EPI_AFFINE || E == DIC_EPI_BIAS_GELU || E == DIC_EPI_BIAS_GELU_D)) {
         if (q.split_k <= 1 && persist_enabled() && gemm_variant() == 0) {
             const TwoHeights th = plan_two_heights(q.M, nbn_split, resident, q.K, rows);
             if (th.cA) {
@@ -1686,8 +1725,8 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
     // built combinations: every epilogue for (k-contiguous, k-contiguous) = nn.Linear forward and the rounding head; the affine and GELU
     // epilogues for a k-major B (input gradients); the affine one for (k-major, k-major) = weight gradients.  Nothing on the path
     // asks for the others.
-    if (epi < DIC_EPI_AFFINE || epi > DIC_EPI_CE_EXP) { dic_set_error("dic_gemm: unknown epilogue"); return 1002; }
-    if ((AKM && epi != DIC_EPI_AFFINE) || (BKM && (epi == DIC_EPI_CE_PARTIAL || epi == DIC_EPI_CE_DLOGITS || epi == DIC_EPI_CE_EXP))) {
+    if (epi < DIC_EPI_AFFINE || epi > DIC_EPI_MUL_AUX) { dic_set_error("dic_gemm: unknown epilogue"); return 1002; }
+    if ((AKM && epi != DIC_EPI_AFFINE) || (BKM && (epi == DIC_EPI_CE_PARTIAL || epi == DIC_EPI_CE_DLOGITS || epi == DIC_EPI_CE_EXP || epi == DIC_EPI_BIAS_GELU_D))) {
         dic_set_error("dic_gemm: this epilogue is not built for this operand layout (weight gradients: AFFINE only; k-major B: no rounding-head epilogues)");
         return 1005;
     }
@@ -1701,6 +1740,16 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
         case DIC_EPI_CE_EXP:                       // bf16 LDS-DMA kernels only (dic_gemm_impl checks)
             if constexpr (!AKM && !BKM && sizeof(T) == 2) {
                 if (p.tile == 256) launch_bf16<T256, false, false, DIC_EPI_CE_EXP>(p, st); else launch_bf16<T128, false, false, DIC_EPI_CE_EXP>(p, st);
+            }
+            break;
+        case DIC_EPI_BIAS_GELU_D:                  // bf16 LDS-DMA kernels only
+            if constexpr (!AKM && !BKM && sizeof(T) == 2) {
+                if (p.tile == 256) launch_bf16<T256, false, false, DIC_EPI_BIAS_GELU_D>(p, st); else launch_bf16<T128, false, false, DIC_EPI_BIAS_GELU_D>(p, st);
+            }
+            break;
+        case DIC_EPI_MUL_AUX:                      // bf16 LDS-DMA kernels only
+            if constexpr (!AKM && sizeof(T) == 2) {
+                if (p.tile == 256) launch_bf16<T256, false, BKM, DIC_EPI_MUL_AUX>(p, st); else launch_bf16<T128, false, BKM, DIC_EPI_MUL_AUX>(p, st);
             }
             break;
 #endif
@@ -1903,9 +1952,11 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (b_km) DIC_REQUIRE((long long)p.K * p.ldb * es < 0x7FFFFFFFll, "dic_gemm: k-major B too large for 32-bit buffer offsets");
     if (!a_km) DIC_REQUIRE((long long)BM * p.lda * es < 0x7FFFFFFFll, "dic_gemm: lda too large");
     if (epi != DIC_EPI_CE_PARTIAL && epi != DIC_EPI_CE_DLOGITS && epi != DIC_EPI_CE_EXP) DIC_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "dic_gemm: N and ldc must be multiples of 4");
-    if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD))
+    if (dtype == DIC_BF16 && (epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_GELU_BWD || epi == DIC_EPI_BIAS_GELU_D || epi == DIC_EPI_MUL_AUX))
         DIC_REQUIRE(p.N % 8 == 0 && p.ldc % 8 == 0 && (p.aux == nullptr || p.ldaux % 8 == 0), "dic_gemm: bf16 GELU epilogues need N, ldc, ldaux multiples of 8");
-    if (epi == DIC_EPI_GELU_BWD) DIC_REQUIRE(p.aux != nullptr, "dic_gemm: GELU_BWD needs the pre-activation (aux)");
+    if (epi == DIC_EPI_GELU_BWD || epi == DIC_EPI_MUL_AUX) DIC_REQUIRE(p.aux != nullptr, "dic_gemm: GELU_BWD / MUL_AUX need their side input (aux)");
+    if (epi == DIC_EPI_BIAS_GELU_D || epi == DIC_EPI_MUL_AUX)
+        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && p.split_k <= 1, "dic_gemm: BIAS_GELU_D / MUL_AUX are epilogues of the bf16 LDS-DMA kernels");
     if (dtype == DIC_BF16) DIC_REQUIRE(p.ldc % 4 == 0 && (p.R == nullptr || p.ldr % 4 == 0), "dic_gemm: ldc/ldr must be multiples of 4");
     if (p.tile == 256)
         DIC_REQUIRE(dtype == DIC_BF16 && !(epi == DIC_EPI_CE_PARTIAL && bf16_on_v1()) && (!a_km || p.M % 256 == 0) && (!b_km || p.N % 256 == 0 || p.N % 8 == 0),
@@ -1917,7 +1968,7 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
     if (p.B2)
-        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && !b_km && (epi == DIC_EPI_AFFINE || epi == DIC_EPI_BIAS_GELU) && p.split_k <= 1 &&
+        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && !b_km && (epi == DIC_EPI_AFFINE || epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_BIAS_GELU_D) && p.split_k <= 1 &&
                     ((uintptr_t)p.B2 % 16) == 0 && gemm_variant() == 0,
                     "dic_gemm: B2 (low-order weight half) is an option of the bf16 forward GEMMs (k-contiguous A and B, AFFINE / BIAS_GELU, no split-K)");
     if (epi == DIC_EPI_CE_EXP)

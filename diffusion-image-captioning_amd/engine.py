@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import DIC_BF16, DIC_F32, EPI_AFFINE, EPI_BIAS_GELU, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_CE_PARTIAL, EPI_GELU_BWD, GemmParams
+from ._lib import (DIC_BF16, DIC_F32, EPI_AFFINE, EPI_BIAS_GELU, EPI_BIAS_GELU_D, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_CE_PARTIAL, EPI_GELU_BWD, EPI_MUL_AUX,
+                   GemmParams)
 from .config import LOSS_KINDS, cfg
 from .params import ParamStore
 
@@ -72,6 +73,10 @@ _V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the regist
 _WGRAD_MAX_SPLIT = int(_os.environ.get("DIC_WGRAD_MAX_SPLIT", "32"))     # cap of the weight-gradient GEMMs' split-K factor (A/B switch)
 _GELU_FWD_TILE = _os.environ.get("DIC_GELU_FWD_TILE", "256")   # tile of the bias+GELU forward GEMM (A/B switch)
 _GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GELU' input-gradient GEMM (A/B switch; 128 measured faster in rounds 2 and 3)
+# bf16 engine: FFN-1's forward epilogue leaves gelu'(u) behind instead of u (same bytes), so the backward's epilogue is one multiply (MUL_AUX)
+# instead of erf + exp per element (round-3 review item 3; "0": the round-3 form, kept as the A/B partner and for the fp32 engine)
+_GELU_D = _os.environ.get("DIC_GELU_D", "1") != "0"
+_MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
 
@@ -83,7 +88,8 @@ def choose_tile(M, N, split_k=1, epi=EPI_AFFINE):
     input) measured faster on 128-tiles (145 vs 154 us); bias+GELU (two 113 MB outputs) on 256-tiles (136 vs 162 us)."""
     if _TILE_MODE in ("128", "256"):
         return int(_TILE_MODE) if (M >= 256 and N >= 256) else 128
-    if M < 256 or N < 256 or (epi == EPI_GELU_BWD and _GELU_BWD_TILE != "256") or (epi == EPI_BIAS_GELU and _GELU_FWD_TILE == "128"):
+    if (M < 256 or N < 256 or (epi == EPI_GELU_BWD and _GELU_BWD_TILE != "256") or (epi == EPI_MUL_AUX and _MUL_AUX_TILE != "256") or
+            (epi in (EPI_BIAS_GELU, EPI_BIAS_GELU_D) and _GELU_FWD_TILE == "128")):
         return 128
     units = ((M + 255) // 256) * ((N + 255) // 256) * max(split_k, 1)
     return 256 if units >= int(0.75 * N_CU) else 128
@@ -374,6 +380,7 @@ class Denoiser:
         lo = (lambda slot: P.ptr(slot, "Pl")) if self.split_w else (lambda slot: 0)       # low-order weight halves (split-weight mode)
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
         ws["has_u"] = keep_u
+        gelu_d = ws["gelu_d"] = self.bf16 and _GELU_D and not _V1_BF16          # Lw["u"] then holds gelu'(u), not u
         if x_ptr is None:
             if x.data_ptr() != ws["xin"].data_ptr():
                 ws["xin"][:N].copy_(x)
@@ -413,7 +420,7 @@ class Denoiser:
             o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(h), ldr=D, B2=lo(pre + "Wo"))
             _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             # K8: FFN
-            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU, bias=P.ptr(pre + "b1"),
+            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU, bias=P.ptr(pre + "b1"),
                    aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd, B2=lo(pre + "W1"))
             o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa"]), ldr=D,
                    p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"))
@@ -574,7 +581,8 @@ class Denoiser:
             fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                              # [ln2g | ln2b | b2]
             dyd = dyd_ if use_drop else dy_
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
-            o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_GELU_BWD, aux=_p(Lw["u"]), ldaux=Hd)
+            o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_MUL_AUX if ws["gelu_d"] else EPI_GELU_BWD,
+                   aux=_p(Lw["u"]), ldaux=Hd)
             wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                                # dW1 (+ db1)
             if _os.environ.get("DIC_WGRAD_GROUP_HALVES", "1") == "1":
                 flush_group()                         # the two FFN gradients go out now (72 tiles), out-proj + qkv at the end of the layer (36):

@@ -39,6 +39,10 @@ const char* dic_last_error(void);
  *   BIAS_GELU   aux = acc + bias ; C = gelu(aux)                            -- hf:221-222 (ffn.lin1 + GELU); aux == NULL: the
  *               pre-activation is not kept (forward-only calls: sampling, validation)
  *   GELU_BWD    C = acc * gelu'(aux)                                        -- backward of the above
+ *   BIAS_GELU_D u = acc + bias ; C = gelu(u) ; aux = gelu'(u)  (bf16 LDS-DMA kernels only) -- the same forward, but what it leaves behind for
+ *               the backward is the DERIVATIVE (evaluated on the unrounded fp32 u, where erf / exp are already at hand) instead of the
+ *               pre-activation: same bytes, and the backward's epilogue becomes one multiply (MUL_AUX) instead of erf + exp per element
+ *   MUL_AUX     C = acc * aux                                              -- backward of BIAS_GELU_D (bf16 LDS-DMA kernels only)
  *   CE_PARTIAL  per (row, 64-col half tile): {max, sum exp(x-max), first argmax}; tgt_logit[m] = acc[m][tgt[m]]
  *               -- streaming form of softmax/gather/argmax over the 30522-wide logits (ref:323,436-437,620)
  *   CE_DLOGITS  C = (exp(acc - lse[m]) - [n == tgt[m]]) * (m < ce_rows_a ? ce_scale_a : ce_scale_b),
@@ -55,6 +59,8 @@ const char* dic_last_error(void);
 #define DIC_EPI_CE_PARTIAL 3
 #define DIC_EPI_CE_DLOGITS 4
 #define DIC_EPI_CE_EXP 5
+#define DIC_EPI_BIAS_GELU_D 6
+#define DIC_EPI_MUL_AUX 7
 
 typedef struct DicGemmParams {
     const void* A; const void* B; void* C;

@@ -24,8 +24,8 @@ def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, resid=Fa
     A = torch.randn((K, M) if a_km else (M, K), device="cuda").to(bf)
     B = torch.randn((K, N) if b_km else (N, K), device="cuda").to(bf)
     Cc = torch.empty(M, N, device="cuda", dtype=torch.float32 if out_f32 else bf)
-    aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2) else None
-    bias = torch.randn(N, device="cuda") if epi in (0, 1) and not out_f32 else None
+    aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2, 6, 7) else None
+    bias = torch.randn(N, device="cuda") if epi in (0, 1, 6) and not out_f32 else None
     ws = torch.empty(split * M * N, device="cuda") if split > 1 else None
     Rr = torch.randn(M, N, device="cuda").to(bf) if resid else None
     g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, tile=int(os.environ.get("TILE", "128")),
@@ -46,15 +46,15 @@ def run(name, M, N, K, a_km, b_km, epi=0, split=1, out_f32=0, iters=20, resid=Fa
 
 
 def run_cold(name, M, N, K, a_km, b_km, epi, split, out_f32, iters, resid, p_drop):
-    per = (M * K + N * K) * 2 + M * N * (4 if out_f32 else 2) * (2 if epi in (1, 2) else 1)
+    per = (M * K + N * K) * 2 + M * N * (4 if out_f32 else 2) * (2 if epi in (1, 2, 6, 7) else 1)
     nset = max(2, min(24, int(1.5e9 // per)))
     sets = []
     for _ in range(nset):
         A = torch.randn((K, M) if a_km else (M, K), device="cuda").to(bf)
         B = torch.randn((K, N) if b_km else (N, K), device="cuda").to(bf)
         Cc = torch.empty(M, N, device="cuda", dtype=torch.float32 if out_f32 else bf)
-        aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2) else None
-        bias = torch.randn(N, device="cuda") if epi in (0, 1) and not out_f32 else None
+        aux = torch.randn(M, N, device="cuda").to(bf) if epi in (1, 2, 6, 7) else None
+        bias = torch.randn(N, device="cuda") if epi in (0, 1, 6) and not out_f32 else None
         Rr = torch.randn(M, N, device="cuda").to(bf) if resid else None
         ws = torch.empty(split * M * N, device="cuda") if split > 1 else None
         g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, tile=int(os.environ.get("TILE", "128")),
@@ -136,3 +136,15 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ce":
     for sp in (1, 2, 3, 4, 6):
         run("rounding dX    (KC,KM) f32", 16384, D, V, 0, 1, out_f32=1, split=sp)
     run("rounding logits(KC,KC) plain", 16384, V, D, 0, 0)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gelu":
+    # FFN-1 forward with the pre-activation (1) or the derivative (6) as its second output; its backward with erf + exp (2) or one multiply (7)
+    for tile in ("128", "256"):
+        os.environ["TILE"] = tile
+        print("TILE =", tile)
+        run("fwd ffn1  BIAS_GELU   (u, g)", T, F, D, 0, 0, epi=1)
+        run("fwd ffn1  BIAS_GELU_D (g', g)", T, F, D, 0, 0, epi=6)
+        run("dX  ffn2->du GELU_BWD (erf)", T, F, D, 0, 1, epi=2)
+        run("dX  ffn2->du MUL_AUX  (mul)", T, F, D, 0, 1, epi=7)
+        run("dX  plain (no side input)", T, F, D, 0, 1, epi=0)

@@ -321,6 +321,40 @@ def test_gemm_gelu_epilogues_and_dropout(L, dtype):
     assert relerr(C1[kept], full[kept] / 0.75) < 1e-5
 
 
+@pytest.mark.parametrize("tile,M,N,K,b_km", [(128, 144, 256, 192, 0), (128, 300, 776, 128, 1), (256, 600, 768, 320, 1), (256, 2176, 3072, 768, 1), (256, 520, 512, 64, 0)])
+def test_gemm_gelu_derivative_epilogue_pair(L, tile, M, N, K, b_km):
+    """BIAS_GELU_D / MUL_AUX (hf:221-223 and its backward): the forward leaves gelu'(u) behind instead of u, the backward's epilogue is one
+    multiply.  g must equal BIAS_GELU's bit for bit (same arithmetic), the stored derivative is the fp64 derivative of the UNROUNDED u to bf16
+    accuracy, and acc * aux matches the erf-form backward (GELU_BWD on the bf16 pre-activation) within bf16 rounding."""
+    g = torch.Generator().manual_seed(9 + M)
+    A, W, bias = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)
+    Ad, Wd = dev(A, torch.bfloat16), dev(W, torch.bfloat16)
+    U, G1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    D, G2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    kw = dict(A=p(Ad), B=p(Wd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), ldaux=N, tile=tile)
+    gemm(L, BF16, 0, 0, 1, C=p(G1), aux=p(U), **kw)
+    gemm(L, BF16, 0, 0, 6, C=p(G2), aux=p(D), **kw)
+    assert torch.equal(G1, G2)
+    u64 = (Ad.float().cpu().double() @ Wd.float().cpu().double().t() + bias.double()).requires_grad_(True)
+    R.gelu(u64).sum().backward()
+    assert relerr(D.float(), u64.grad) < 6e-3
+    G3 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    gemm(L, BF16, 0, 0, 6, C=p(G3), aux=0, **kw)                       # forward-only call: nothing kept
+    assert torch.equal(G3, G1)
+    # backward: dU = dY W2-shaped product * aux; operands of the engine's call: A = dY [M][Kb], B = W2 stored k-major [Kb][N]
+    Kb = 192
+    dY, W2 = torch.randn(M, Kb, generator=g) * 0.3, torch.randn(N, Kb, generator=g) * 0.3
+    dYd = dev(dY, torch.bfloat16)
+    W2d = dev(W2.t() if b_km else W2, torch.bfloat16)
+    acc = dYd.float().cpu().double() @ (W2d.float().cpu().double() if b_km else W2d.float().cpu().double().t())
+    O1, O2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    kb = dict(A=p(dYd), B=p(W2d), M=M, N=N, K=Kb, lda=Kb, ldb=(N if b_km else Kb), ldc=N, ldaux=N, tile=tile)
+    gemm(L, BF16, 0, b_km, 7, C=p(O1), aux=p(D), **kb)
+    assert relerr(O1.float(), acc * D.float().cpu().double()) < 6e-3
+    gemm(L, BF16, 0, b_km, 2, C=p(O2), aux=p(U), **kb)
+    assert relerr(O1.float(), O2.float()) < 2e-2
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(17408, 2304, 768, 0), (17408, 3072, 768, 1), (34816, 768, 768, 0), (34816, 3072, 768, 1), (29920, 768, 3072, 0),
                                        (38080, 768, 768, 0), (20000, 1024, 192, 0)])
 def test_gemm_two_tile_heights_in_one_launch(L, M, N, K, epi):
