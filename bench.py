@@ -82,8 +82,8 @@ def pmc_traffic():
             continue
         if pj.get("csrc_sha") == sha:
             return round(pj["gemm_fetch_bytes_per_launch_x2"] + pj["gemm_write_bytes_per_launch"]), \
-                f"bytes/launch averaged over the step's GEMM launches, FETCH_SIZE(x2)+WRITE_SIZE, profiles/{os.path.basename(f)} (csrc {sha})"
-    return None, f"no PMC collection for csrc {sha} under profiles/ (rocprofv3 --pmc needs its own passes: scripts/pmc_traffic.sh)"
+                f"bytes/launch averaged over the step's GEMM launches, FETCH_SIZE(x2)+WRITE_SIZE, profiles/{os.path.basename(f)} (csrc {sha})", pj
+    return None, f"no PMC collection for csrc {sha} under profiles/ (rocprofv3 --pmc needs its own passes: scripts/pmc_traffic.sh)", None
 
 
 def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_batch=256, oracle_captions=64):
@@ -210,6 +210,14 @@ def main():
     rank, world, local = dic.parallel.init_from_env()
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}: refusing to report a line for a different GPU count")
+    if world > 1:
+        # a multi-GPU line is an RCCL-over-xGMI line: any other backend must have been asked for by name (DIC_DIST_BACKEND, the shared-GPU
+        # gloo rig of the tests) and is labelled as such in `data_parallel`
+        be = torch.distributed.get_backend()
+        if be != "nccl" and not os.environ.get("DIC_DIST_BACKEND"):
+            sys.exit(f"bench.py: --gpus {args.gpus} initialised the '{be}' backend, not nccl (= RCCL on ROCm): refusing to report a multi-GPU number over it")
+        if torch.distributed.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: the communicator has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     E = dic.synth.vocab_embedding(30522, 768, 0)
@@ -290,7 +298,14 @@ def main():
                 ncoll = red.n_collectives
         os.environ.pop("DIC_DP_TIMING", None)
         barrier()
-        dp_info = {"rccl_ranks": world, "backend": torch.distributed.get_backend(), "collectives_per_step": ncoll,
+        try:
+            rccl_ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_ver = None
+        devs = [None] * world
+        torch.distributed.all_gather_object(devs, f"{torch.cuda.current_device()}:{torch.cuda.get_device_properties(torch.cuda.current_device()).name}")
+        dp_info = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(), "rccl_version": rccl_ver,
+                   "devices_by_rank": devs, "collectives_per_step": ncoll,
                    "mode": "single all-reduce after the backward (DIC_DP_SINGLE=1)" if os.environ.get("DIC_DP_SINGLE", "0") == "1" else
                            f"slices of {os.environ.get('DIC_DP_GROUP', '3')} layers issued from the backward + tail",
                    "allreduce_ms_per_step": round(sum(ar_ms) / len(ar_ms), 3) if ar_ms else None,
@@ -319,17 +334,26 @@ def main():
             dic.train_func(model, trainer, x)
         torch.cuda.synchronize()
         ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+        alg_bytes = Lh.dic_prof_algorithmic_bytes() / max(args.steps, 1)
         Lh.dic_prof_end(C.byref(ms), C.byref(fl), C.byref(n))
         model.wgrad_stream_enabled = True
         peak = 2500.0 if args.dtype != "fp32" else 157.3
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        traffic, traffic_src = (None, "PMC traffic is collected for the default workload only")
+        traffic, traffic_src, pj = (None, "PMC traffic is collected for the default workload only", None)
         if (B, S, L, args.layers, args.dtype, w) == (512, 1, 16, 12, "bf16", 0.0):
-            traffic, traffic_src = pmc_traffic()
+            traffic, traffic_src, pj = pmc_traffic()
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all layouts/epilogues)" if args.dtype != "fp32" else "gemm_kernel<float>", "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_src,
                 "launches_per_step": n.value // max(args.steps, 1), "gemm_ms_per_step": round(ms.value / args.steps, 3),
-                "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
+                "gemm_gflop_per_step": round(fl.value / args.steps / 1e9, 1),
+                # every operand / side input / output of the step's GEMM launches once (dic_prof_algorithmic_bytes): what the PMC traffic is to be held against
+                "algorithmic_bytes_per_step": round(alg_bytes), "algorithmic_bytes_per_launch": round(alg_bytes / max(n.value // max(args.steps, 1), 1))}
+        if pj is not None and "gemm_bytes_per_step" in pj:
+            roof["traffic_per_step"] = round(pj["gemm_bytes_per_step"])
+            roof["pmc_launches_per_step"] = pj["gemm_launches_per_step"]
+            roof["fold_traffic_per_step"] = round(pj.get("fold_bytes_per_step", 0))
+            roof["traffic_waste_ratio"] = round((pj["gemm_bytes_per_step"] + pj.get("fold_bytes_per_step", 0)) / max(alg_bytes, 1.0), 3)
+            roof["whole_step_traffic_gb"] = round(pj["step_fetch_gb_x2"] + pj["step_write_gb"], 2)
         if args.dtype == "bf16w":
             roof["note"] = "executed flops: the forward Linears run their K loop twice (hi + lo weight halves); algorithmic flops per step are those of the bf16 line"
         if args.dtype == "bf16" and w == 0.0:

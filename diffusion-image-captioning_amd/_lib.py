@@ -22,7 +22,7 @@ EXPORTS = [
     "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
-    "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end",
+    "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_colsum_pair", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end", "dic_prof_algorithmic_bytes", "dic_prof_get",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
     "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep", "dic_step_ctx_set", "dic_step_advance",
@@ -150,6 +150,7 @@ def lib():
         L.dic_cfg_mix_bwd.argtypes = [P, P, P, I, I, F, P]
         L.dic_seq_sum.argtypes = [P, P, P, P, I, I, I, P]
         L.dic_colsum.argtypes = [I, P, I, I, I, P, I, P, P]
+        L.dic_colsum_pair.argtypes = [P, P, P, P, I, I, I, P]
         L.dic_adamw.argtypes = [P, P, P, P, P, I64, F, F, F, F, F, F, F, F, P]
         L.dic_cast_bf16.argtypes = [P, P, I64, P]
         L.dic_adamw_hl.argtypes = [P, P, P, P, P, P, I64, F, F, F, F, F, F, F, F, P]
@@ -157,6 +158,9 @@ def lib():
         L.dic_probe_tr16.argtypes = [P, P, P]
         L.dic_gemm_set_variant.argtypes = [I]
         L.dic_prof_begin.argtypes = [I]
+        L.dic_prof_algorithmic_bytes.restype = C.c_double
+        L.dic_prof_algorithmic_bytes.argtypes = []
+        L.dic_prof_get.argtypes = [I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.dic_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _lib = L
     return _lib

@@ -141,10 +141,23 @@ __device__ __forceinline__ TileId tile_of_unit(const DicGemmParams& p, int BK, i
 #define DIC_GEMM_GW 8
 #endif
     constexpr int GW = DIC_GEMM_GW;
-    const int grp = lin / (GW * nbm), rem = lin - grp * (GW * nbm);
-    const int w = min(GW, nbn - grp * GW);
-    t.bm = rem / w;
-    t.bn = grp * GW + (rem - t.bm * w);
+#ifndef DIC_GEMM_WIDE_ORDER
+#define DIC_GEMM_WIDE_ORDER 1
+#endif
+    if (DIC_GEMM_WIDE_ORDER && nbn >= 4 * nbm) {
+        // WIDE problems (the rounding head: 64 row tiles x 120 column tiles): the patch an XCD works on moves along the LONG dimension, so the
+        // GW row panels of A it holds (8 x 393 KB at K = 768) stay in its L2 while the column panels of the vocabulary matrix stream through --
+        // (nbm / GW) x |B| + |A| of L2 misses instead of (nbn / GW) x |A| + |B| (round 4; PMC: profiles/r04_pmc_hbm_traffic.txt)
+        const int grp = lin / (GW * nbn), rem = lin - grp * (GW * nbn);
+        const int h = min(GW, nbm - grp * GW);
+        t.bn = rem / h;
+        t.bm = grp * GW + (rem - t.bn * h);
+    } else {
+        const int grp = lin / (GW * nbm), rem = lin - grp * (GW * nbm);
+        const int w = min(GW, nbn - grp * GW);
+        t.bm = rem / w;
+        t.bn = grp * GW + (rem - t.bm * w);
+    }
     t.nbn = nbn;
     const int nk = (p.K + BK - 1) / BK, per = (nk + split - 1) / split;
     t.kt0 = t.kz * per;
@@ -445,7 +458,10 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     // XCD's L2 between rounds of the persistent grid (PMC: 149 MB fetched for 31 MB of operands); with nt the launch is 14 % faster
     // (130 -> 112 us, cold operands).  NOT for the other outputs: split-K slabs are re-read by the fold right away (nt: +20-50 %), the
     // GELU' and residual epilogues measured 0-6 % slower with nt.
-    constexpr bool NT = EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D;
+#ifndef DIC_CE_EXP_NT
+#define DIC_CE_EXP_NT 1       // streaming stores for the rounding head's 1 GB of exp(logit - c): nothing reads it before the backward, and it must not push the operand panels out of L2
+#endif
+    constexpr bool NT = EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D || (DIC_CE_EXP_NT && EPI == DIC_EPI_CE_EXP);
     static_assert(G::NP == 2, "line stores pair the two 8-column groups of a 64-column wave slab");
     const int lrow = t & 7, lcol = 8 * (g + 4 * (t >> 3));          // row within an 8-row half fragment; column of this lane's chunk in line order
     // Buffer addressing (32-bit lane offsets against a descriptor anchored at the wave's first row): no 64-bit address arithmetic and no
@@ -1503,7 +1519,7 @@ __global__ void reduce_slabs_kernel(const float* ws, int nslab, long long n4, lo
 // (at most two) kernels of a dic_gemm / dic_wgrad_group call are launched through hipExtLaunchKernelGGL with a start and a stop event each,
 // which stamp the kernel's own begin and end -- the same interval rocprofv3 reports.  (Events recorded around the launch added ~4 us of
 // dispatch latency per call: 0.56 ms per step over 140 launches.)
-struct ProfRec { hipEvent_t a, b, a2, b2; double flops; int used; };
+struct ProfRec { hipEvent_t a, b, a2, b2; double flops, bytes; int used; };
 thread_local ProfRec* tl_prof = nullptr;
 template <typename... Args, typename F = void (*)(Args...)>
 void launch_timed(F kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t st, Args... args) {
@@ -1779,7 +1795,7 @@ int launch_layout(const DicGemmParams& p, int a_km, int b_km, int epi, hipStream
 }  // namespace
 
 // claims the next timing record of the measurement hooks below (false when profiling is off); thread-safe
-static ProfRec* prof_slot(double flops);
+static ProfRec* prof_slot(double flops, double bytes = 0.0);
 
 // ---- grouped weight gradients: host side ---------------------------------------------------------------------------------------------------
 namespace {
@@ -1848,7 +1864,8 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     DicGemmParams q{};
     q.K = T; q.out_f32 = 1; q.split_k = 1; q.tile = 256;
     hipStream_t st = (hipStream_t)stream;
-    tl_prof = prof_slot([&] { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * items[i].M * items[i].N * T; return f; }());
+    tl_prof = prof_slot([&] { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * items[i].M * items[i].N * T; return f; }(),
+                        [&] { double b = 0; for (int i = 0; i < n; ++i) b += ((double)items[i].M + items[i].N) * T * 2.0 + (double)items[i].M * items[i].N * 4.0; return b; }());
 #ifdef DIC_GEMM_VARIANTS
     if (pp_enabled()) launch_timed(wgrad_group_pp_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
     else
@@ -1923,16 +1940,42 @@ extern "C" int dic_prof_end(double* total_ms, double* total_flops, int* n_launch
 }
 
 static std::mutex g_prof_mu;
-static ProfRec* prof_slot(double flops) {
+static ProfRec* prof_slot(double flops, double bytes) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof || g_prof_n >= g_prof_cap) return nullptr;
     ProfRec& r = g_prof[g_prof_n++];
-    r.flops = flops; r.used = 0;
+    r.flops = flops; r.bytes = bytes; r.used = 0;
     return &r;
+}
+// One recorded launch (caller has synchronised; call before dic_prof_end): kernel time incl. its slab fold, flops, algorithmic bytes.  Returns 0 past the end.
+extern "C" int dic_prof_get(int i, double* ms, double* flops, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof || i < 0 || i >= g_prof_n) return 0;
+    float t = 0, t2 = 0;
+    if (g_prof[i].used >= 1) (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+    if (g_prof[i].used >= 2) (void)hipEventElapsedTime(&t2, g_prof[i].a2, g_prof[i].b2);
+    *ms = (double)t + t2; *flops = g_prof[i].flops; *bytes = g_prof[i].bytes;
+    return 1;
+}
+// ALGORITHMIC bytes of the launches recorded so far (call before dic_prof_end): every operand, side input and output of a GEMM once --
+// what a launch would move if nothing were re-fetched and split-K partial sums never left the chip.  bench.py puts it next to the PMC traffic.
+extern "C" double dic_prof_algorithmic_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double b = 0;
+    for (int i = 0; i < g_prof_n; ++i) b += g_prof[i].bytes;
+    return b;
 }
 static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream);
 extern "C" int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* pp, void* stream) {
-    tl_prof = prof_slot(2.0 * pp->M * pp->N * pp->K * (pp->B2 ? 2.0 : 1.0));          // (executed flops: a split-weight launch runs its K loop twice)
+    {
+        const double es = dtype == DIC_BF16 ? 2.0 : 4.0, M = pp->M, N = pp->N, K = pp->K;
+        double by = (M * K + N * K * (pp->B2 ? 2.0 : 1.0)) * es;
+        if (pp->C) by += M * (epi == DIC_EPI_CE_EXP || epi == DIC_EPI_CE_DLOGITS ? (double)pp->ldc : N) * (pp->out_f32 ? 4.0 : es);
+        if (pp->R) by += M * N * es;
+        if (pp->aux) by += M * N * es;
+        if (pp->accumulate) by += M * N * 4.0;
+        tl_prof = prof_slot(2.0 * M * N * K * (pp->B2 ? 2.0 : 1.0), by);          // (executed flops: a split-weight launch runs its K loop twice)
+    }
     const int rc = dic_gemm_impl(dtype, a_km, b_km, epi, pp, stream);
     tl_prof = nullptr;
     return rc;

@@ -520,7 +520,9 @@ __global__ void colsum_stage2(const float* ws, int nslab, int cols, float* out, 
 // 256 columns split the rows (the kernel is a chain of memory round trips: rows / (16 waves x 8 loads in flight) of them),
 // LDS fold in fixed order.
 constexpr int CS_WAVES = 16;
-__global__ __launch_bounds__(64 * CS_WAVES) void colsum_small(const float* in, int rows, int cols, int ld, float* out, int accumulate) {
+__global__ __launch_bounds__(64 * CS_WAVES) void colsum_small(const float* in, int rows, int cols, int ld, float* out, int accumulate,
+                                                              const float* in2 = nullptr, float* out2 = nullptr) {
+    if (blockIdx.y == 1) { in = in2; out = out2; }          // dic_colsum_pair: two independent (in, out) problems of one shape in one launch
     __shared__ f32x4 red[CS_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
@@ -619,10 +621,19 @@ extern "C" size_t dic_colsum_ws_bytes(int in_dtype, int rows, int cols) {
 }
 extern "C" size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D) { return (size_t)n_partial_blocks * n_vectors * D * sizeof(float); }
 
+// Two fp32 column sums of the same shape (rows <= 1024) in ONE launch: the two LayerNorm-backward partial buffers of an encoder layer
+// ([gamma | beta | bias] gradients of sa_layer_norm + out_lin and of output_layer_norm + lin2) are folded together.
+extern "C" int dic_colsum_pair(const float* in0, float* out0, const float* in1, float* out1, int rows, int cols, int ld, void* stream) {
+    DIC_REQUIRE(cols % 4 == 0 && rows > 0 && rows <= 1024 && in0 && in1 && out0 && out1, "dic_colsum_pair: two fp32 problems of <= 1024 rows, cols a multiple of 4");
+    hipLaunchKernelGGL(colsum_small, dim3((cols + 255) / 256, 2), dim3(64 * CS_WAVES), 0, (hipStream_t)stream, in0, rows, cols, ld, out0, 0, in1, out1);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream) {
     DIC_REQUIRE(cols % 4 == 0 && rows > 0, "dic_colsum: cols must be a multiple of 4");
     if (in_dtype == DIC_F32 && rows <= 1024) {
-        hipLaunchKernelGGL(colsum_small, dim3((cols + 255) / 256), dim3(64 * CS_WAVES), 0, (hipStream_t)stream, (const float*)in, rows, cols, ld, out, accumulate);
+        hipLaunchKernelGGL(colsum_small, dim3((cols + 255) / 256), dim3(64 * CS_WAVES), 0, (hipStream_t)stream, (const float*)in, rows, cols, ld, out, accumulate,
+                           (const float*)nullptr, (float*)nullptr);
         DIC_CHECK_LAUNCH();
         return 0;
     }

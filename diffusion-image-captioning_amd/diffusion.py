@@ -80,6 +80,7 @@ def seed_guidance(seed: int, device=None):
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
     _state["cfg_gen"]["cpu"] = g
+    _state["cfg_seed_value"], _state["cfg_draws"] = int(seed) & 0x7FFFFFFFFFFFFFFF, 0       # (what a checkpoint needs to re-derive another rank's stream)
     return g
 
 
@@ -92,7 +93,9 @@ def _guidance_gen():
 
 def _guidance_uniform(n, dev):
     """torch.rand((n, 1)) of ref :407 from the guidance generator (host), returned on `dev`."""
-    return torch.rand((n, 1), generator=_guidance_gen()).to(dev)
+    g = _guidance_gen()
+    _state["cfg_draws"] = _state.get("cfg_draws", 0) + int(n)
+    return torch.rand((n, 1), generator=g).to(dev)
 
 
 def _guidance_draw(model, Nt, cfg_uniform=None):
@@ -103,7 +106,9 @@ def _guidance_draw(model, Nt, cfg_uniform=None):
         u = cfg_uniform.detach().reshape(-1).to("cpu", torch.float32)
         assert u.numel() == Nt
     else:
-        u = torch.rand(Nt, generator=_guidance_gen())
+        g = _guidance_gen()
+        _state["cfg_draws"] = _state.get("cfg_draws", 0) + int(Nt)
+        u = torch.rand(Nt, generator=g)
     cm = u > cfg.CLASSIFIER_FREE_PROB
     if model.rank_rows_forced:
         cm[0] = False
@@ -141,6 +146,11 @@ def _next_t_seed() -> int:
     per-step collective (`parallel.assert_shared_timestep_seed` checks it)."""
     if "t_seed" not in _state:
         _state["t_seed"] = (T_SEED_BASE + (torch.initial_seed() & 0x3FFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+        from . import parallel
+        if parallel.world_size() > 1:
+            # torch.initial_seed() differs per process: a data-parallel run that never called parallel.configure_model_for_rank would draw a
+            # different t on every rank (ref :461 shares one t-vector over the whole batch) -- take rank 0's start, once
+            parallel.share_timestep_seed()
     _state["t_seed"] += 1
     return _state["t_seed"]
 
@@ -170,25 +180,42 @@ def seed_all(seed: int, device=None):
 
 def rng_state(model=None) -> dict:
     """Everything a resumed run needs to continue the SAME random streams (harness.save_checkpoint stores it): the timestep counter, the
-    q_sample noise counter, the guidance generators and, given the model, its dropout-mask counter."""
-    st = {"t_seed": _state.get("t_seed"), "noise_seed": _state["noise_seed"],
-          "guidance": {k: g.get_state().cpu() for k, g in _state["cfg_gen"].items()}}
+    q_sample noise counter, the guidance generator and, given the model, its dropout-mask counter -- together with the data-parallel RANK
+    they belong to: noise, dropout masks and guidance draws are per-rank streams (parallel.configure_model_for_rank), so a checkpoint written
+    by one rank must not hand ITS streams to every rank that loads it (set_rng_state re-derives the others from it)."""
+    from . import parallel
+    _guidance_gen()
+    st = {"t_seed": _state.get("t_seed"), "noise_seed": _state["noise_seed"], "rank": parallel.rank(),
+          "guidance": {k: g.get_state().cpu() for k, g in _state["cfg_gen"].items()},
+          "guidance_seed": _state.get("cfg_seed_value"), "guidance_draws": _state.get("cfg_draws", 0)}
     if model is not None:
         st["dropout_seed"] = int(model._seed)
     return st
 
 
 def set_rng_state(st: dict, model=None):
+    """Continue the streams of `rng_state`.  The timestep stream is shared by all ranks and restored as saved.  The per-item streams (noise,
+    dropout, guidance) are restored exactly on the rank that saved them and SHIFTED by the rank difference on every other rank, the same way
+    parallel.rank_seed separates them at start-up -- every rank loading rank 0's checkpoint keeps drawing its own eps / masks / guidance rows.
+    (A guidance generator cannot be shifted: another rank reseeds it from the saved seed, the rank mix and the number of draws so far.)
+    Checkpoints from before round 4 carry no rank (= 0) and may name the guidance generator 'cuda:0': it lives on the host now."""
+    from . import parallel
+    r, sr = parallel.rank(), int(st.get("rank", 0) or 0)
+    shift = (r - sr) * parallel._RANK_MIX
     if st.get("t_seed") is not None:
         _state["t_seed"] = int(st["t_seed"])
-    _state["noise_seed"] = int(st["noise_seed"])
-    for k, gs in st.get("guidance", {}).items():
-        g = _state["cfg_gen"].get(k)
-        if g is None:
-            g = _state["cfg_gen"][k] = torch.Generator(device=torch.device(k))
-        g.set_state(gs)
+    _state["noise_seed"] = (int(st["noise_seed"]) + shift) & 0xFFFFFFFFFFFFFFFF
+    gstates = list(st.get("guidance", {}).values())
+    if r == sr and gstates:
+        g = _guidance_gen()
+        g.set_state(gstates[0])                        # (one generator, whatever device key an old checkpoint filed it under)
+        _state["cfg_seed_value"], _state["cfg_draws"] = st.get("guidance_seed"), int(st.get("guidance_draws", 0) or 0)
+    elif r != sr:
+        base = st.get("guidance_seed")
+        base = GUIDANCE_SEED_BASE if base is None else int(base)
+        seed_guidance((base + int(st.get("guidance_draws", 0) or 0) * 0x9E3779B1 + shift) & 0x7FFFFFFFFFFFFFFF)
     if model is not None and "dropout_seed" in st:
-        model._seed = int(st["dropout_seed"])
+        model._seed = (int(st["dropout_seed"]) + shift) & 0x7FFFFFFFFFFFFFFF
 
 
 def _t_one(dev):
@@ -559,11 +586,14 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
                 lo = store.off(f"L{i}.Wqkv")
                 hi = store.off(f"L{i + 1}.Wqkv") if i + 1 < store.n_layers else store.off("pos")
                 trainer.step_range(lo, hi)
-        model.backward(layer_done=layer_done)
-        if model.te:
-            from . import train_embedding
-            train_embedding.backward_tail(model, t, None if cfg.X_0_PREDICTION else t_next)   # projections, q_sample, embedding (x_0 carries gradient)
-        reducer.finish(trainer)
+        try:
+            model.backward(layer_done=layer_done)
+            if model.te:
+                from . import train_embedding
+                train_embedding.backward_tail(model, t, None if cfg.X_0_PREDICTION else t_next)   # projections, q_sample, embedding (x_0 carries gradient)
+            reducer.finish(trainer)
+        finally:
+            model.ops.default_cu_cap = 0          # (DIC_DP_CU_CAP: a failed backward / collective must not leave validation and sampling capped)
         if not isinstance(trainer, AdamW):
             model.params.relink_grads()
         trainer.step()
@@ -631,6 +661,13 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
         t_later = torch.ones(B, dtype=torch.int32, device=dev)
     x_view = (restored.data_ptr(), restored.shape[1] * 768, B, L)
     x_out, graph = None, None
+    if steps <= 0:                                            # no refinement pass: round the start tensor itself (the reference's loop body never runs)
+        x = restored[:, :L, :].contiguous()
+        _, ids, _ = model.rounding(x.reshape(B * L, 768), B * L, dtype=_lib.DIC_F32)
+        ids = ids.clone().reshape(B, L)
+        return (ids, restored.clone()) if return_hidden else ids
+    # a replayed pass re-uses the captured dropout seed: only capture when no mask is drawn (eval mode, or p = 0)
+    no_dropout = (not model.training) or (model.p_hidden == 0.0 and model.p_attn == 0.0)
     # a forward-only pass is one stream of kernels: its GEMMs may finish their last round with shorter tiles (include/dic_hip.h,
     # dic_gemm_set_two_heights; 7.56 -> 7.47 ms per pass at B = 2048 -- the training step keeps the switch off)
     lib = _lib.lib()
@@ -643,15 +680,19 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
             if k >= 1:
                 x_view = (x_out.data_ptr(), Tk * 768, B, L)
             run = lambda: model.encode(None, None, None, None, drop_txt=drop_txt, x_view=x_view, inputs_ready=k > 0, tidx=t_first if k == 0 else t_later)
-            if _SAMPLE_GRAPH and k == 2 and steps >= 8 and not _os.environ.get("DIC_SAMPLE_GRAPH_OFF"):
+            if _SAMPLE_GRAPH and no_dropout and k == 2 and steps >= 8 and not _os.environ.get("DIC_SAMPLE_GRAPH_OFF"):
+                seed_before = model._seed
                 try:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         run()
                     graph.replay()
                     continue
-                except Exception:                             # capture not possible here: run the loop launch by launch
+                except Exception as e:                        # capture not possible here: run the loop launch by launch, and say so
+                    import warnings
+                    warnings.warn(f"sample(): hipGraph capture of a denoising pass failed ({type(e).__name__}: {e}); running launch by launch")
                     graph = None
+                    model._seed = seed_before
             x_out = run()
     finally:
         lib.dic_gemm_set_two_heights(prev_two)

@@ -76,6 +76,7 @@ _GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GEL
 # bf16 engine: FFN-1's forward epilogue leaves gelu'(u) behind instead of u (same bytes), so the backward's epilogue is one multiply (MUL_AUX)
 # instead of erf + exp per element (round-3 review item 3; "0": the round-3 form, kept as the A/B partner and for the fp32 engine)
 _GELU_D = _os.environ.get("DIC_GELU_D", "1") != "0"
+_PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"   # the two LayerNorm-gradient folds of a layer in one launch (A/B switch)
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
@@ -497,7 +498,9 @@ class Denoiser:
         # SLOWER with the weight gradients on their second stream -- a 256-workgroup persistent kernel holding 128 KB of LDS per CU for
         # ~400 us keeps the main stream's GEMMs off the CUs for that long, ~100 us launches interleave with them.  The default, 2, groups only
         # out-proj + qkv, the two with too few tiles to split well on their own (9 + 27 tiles x 7 slices = one round): 0.5-0.8 % on the step.
-        gmode = _os.environ.get("DIC_WGRAD_GROUP", "2")       # "0": none; "1": every Linear of the layer; "2": out-proj + qkv
+        # Round 4 re-measured with the halves (DIC_WGRAD_GROUP_HALVES, below): "1" = [lin2, lin1] as one launch and [out-proj, qkv] as another
+        # ties "2" on the two-stream step (13.93 vs 13.93 ms, profiles/r04_wgrad_group_ab.txt) with 24 launches fewer per step -> default "1".
+        gmode = _os.environ.get("DIC_WGRAD_GROUP", "1")       # "0": none; "1": every Linear of the layer (two halves); "2": out-proj + qkv only
         group = self.bf16 and gmode in ("1", "2")
         items = []
 
@@ -540,6 +543,10 @@ class Denoiser:
             so the fold runs on the weight-gradient stream (one launch + one dependent-launch gap less on the main stream per LayerNorm)."""
             on_side(lambda: _lib.check(lib.dic_colsum(DIC_F32, pbuf, NPART, cols, cols, dst, 0, csw, o.stream), "colsum"))
 
+        def fold2(pbuf0, dst0, pbuf1, dst1, cols):
+            """The two LayerNorm folds of one encoder layer as ONE launch (round 4: 12 launches fewer per step)."""
+            on_side(lambda: _lib.check(lib.dic_colsum_pair(pbuf0, dst0, pbuf1, dst1, NPART, cols, cols, o.stream), "colsum_pair"))
+
         def finish_layer(j):
             """dW launches of layer j are queued: mark it, and hand the layer's gradient slice to the data-parallel reducer."""
             flush_group()
@@ -578,7 +585,8 @@ class Denoiser:
             # output_layer_norm backward; bias grad of lin2 folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
                                       _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
-            fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                              # [ln2g | ln2b | b2]
+            if not _PAIR_FOLDS:
+                fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                          # [ln2g | ln2b | b2]
             dyd = dyd_ if use_drop else dy_
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_MUL_AUX if ws["gelu_d"] else EPI_GELU_BWD,
@@ -591,7 +599,10 @@ class Denoiser:
             # sa_layer_norm backward; bias grad of out_lin folded in
             _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
                                       0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
-            fold(parts[2 * sp + 1], 3 * D, P.ptr(pre + "ln1g", "G"))                          # [ln1g | ln1b | bo]
+            if _PAIR_FOLDS:                                                                   # [ln2g | ln2b | b2] and [ln1g | ln1b | bo] in one launch
+                fold2(parts[2 * sp], P.ptr(pre + "ln2g", "G"), parts[2 * sp + 1], P.ptr(pre + "ln1g", "G"), 3 * D)
+            else:
+                fold(parts[2 * sp + 1], 3 * D, P.ptr(pre + "ln1g", "G"))                      # [ln1g | ln1b | bo]
             wgrad(_p(dy1_), _p(Lw["ctx"]), pre + "Wo", D, D, D, D)
             o.gemm(_p(dy1_), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
             _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(dqkv_), N, Tk, self.n_heads, 64, pa,

@@ -151,6 +151,10 @@ int dic_step_advance(int64_t* ctr, void* stream);
  * use.  The only other shared state of the library: dic_last_error's message buffer, dic_gemm_set_variant, dic_step_ctx_set. */
 int dic_prof_begin(int max_launches);
 int dic_prof_end(double* total_ms, double* total_flops, int* n_launches);
+/* ALGORITHMIC bytes of the launches recorded since dic_prof_begin (call before dic_prof_end): each operand, side input and output once. */
+double dic_prof_algorithmic_bytes(void);
+/* record i of the armed window (after a stream synchronise, before dic_prof_end): kernel milliseconds (GEMM + its slab fold), flops, algorithmic bytes; 0 = past the end */
+int dic_prof_get(int i, double* ms, double* flops, double* bytes);
 
 /* Reduce CE_PARTIAL output: lse[m], argmax[m] (first index of the max, as torch.argmax), nll[m] = lse - tgt_logit.
  * ref:436-437 (-log softmax gathered at the true id) and ref:620 (softmax.argmax).                               */
@@ -290,6 +294,9 @@ int dic_seq_sum(const float* in, const uint8_t* flags, float* out_all, float* ou
 /* ---------------------------------------------------------------- reductions for bias / LN / embedding grads
  * out[c] (+)= sum_r in[r][c]; in dtype f32 (in_dtype 0) or bf16 (1); two-stage, deterministic; ws >= 64*cols f32 */
 int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* out, int accumulate, float* ws, void* stream);
+/* two fp32 problems of one shape (rows <= 1024) in one launch: out0[c] = sum_r in0[r][c], out1[c] = sum_r in1[r][c] -- the two LayerNorm-backward
+ * partial buffers of an encoder layer (hf:236, 253 backward: gamma / beta / bias gradients) */
+int dic_colsum_pair(const float* in0, float* out0, const float* in1, float* out1, int rows, int cols, int ld, void* stream);
 
 /* ---------------------------------------------------------------- AdamW (ref:335 -- torch defaults, decoupled wd on every tensor)
  * p,g,m,v flat f32 [n]; g is multiplied by grad_scale first (1/world_size after the RCCL sum);

@@ -63,7 +63,7 @@ ls = torch.tensor([float(l1)], dtype=torch.float64)
 torch.distributed.all_reduce(ls)
 l_dp = float(ls) / world
 g = m.params.G * (1.0 / world)
-tol_l, tol_g = (2e-5, 2e-4) if dtype == "fp32" else (3e-3, 5e-2)
+tol_l, tol_g = (2e-5, 2e-4) if dtype == "fp32" else (3e-3, 5e-2)          # (bf16 / bf16w: shard batches of 1-4 captions round differently from the full batch)
 err_l = abs(l_dp - l0) / abs(l0)
 err_g = float((g - g0).abs().max() / g0.abs().max())
 red = dic.parallel.GradReducer.last

@@ -17,7 +17,12 @@ local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 dev = torch.device("cuda", local)
-t = dic.parallel.shared_randint(0, 100, (4, 1, 1), dev)
+dic.cfg.update(STEP_TOT=100)
+dic.parallel.share_timestep_seed()                         # every rank continues rank 0's timestep counter ...
+t = importlib.import_module("diffusion-image-captioning_amd.diffusion")._draw_t(4, dev)
+tt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+dist.all_gather(tt, t)                                      # ... so the t-vector drawn on the device is the same everywhere, with no per-step collective
+assert all(torch.equal(tt[0], x) for x in tt), "ranks drew different timesteps"
 g = torch.ones(86_830_848 + 4096, device=dev)             # 12-layer flat gradient buffer
 dist.all_reduce(g)
 torch.cuda.synchronize()

@@ -19,7 +19,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     dic.build()
     L = dic.lib()
     header = open(os.path.join(ROOT, "include", "dic_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(dic_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|double|const char\*)\s+(dic_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 25, declared
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
@@ -337,3 +337,47 @@ def test_product_alpha_cumprod_tables_match_the_reference_host():
     finally:
         dic.cfg.update(**saved)
         diffusion.set_alpha_cumprod(None)
+
+
+def test_checkpointed_rng_streams_are_rederived_per_rank(monkeypatch):
+    """Advisor finding (round 3): harness.load_checkpoint restored the SAVING rank's noise / dropout / guidance streams on every rank.  A state
+    saved by rank 0 and loaded on rank 2 must keep the shared timestep counter but shift the per-item streams by the rank mix -- exactly the
+    separation parallel.configure_model_for_rank sets up at start -- and loading on the saving rank must restore everything as saved,
+    guidance generator included (also from a pre-round-4 state that filed it under 'cuda:0' and carries no rank)."""
+    import torch
+    diffusion = importlib.import_module("diffusion-image-captioning_amd.diffusion")
+    parallel = dic.parallel
+
+    class M:
+        _seed = 12345
+    diffusion.seed_all(5)
+    diffusion._state["t_seed"] = 777
+    u0 = diffusion._guidance_uniform(7, "cpu")          # advance the guidance generator a little
+    st = diffusion.rng_state(M())
+    assert st["rank"] == 0 and st["guidance_draws"] == 7
+    nxt = diffusion._guidance_uniform(5, "cpu")
+    # same rank: exact continuation
+    diffusion.seed_all(99)
+    m = M(); m._seed = 1
+    diffusion.set_rng_state(st, m)
+    assert diffusion._state["t_seed"] == 777 and diffusion._state["noise_seed"] == st["noise_seed"] and m._seed == 12345
+    assert torch.equal(diffusion._guidance_uniform(5, "cpu"), nxt)
+    # legacy layout: generator under a device key, no rank
+    legacy = {"t_seed": 777, "noise_seed": st["noise_seed"], "guidance": {"cuda:0": st["guidance"]["cpu"]}, "dropout_seed": 12345}
+    diffusion.seed_all(99)
+    diffusion.set_rng_state(legacy, m)
+    assert torch.equal(diffusion._guidance_uniform(5, "cpu"), nxt)
+    # another rank: shared t, shifted per-item streams, its own guidance draws
+    monkeypatch.setattr(parallel, "rank", lambda: 2)
+    m2 = M(); m2._seed = 1
+    diffusion.set_rng_state(st, m2)
+    assert diffusion._state["t_seed"] == 777
+    assert diffusion._state["noise_seed"] == (st["noise_seed"] + 2 * parallel._RANK_MIX) & 0xFFFFFFFFFFFFFFFF
+    assert m2._seed == (12345 + 2 * parallel._RANK_MIX) & 0x7FFFFFFFFFFFFFFF and m2._seed != 12345
+    assert not torch.equal(diffusion._guidance_uniform(5, "cpu"), nxt)
+    # ... and saved by rank 2, loaded by rank 2: as saved
+    st2 = diffusion.rng_state(m2)
+    assert st2["rank"] == 2
+    nxt2 = diffusion._guidance_uniform(3, "cpu")
+    diffusion.set_rng_state(st2, m2)
+    assert torch.equal(diffusion._guidance_uniform(3, "cpu"), nxt2)
