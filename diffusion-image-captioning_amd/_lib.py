@@ -19,7 +19,7 @@ DIC_F32, DIC_BF16 = 0, 1
 EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [
-    "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
+    "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_set_w4a", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_colsum_pair", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end", "dic_prof_algorithmic_bytes", "dic_prof_get",
@@ -62,7 +62,7 @@ def build(verbose: bool = False, force: bool = False, variants: bool = False) ->
     variants: -DDIC_GEMM_VARIANTS, the measurement build that also carries the round-3 K-loop alternatives (gemm_pp.h, gemm_w4.h)."""
     global LAST_BUILD
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "gemm_w4a.h", "gemm_w4a_asm.inc")] + [os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
     if not force and not variants and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         LAST_BUILD = "reused"
         return LIB_PATH
@@ -157,6 +157,7 @@ def lib():
         L.dic_cast_bf16_hl.argtypes = [P, P, P, I64, P]
         L.dic_probe_tr16.argtypes = [P, P, P]
         L.dic_gemm_set_variant.argtypes = [I]
+        L.dic_gemm_set_w4a.argtypes = [I]
         L.dic_prof_begin.argtypes = [I]
         L.dic_prof_algorithmic_bytes.restype = C.c_double
         L.dic_prof_algorithmic_bytes.argtypes = []

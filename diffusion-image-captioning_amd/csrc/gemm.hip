@@ -1560,6 +1560,8 @@ bool rows_enabled() {
     return v == 1;
 }
 
+#include "gemm_w4a.h"         // gemm_w4a_kernel: the hand-scheduled four-wave kernel (round 4; DIC_GEMM_W4A)
+
 // Tile height for a k-contiguous A (the token dimension of the forward / input-gradient GEMMs).  With full-height tiles the tile count
 // rarely fills whole rounds of resident workgroups (17 408 tokens x 768 columns = 204 tiles of 256x256 on 256 CUs: one round at 80 %;
 // x 2304: 612 = 2.39 rounds run as 3), and a persistent grid cannot rebalance inside a round.  Tiles may be any multiple of 32 rows
@@ -1889,6 +1891,12 @@ extern "C" int dic_gemm_set_variant(int v) {
     return 1006;
 #endif
 }
+// process-global measurement / test switch: 1 = eligible forward GEMMs run on the hand-scheduled four-wave kernel (gemm_w4a.h).  Returns the previous value.
+extern "C" int dic_gemm_set_w4a(int on) {
+    const int prev = w4a_mode();
+    g_w4a = on ? 1 : 0;
+    return prev;
+}
 // process-global measurement / test switch: 1 = launches may use two tile heights (default), 0 = one height per launch.  Returns the previous value.
 extern "C" int dic_gemm_set_two_heights(int on) {
     const int prev = two_heights_enabled() ? 1 : 0;
@@ -2020,6 +2028,11 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
                     "dic_gemm: CE_EXP is a bf16 epilogue (LDS-DMA kernels); needs C, lse (reference points), partial, tgt_logit and an ldc that covers N within the last tile");
     if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % (dtype == DIC_BF16 ? 8 : 4) == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
+    if (w4a_mode() == 1 && w4a_eligible(dtype, a_km, b_km, epi, p) && p.tile == 256) {
+        launch_w4a(p, st);
+        DIC_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == DIC_BF16) return launch_layout<bf16_t>(p, a_km, b_km, epi, st);
     if (dtype == DIC_F32) return launch_layout<float>(p, a_km, b_km, epi, st);
     dic_set_error("dic_gemm: unknown dtype");

@@ -131,6 +131,11 @@ int dic_gemm_set_variant(int pp);
  * depend on its height).  Returns the previous setting.  Pays on single-stream forward passes (the sampling loop turns it on), costs on the
  * two-stream training step, where another stream's kernels use the CUs a partial round leaves idle.                                 */
 int dic_gemm_set_two_heights(int on);
+/* Measurement / test switch (PROCESS-GLOBAL; env DIC_GEMM_W4A): 1 = a dic_gemm call inside its scope (bf16, k-contiguous A and B, AFFINE with optional
+ * bias, bf16 output, M and N multiples of 256, K a multiple of 128, tile = 256) runs on the hand-scheduled four-wave kernel (csrc/gemm_w4a.h: one wave per
+ * SIMD, accumulators in the AGPR file, tile loop + K loop + epilogue as one generated assembly block) instead of the 8-wave kernel.  Same tile order,
+ * LDS image and MFMA order; the bias is added after the K loop instead of before it (last-bit differences).  Returns the previous setting.       */
+int dic_gemm_set_w4a(int on);
 /* host-only: the plan for an M x N x K forward problem on this device -- out[0] / out[1] = 16-row fragments per wave of the tall / the
  * last-round tiles (out[0] == 0: one height), out[2] = rows covered by the tall tiles */
 int dic_gemm_two_heights_plan(int M, int N, int K, int cu_cap, int* out3);
