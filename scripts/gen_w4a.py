@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""Generator of the hand-scheduled four-wave GEMM main loop (csrc/gemm_w4a_asm.inc), round 4.
+"""Generator of the hand-scheduled four-wave GEMM main loops (csrc/gemm_w4a_asm.inc), round 4.
 
-Why a generator: the loop is ONE inline-asm statement per kernel -- persistent tile loop, software-pipelined K loop, epilogue -- with
+Why a generator: each loop is ONE inline-asm statement per kernel -- persistent tile loop, software-pipelined K loop, epilogue -- with
 explicit register numbers (accumulators in a[0:255], operand fragments in v[0:95]; nothing is left to the compiler's allocator or
 scheduler: round-3 review item 2).  A few hundred MFMAs with their fillers and counted waits are not something to type by hand; this script
 places them and COUNTS the waits (every `s_waitcnt lgkmcnt(n)` is derived from the issue order it has just generated).
 
 Geometry (fixed): workgroup 256 threads = 4 waves as 2 x 2, tile 256 x 256 x 64, wave tile 128 x 128 = 8 x 8 fragments of 16 x 16,
 `v_mfma_f32_16x16x32_bf16` with the operands swapped (D = Bfrag x Afrag: a lane holds 4 consecutive output columns), LDS image and
-output mapping those of the 8-wave kernel in gemm.hip (same swizzle keys, same B-row permutation, same full-line stores), so the two
-kernels produce identical results.
+output mapping those of the 8-wave kernel in gemm.hip (same swizzle keys, same B-row permutation, same full-line stores and side-input
+loads), so the two kernels produce the same results (the bias is added after the K loop here: last-bit differences).
 
-LDS (bytes): A stage 0 [0, 32K), A stage 1 [32K, 64K), B stage 0 [64K, 96K), B stage 1 [96K, 128K), tile table [128K, +16K).
+Variants (one asm body each): B operand k-contiguous (KC: nn.Linear forward) or k-major (KM: input gradients, read with
+ds_read_b64_tr_b16) x epilogue `plain` (+ bias), `resid` (+ bias + residual R), `mulaux` (x aux, the GELU' factor left by the forward).
+
+LDS (bytes): A stage 0 [0, 32K), A stage 1 [32K, 64K), B stage 0 [64K, 96K), B stage 1 [96K, 128K), tile table [128K, +16K: 512 tiles x {16 B of A / B / C offsets + first column, 16 B holding the side-input offset}).
 
 Pipeline per K-step k (stage s = k & 1), two phases of 64 MFMAs (kk = 0, 1), group i = the 8 MFMAs of A fragment i:
   phase 0: MFMAs on B(kk0) x A(kk0)[i]; the B(kk1) set is read into the second B buffer during groups 0-3; A(kk1)[i] is read INTO A(kk0)[i]'s
@@ -20,12 +23,13 @@ Pipeline per K-step k (stage s = k & 1), two phases of 64 MFMAs (kk = 0, 1), gro
            LDS-DMA of K-step k+2 goes into it, 8 pieces before and 8 after barrier E.  At group 5: `s_waitcnt vmcnt(N)`, N = the VMEM
            operations younger than K-step k+1's last DMA piece (the counter is in order) -> barrier E -> stage s^1 (K-step k+1) is visible: its
            B(kk0) set and A(kk0)[0..6] are read during groups 5-7 into registers phase 1 has finished with ([7]: first group of the next step).
-  A K-step's DMA is issued 0.6-1.0 K-steps before the step before it ends and is needed 0.7 K-steps into that step: 1.1-1.3 K-steps of
-  latency budget with 128 KB of LDS (the 8-wave kernel: 1.0, and its K-step then waits for the slowest piece).
+  A K-step's DMA has 1.1-1.3 K-steps to land with 128 KB of LDS (the 8-wave kernel: 1.0, and its K-step then waits for the slowest piece).
 Tiles follow each other without a prologue: during a tile's last two K-steps the DMA slots carry the NEXT tile's first two K-steps
-(descriptor swap), so the next tile's fragments are in registers when the epilogue starts, and the epilogue's stores are YOUNGER than
-every load the next K loop waits for (gfx950 has one in-order vmcnt for loads and stores: a wait never has to sit out a store's ~2 us
-acknowledge unless it asks for something issued after it).
+(descriptor swap), and the epilogue's stores are YOUNGER than every load the next K loop waits for (gfx950 has one in-order vmcnt for
+loads and stores: a wait never has to sit out a store's ~2 us acknowledge unless it asks for something issued after it).
+Side inputs (`resid`, `mulaux`): the wave's 128 x 128 tile of R / aux (128 registers) is requested during the tile's LAST K-step, into
+registers that step has finished with (the first B buffer, the A fragments as their groups retire) and 64 high registers -- before any store of
+the epilogue, so its wait does not sit behind one; those variants re-read the next tile's first fragments after the epilogue instead.
 """
 import sys
 
@@ -41,33 +45,27 @@ V_T = 128                # temporaries (24)
 V_VOA = 152              # 8 DMA source offsets (A pieces)
 V_VOB = 160              # 8 (B pieces)
 V_AA = [168, 169]        # A fragment address kk0 / kk1
-V_AB = [170, 171]        # B fragment address kk0 / kk1 (B region base folded in)
-V_CST = 172              # store lane offset (bytes)
-V_BOFF = 173             # bias lane offset (bytes)
-V_TBL = 174              # LDS address of the tile table (same in every lane)
-V_LAST = 179
-S0 = 36
-S_RSA, S_RSB = 36, 40            # DMA descriptors in use (current tile, or the next tile's during the last pair)
-S_NXA, S_NXB = 44, 48            # next tile's
-S_RSC, S_RSBIAS = 52, 56         # output / bias descriptors of the tile being finished
-S_NXC_OFF, S_NXN0 = 60, 61       # next tile's output offset / first column
-S_K = 62                         # k byte offset of the next DMA (soffset)
-S_PAIRS = 63                     # remaining K-step pairs of the tile
-S_TILE = 64                      # tiles left
-S_TMP = 65                       # 65..71 scratch
-S_CUR_C_OFF, S_CUR_N0 = 72, 73
-S_M0A, S_M0B = 74, 75            # LDS destinations of this wave's first A / B piece in stage 0
-S_LDC16, S_LDC8 = 76, 77         # 16 / 8 output rows in bytes
-S_SOFF = 78                      # store soffset cursor
-S_TIDX = 79                      # index of the next table entry to read
-S_NULL = 80                      # 80..83: null descriptor (num_records 0)
-S_BIASB = 84                     # 84,85: bias base or 0; 86: bias bytes
-S_LAST = 91
+V_AB = [170, 171, 172, 173]   # B fragment addresses: KC kk0 / kk1; KM column pair 0..3 (B region base folded in)
+V_CST = 174              # store lane offset (bytes)
+V_BOFF = 175             # bias lane offset (bytes)
+V_TBL = 176              # LDS address of the tile table (same in every lane)
+V_RST = 177              # side-input lane offset (bytes)
+V_LAST = 241             # (v242..v255 stay with the compiler: the statement's nine vector operands live there)
+R_BLOCK = [0, 16, 178, 194, 210, 226, 64, 80]     # first register of side-input block i (16 registers: slab 0 {rows 0-7, rows 8-15}, slab 1 {..})
 
-# operands of the asm statement (gemm_w4a.h must pass them in this order)
-OPS = ["tbl", "voA0", "voBbase", "chunkx", "aA0", "aB0", "cst", "boff",                      # "v"
-       "A_lo", "A_hi", "B_lo", "B_hi", "C_lo", "C_hi", "bias_lo", "bias_hi",                 # "s"
-       "a_bytes", "b_bytes", "c_bytes", "lda64", "ldb16", "ldc2", "pairs", "ntiles", "m0A", "m0B", "bias_bytes"]
+S0 = 24
+S_ARG = 24               # 24..39: A, B, C, bias, R (lo, hi each), M, N, K, lda, ldb, ldc
+S_A, S_Bp, S_C, S_BIAS, S_R, S_M, S_N, S_Kd, S_LDA, S_LDB, S_LDC = 24, 26, 28, 30, 32, 34, 35, 36, 37, 38, 39
+S_LDR, S_ABYTES, S_BBYTES, S_CBYTES, S_RBYTES, S_KSTEPB, S_NPAIRS, S_LDA64, S_LDBP, S_LDC2, S_LDR2, S_BIASBYTES = 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51
+S_RSA, S_RSB, S_NXA, S_NXB, S_RSC, S_RSBIAS, S_RSR, S_NULL = 52, 56, 60, 64, 68, 72, 76, 80
+S_NXC_OFF, S_NXN0, S_CUR_C_OFF, S_CUR_N0, S_KA, S_KB, S_PAIRS, S_TILE, S_TIDX, S_M0A, S_M0B, S_LDC16, S_LDC8, S_SOFF = range(84, 98)
+S_T = 98                 # 98..101 scratch
+S_LDR16, S_LDR8, S_NXR_OFF, S_CUR_R_OFF = 19, 20, 22, 23     # (below S0: listed separately in the clobbers)
+S_EXTRA = [19, 20, 21, 22, 23]
+S_LAST = 101
+
+OPS = ["tbl", "voA0", "voBbase", "chunkx", "aA0", "aB0", "cst", "boff", "rst",          # "v"
+       "karg", "ntiles", "m0A", "m0B"]                                                 # "s" (karg: 64-bit)
 OP = {n: f"%{i}" for i, n in enumerate(OPS)}
 
 
@@ -80,21 +78,19 @@ class Asm:
     def __call__(self, s):
         self.l.append(s)
 
-    def read(self, tag, text):
-        self.lds.append(tag)
+    def read(self, tag, text, n=1):
+        for _ in range(n):
+            self.lds.append(tag)
         self(text)
 
     def wait_lds(self, *tags):
-        """wait until the reads tagged `tags` have returned: LDS reads return in order, so everything issued after the youngest of them
-        may stay outstanding"""
-        idx = max(i for i, t in enumerate(self.lds) if t in tags)
+        """wait until the reads tagged `tags` have returned: LDS reads return in order, so everything issued after the youngest of them may
+        stay outstanding.  The counter has 4 bits: with 15 or more younger reads the hardware has already stalled until the target returned."""
         assert all(t in self.lds for t in tags), tags
+        idx = max(i for i, t in enumerate(self.lds) if t in tags)
         n = len(self.lds) - 1 - idx
-        assert n <= 15, (tags, n)
-        self(f"s_waitcnt lgkmcnt({n})")
-
-    def wait_lds_all(self):
-        self("s_waitcnt lgkmcnt(0)")
+        if n < 15:
+            self(f"s_waitcnt lgkmcnt({n})")
 
     def label(self, stem):
         self.uid += 1
@@ -113,285 +109,427 @@ def mfma(a, i, j, kk, first):
     a(f"v_mfma_f32_16x16x32_bf16 a[{d}:{d + 3}], v[{b}:{b + 3}], v[{av}:{av + 3}], {c}")
 
 
-def b_frag_off(j):
-    return (32 * (j >> 1) + 4 * (j & 1)) * 128
+class Gen:
+    def __init__(self, bkm, epi):
+        self.bkm, self.epi = bkm, epi
+        self.a = Asm()
+        self.gen = 0
+        self.side = epi in ("resid", "mulaux")
 
+    # ---------------------------------------------------------------- fragment reads / DMA
+    def read_b(self, j, kk, stage, gen):
+        a = self.a
+        r = V_B[kk] + 4 * j
+        st = B_ST[stage] - B_ST[0]
+        if not self.bkm:
+            a.read(("B", gen, kk, j), f"ds_read_b128 v[{r}:{r + 3}], v{V_AB[kk]} offset:{st + (32 * (j >> 1) + 4 * (j & 1)) * 128}")
+        else:   # k-major tile [64 k][512 B]: two transpose reads (k rows 8g+{0..3} and +4), column pair j>>1 has its own address, parity = +8 B
+            off = st + kk * 32 * 512 + (j & 1) * 8
+            a.read(("B", gen, kk, j), f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{V_AB[j >> 1]} offset:{off}")
+            a.read(("B", gen, kk, j), f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{V_AB[j >> 1]} offset:{off + 4 * 512}")
 
-def read_b(a, j, kk, stage, gen):
-    r = V_B[kk] + 4 * j
-    a.read(("B", gen, kk, j), f"ds_read_b128 v[{r}:{r + 3}], v{V_AB[kk]} offset:{(B_ST[stage] - B_ST[0]) + b_frag_off(j)}")
+    def read_a(self, i, kk, stage, gen):
+        r = V_A + 4 * i
+        self.a.read(("A", gen, kk, i), f"ds_read_b128 v[{r}:{r + 3}], v{V_AA[kk]} offset:{A_ST[stage] + i * 2048}")
 
-
-def read_a(a, i, kk, stage, gen):
-    r = V_A + 4 * i
-    a.read(("A", gen, kk, i), f"ds_read_b128 v[{r}:{r + 3}], v{V_AA[kk]} offset:{A_ST[stage] + i * 2048}")
-
-
-def dma_piece(a, p, stage):
-    """piece p of the wave's 16 per K-step (0-7: A rows, 8-15: B rows) into `stage`; source = descriptors in use, soffset S_K"""
-    if p < 8:
-        a(f"s_add_u32 m0, s{S_M0A}, {A_ST[stage] + p * NW * 1024}")
-        a("s_nop 0")
-        a(f"buffer_load_dwordx4 v{V_VOA + p}, s[{S_RSA}:{S_RSA + 3}], s{S_K} offen lds")
-    else:
-        q = p - 8
-        a(f"s_add_u32 m0, s{S_M0B}, {(B_ST[stage] - B_ST[0]) + q * 1024}")
-        a("s_nop 0")
-        a(f"buffer_load_dwordx4 v{V_VOB + q}, s[{S_RSB}:{S_RSB + 3}], s{S_K} offen lds")
-
-
-GEN = [0]
-
-
-def gen_step(a, stage, first, n_e, bias_loads=False):
-    """One K-step on `stage`.  first: the accumulators start from 0 (phase 0 takes the inline constant as C).  n_e: vmcnt count of barrier E.
-    bias_loads: the 8 bias-quad loads of this tile ride in phase 0 (older than everything the tile's later waits ask for)."""
-    g0 = GEN[0]            # generation number of this step's fragments (tags)
-    GEN[0] += 1
-    # ---------------- phase 0: fillers by (group, slot)
-    fill = {}
-    for j in range(8):
-        fill[(j // 2, 2 + j % 2)] = lambda j=j: read_b(a, j, 1, stage, g0)   # (not in the first slots: the previous phase's last MFMAs read this buffer)
-    fill[(0, 5)] = lambda: read_a(a, 7, 0, stage, g0)                      # the last A(kk0) fragment (its registers were busy until now)
-    for i in range(7):
-        fill[(i + 1, 5)] = lambda i=i: read_a(a, i, 1, stage, g0)          # A(kk1)[i] over A(kk0)[i], half a group after its MFMAs
-    if bias_loads:
-        for j in range(8):
-            off = (32 * (j >> 1) + 4 * (j & 1)) * 4
-            fill[(4 + j // 2, 1 + j % 2)] = lambda j=j, off=off: a(
-                f"buffer_load_dwordx4 v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 3}], v{V_BOFF}, s[{S_RSBIAS}:{S_RSBIAS + 3}], 0 offen offset:{off}")
-    for i in range(8):
-        if i == 0:
-            a.wait_lds(("B", g0, 0, 7), ("A", g0, 0, 0))
+    def dma_piece(self, p, stage):
+        a = self.a
+        if p < 8:
+            a(f"s_add_u32 m0, s{S_M0A}, {A_ST[stage] + p * NW * 1024}")
+            a("s_nop 0")
+            a(f"buffer_load_dwordx4 v{V_VOA + p}, s[{S_RSA}:{S_RSA + 3}], s{S_KA} offen lds")
         else:
-            a.wait_lds(("A", g0, 0, i))
+            q = p - 8
+            a(f"s_add_u32 m0, s{S_M0B}, {(B_ST[stage] - B_ST[0]) + q * 1024}")
+            a("s_nop 0")
+            a(f"buffer_load_dwordx4 v{V_VOB + q}, s[{S_RSB}:{S_RSB + 3}], s{S_KB} offen lds")
+
+    def side_load(self, blk, n):
+        """load n (0..3) of side-input block blk: slab n >> 1, row half n & 1"""
+        r = R_BLOCK[blk] + 4 * n
+        a = self.a
+        a(f"s_mul_i32 s{S_T}, s{S_LDR16}, {blk}")
+        a(f"s_add_u32 s{S_T}, s{S_T}, {128 * (n >> 1)}")
+        if n & 1:
+            a(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDR8}")
+        a(f"buffer_load_dwordx4 v[{r}:{r + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen")
+
+    # ---------------------------------------------------------------- one K-step
+    def step(self, stage, first=False, n_e=8, bias_loads=False, last_of_tile=False):
+        """first: accumulators start from 0.  n_e: vmcnt count of barrier E (None: no wait, only the barrier).  bias_loads: the tile's 8 bias
+        quads ride in phase 0.  last_of_tile (side-input variants): no prefetch of the next tile's fragments; the side tile is requested."""
+        a = self.a
+        g0 = self.gen
+        self.gen += 1
+        fill = {}
+
+        def put(key, f):
+            fill.setdefault(key, []).append(f)
         for j in range(8):
-            mfma(a, i, j, 0, first)
-            if (i, j) in fill:
-                fill[(i, j)]()
-    # ---------------- phase 1
-    for i in range(8):
-        slots = {}
-        if i == 0:
-            a.wait_lds(("B", g0, 1, 7), ("A", g0, 1, 0))
-            slots[5] = [lambda: read_a(a, 7, 1, stage, g0)]
-        elif i == 1:
-            a.wait_lds(("A", g0, 1, 1))
-        elif i == 2:
-            a.wait_lds_all()                              # every read of this stage is back ...
-            a("s_barrier")                                # ... barrier M: in every wave -> the stage is free
-        if 2 <= i <= 4:                                   # DMA of K-step k+2, pieces 0-7 before barrier E
-            lo, hi = {2: (0, 3), 3: (3, 6), 4: (6, 8)}[i]
-            for n, p in enumerate(range(lo, hi)):
-                slots[1 + 2 * n] = [lambda p=p: dma_piece(a, p, stage)]
-        if i == 5:
-            a(f"s_waitcnt vmcnt({n_e})")                  # K-step k+1 has landed (this wave's pieces) ...
-            a("s_barrier")                                # ... barrier E: everybody's
+            put((j // 2, 2 + j % 2), lambda j=j: self.read_b(j, 1, stage, g0))      # (not the first slots: the previous phase's last MFMAs read this buffer)
+        put((0, 5), lambda: self.read_a(7, 0, stage, g0))                             # the last A(kk0) fragment (its registers were busy until now)
+        for i in range(7):
+            put((i + 1, 5), lambda i=i: self.read_a(i, 1, stage, g0))                 # A(kk1)[i] over A(kk0)[i], half a group after its MFMAs
+        if bias_loads:
             for j in range(8):
-                slots[j] = [lambda j=j: read_b(a, j, 0, stage ^ 1, g0 + 1)]
-        if i == 6:
-            for q in range(5):
-                slots[q] = [lambda q=q: read_a(a, q, 0, stage ^ 1, g0 + 1)]
-            for n, p in enumerate(range(8, 11)):
-                slots[5 + n] = [lambda p=p: dma_piece(a, p, stage)]
-        if i == 7:
-            slots[0] = [lambda: read_a(a, 5, 0, stage ^ 1, g0 + 1)]
-            for n, p in enumerate(range(11, 16)):
-                slots[1 + n] = [lambda p=p: dma_piece(a, p, stage)]
+                off = (32 * (j >> 1) + 4 * (j & 1)) * 4
+                put((4 + j // 2, j % 2), lambda j=j, off=off: a(
+                    f"buffer_load_dwordx4 v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 3}], v{V_BOFF}, s[{S_RSBIAS}:{S_RSBIAS + 3}], 0 offen offset:{off}"))
+        for i in range(8):
+            if i == 0:
+                a.wait_lds(("B", g0, 0, 7), ("A", g0, 0, 0))
+            else:
+                a.wait_lds(("A", g0, 0, i))
+            for j in range(8):
+                mfma(a, i, j, 0, first)
+                for f in fill.get((i, j), []):
+                    f()
+        # ---------------- phase 1
+        side_q = []
+        if last_of_tile and self.side:
+            # side-input blocks 0-5 (24 loads) into the first B buffer and the high registers: before barrier E; block 6 (A[0..3]) after group 4
+            side_q = [(blk, n) for blk in range(6) for n in range(4)]
+        n_side_before_e = len(side_q)
+        for i in range(8):
+            slots = {}
+
+            def sput(j, f):
+                slots.setdefault(j, []).append(f)
+            if i == 0:
+                a.wait_lds(("B", g0, 1, 7), ("A", g0, 1, 0))
+                sput(5, lambda: self.read_a(7, 1, stage, g0))
+            elif i == 1:
+                a.wait_lds(("A", g0, 1, 1))
+            elif i == 2:
+                a("s_waitcnt lgkmcnt(0)")                     # every read of this stage is back ...
+                a("s_barrier")                                # ... barrier M: in every wave -> the stage is free
+            if i <= 4 and side_q:
+                for s_ in (0, 2, 4, 6, 7)[: (5 if i < 4 else 4)]:
+                    if side_q:
+                        blk, n = side_q.pop(0)
+                        sput(s_, lambda blk=blk, n=n: self.side_load(blk, n))
+            if 2 <= i <= 4:                                   # DMA of K-step k+2, pieces 0-7 before barrier E
+                lo, hi = {2: (0, 3), 3: (3, 6), 4: (6, 8)}[i]
+                for n, p in enumerate(range(lo, hi)):
+                    sput(1 + 2 * n, lambda p=p: self.dma_piece(p, stage))
+            if i == 5:
+                assert not side_q
+                if n_e is not None:
+                    a(f"s_waitcnt vmcnt({n_e + n_side_before_e})")   # K-step k+1 has landed (this wave's pieces) ...
+                a("s_barrier")                                # ... barrier E: everybody's
+                if not (last_of_tile and self.side):
+                    for j in range(8):
+                        sput(j, lambda j=j: self.read_b(j, 0, stage ^ 1, g0 + 1))
+                else:
+                    for n in range(4):
+                        sput(2 * n, lambda n=n: self.side_load(6, n))
+            if i == 6:
+                if not (last_of_tile and self.side):
+                    for q in range(5):
+                        sput(q, lambda q=q: self.read_a(q, 0, stage ^ 1, g0 + 1))
+                for n, p in enumerate(range(8, 11)):
+                    sput(5 + n, lambda p=p: self.dma_piece(p, stage))
+            if i == 7:
+                if not (last_of_tile and self.side):
+                    sput(0, lambda: self.read_a(5, 0, stage ^ 1, g0 + 1))
+                for n, p in enumerate(range(11, 16)):
+                    sput(1 + n, lambda p=p: self.dma_piece(p, stage))
+            for j in range(8):
+                mfma(a, i, j, 1, False)
+                for f in slots.get(j, []):
+                    f()
+        if not (last_of_tile and self.side):
+            self.read_a(6, 0, stage ^ 1, g0 + 1)
+        else:
+            for n in range(4):
+                self.side_load(7, n)
+        a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
+        a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
+
+    def first_frags(self, stage):
+        """B(kk0) set and A(kk0)[0..6] of a tile's first K-step (kernel prologue; side-input variants: after every epilogue)"""
+        g0 = self.gen
         for j in range(8):
-            mfma(a, i, j, 1, False)
-            for f in slots.get(j, []):
-                f()
-    read_a(a, 6, 0, stage ^ 1, g0 + 1)
-    a(f"s_add_u32 s{S_K}, s{S_K}, 128")
+            self.read_b(j, 0, stage, g0)
+        for i in range(7):
+            self.read_a(i, 0, stage, g0)
+
+    # ---------------------------------------------------------------- the whole body
+    def body(self):
+        a = self.a
+        bkm = self.bkm
+        a("s_nop 4")
+        a(f"s_load_dwordx16 s[{S_ARG}:{S_ARG + 15}], {OP['karg']}, 0")
+        a(f"s_load_dword s{S_LDR}, {OP['karg']}, 64")
+        a(f"v_mov_b32 v{V_TBL}, {OP['tbl']}")
+        a(f"v_mov_b32 v{V_CST}, {OP['cst']}")
+        a(f"v_mov_b32 v{V_BOFF}, {OP['boff']}")
+        a(f"v_mov_b32 v{V_RST}, {OP['rst']}")
+        a(f"v_mov_b32 v{V_AA[0]}, {OP['aA0']}")
+        a(f"v_xor_b32 v{V_AA[1]}, 64, {OP['aA0']}")
+        a(f"v_mov_b32 v{V_AB[0]}, {OP['aB0']}")
+        if not bkm:
+            a(f"v_xor_b32 v{V_AB[1]}, 64, {OP['aB0']}")
+        else:
+            for pp in range(1, 4):                            # column pair pp: chunk index + 4 pp (bits the swizzle key does not carry into) -> address ^ (pp << 6)
+                a(f"v_xor_b32 v{V_AB[pp]}, {pp << 6}, {OP['aB0']}")
+        a(f"s_mov_b32 s{S_M0A}, {OP['m0A']}")
+        a(f"s_mov_b32 s{S_M0B}, {OP['m0B']}")
+        a(f"s_mov_b32 s{S_TILE}, {OP['ntiles']}")
+        a("s_waitcnt lgkmcnt(0)")
+        for ptr in (S_A, S_Bp, S_C, S_BIAS, S_R):
+            a(f"s_and_b32 s{ptr + 1}, s{ptr + 1}, 0xffff")
+        # derived scalars
+        a(f"s_lshl_b32 s{S_LDA64}, s{S_LDA}, 6")
+        a(f"s_lshl_b32 s{S_LDBP}, s{S_LDB}, {2 if bkm else 4}")          # bytes between a wave's consecutive B pieces (KM: 2 k-rows, KC: 8 rows)
+        a(f"s_lshl_b32 s{S_LDC2}, s{S_LDC}, 1")
+        a(f"s_lshl_b32 s{S_LDR2}, s{S_LDR}, 1")
+        a(f"s_lshl_b32 s{S_LDC8}, s{S_LDC}, 4")
+        a(f"s_lshl_b32 s{S_LDC16}, s{S_LDC}, 5")
+        a(f"s_lshl_b32 s{S_LDR8}, s{S_LDR}, 4")
+        a(f"s_lshl_b32 s{S_LDR16}, s{S_LDR}, 5")
+        a(f"s_lshr_b32 s{S_NPAIRS}, s{S_Kd}, 7")
+        if bkm:
+            a(f"s_lshl_b32 s{S_KSTEPB}, s{S_LDB}, 7")                     # 64 k-rows further
+        else:
+            a(f"s_mov_b32 s{S_KSTEPB}, 128")
+        a(f"s_lshl_b32 s{S_BIASBYTES}, s{S_N}, 2")
+
+        def bytes_of(dst, rows, ld, cols):                    # ((rows - 1) * ld + cols) * 2
+            a(f"s_sub_u32 s{S_T}, s{rows}, 1")
+            a(f"s_mul_i32 s{S_T}, s{S_T}, s{ld}")
+            a(f"s_add_u32 s{S_T}, s{S_T}, s{cols}")
+            a(f"s_lshl_b32 s{dst}, s{S_T}, 1")
+        bytes_of(S_ABYTES, S_M, S_LDA, S_Kd)
+        if bkm:
+            bytes_of(S_BBYTES, S_Kd, S_LDB, S_N)
+        else:
+            bytes_of(S_BBYTES, S_N, S_LDB, S_Kd)
+        bytes_of(S_CBYTES, S_M, S_LDC, S_N)
+        bytes_of(S_RBYTES, S_M, S_LDR, S_N)
+        a(f"s_or_b32 s{S_T}, s{S_BIAS}, s{S_BIAS + 1}")
+        a(f"s_cmp_eq_u32 s{S_T}, 0")
+        a(f"s_cselect_b32 s{S_BIASBYTES}, 0, s{S_BIASBYTES}")             # no bias: zero records -> every bias load reads 0
+        a(f"s_or_b32 s{S_T}, s{S_R}, s{S_R + 1}")
+        a(f"s_cmp_eq_u32 s{S_T}, 0")
+        a(f"s_cselect_b32 s{S_RBYTES}, 0, s{S_RBYTES}")
+        # DMA source offsets
+        a(f"v_mov_b32 v{V_VOA}, {OP['voA0']}")
+        for p in range(1, 8):                                  # A pieces are 32 rows apart (piece q = 4 p + wave), same swizzle key
+            a(f"v_add_u32 v{V_VOA + p}, v{V_VOA + p - 1}, s{S_LDA64}")
+        for j in range(8):
+            # KC: piece j covers rows 8 j further, key bits 1-2 = j & 3;  KM: k-rows 2 j further, key = 4 (j & 1) + 8 ((j >> 2) & 1) (+ 2 r1 in chunkx)
+            kx = (4 * (j & 1) + 8 * ((j >> 2) & 1)) if bkm else 2 * (j & 3)
+            a(f"v_xor_b32 v{V_T}, {kx}, {OP['chunkx']}")
+            a(f"v_lshlrev_b32 v{V_T}, 4, v{V_T}")
+            a(f"s_mul_i32 s{S_T}, s{S_LDBP}, {j}")
+            a(f"v_add3_u32 v{V_VOB + j}, {OP['voBbase']}, v{V_T}, s{S_T}")
+        a(f"s_mov_b32 s{S_NULL}, 0")
+        a(f"s_mov_b32 s{S_NULL + 1}, 0")
+        a(f"s_mov_b32 s{S_NULL + 2}, 0")
+        a(f"s_mov_b32 s{S_NULL + 3}, 0x00020000")
+        a(f"s_mov_b32 s{S_TIDX}, 0")
+
+        def load_next():
+            """table entry S_TIDX -> next-tile descriptors (null past the end); entry = {a_off, b_off, c_off, n0}; side-input offset = c_off scaled"""
+            l_no, l_done = a.label("nonext"), a.label("nextdone")
+            a(f"s_cmp_lt_u32 s{S_TIDX}, {OP['ntiles']}")
+            a(f"s_cbranch_scc0 {l_no}")
+            a(f"s_lshl_b32 s{S_T}, s{S_TIDX}, 4")
+            a(f"v_add_u32 v{V_T}, s{S_T}, v{V_TBL}")
+            a(f"ds_read_b128 v[{V_T + 4}:{V_T + 7}], v{V_T}")
+            a(f"ds_read_b32 v{V_T + 8}, v{V_T} offset:8192")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"v_readfirstlane_b32 s{S_T}, v{V_T + 4}")
+            a(f"v_readfirstlane_b32 s{S_T + 1}, v{V_T + 5}")
+            a(f"v_readfirstlane_b32 s{S_NXC_OFF}, v{V_T + 6}")
+            a(f"v_readfirstlane_b32 s{S_NXN0}, v{V_T + 7}")
+            a(f"v_readfirstlane_b32 s{S_NXR_OFF}, v{V_T + 8}")
+            a("s_nop 3")
+            a(f"s_add_u32 s{S_NXA}, s{S_A}, s{S_T}")
+            a(f"s_addc_u32 s{S_NXA + 1}, s{S_A + 1}, 0")
+            a(f"s_sub_u32 s{S_NXA + 2}, s{S_ABYTES}, s{S_T}")
+            a(f"s_mov_b32 s{S_NXA + 3}, 0x00020000")
+            a(f"s_add_u32 s{S_NXB}, s{S_Bp}, s{S_T + 1}")
+            a(f"s_addc_u32 s{S_NXB + 1}, s{S_Bp + 1}, 0")
+            a(f"s_sub_u32 s{S_NXB + 2}, s{S_BBYTES}, s{S_T + 1}")
+            a(f"s_mov_b32 s{S_NXB + 3}, 0x00020000")
+            a(f"s_branch {l_done}")
+            a(f"{l_no}:")
+            for k in range(4):
+                a(f"s_mov_b32 s{S_NXA + k}, s{S_NULL + k}")
+                a(f"s_mov_b32 s{S_NXB + k}, s{S_NULL + k}")
+            a(f"{l_done}:")
+            a(f"s_add_u32 s{S_TIDX}, s{S_TIDX}, 1")
+
+        def next_to_cur():
+            for k in range(4):
+                a(f"s_mov_b32 s{S_RSA + k}, s{S_NXA + k}")
+                a(f"s_mov_b32 s{S_RSB + k}, s{S_NXB + k}")
+
+        def desc(dst, base, total, off):
+            a(f"s_add_u32 s{dst}, s{base}, s{off}")
+            a(f"s_addc_u32 s{dst + 1}, s{base + 1}, 0")
+            a(f"s_sub_u32 s{dst + 2}, s{total}, s{off}")
+            a(f"s_max_i32 s{dst + 2}, s{dst + 2}, 0")
+            a(f"s_mov_b32 s{dst + 3}, 0x00020000")
+
+        def cur_output_descriptors():
+            """C / bias / side-input descriptors of the tile whose K loop starts now"""
+            desc(S_RSC, S_C, S_CBYTES, S_CUR_C_OFF)
+            a(f"s_lshl_b32 s{S_T + 2}, s{S_CUR_N0}, 2")
+            desc(S_RSBIAS, S_BIAS, S_BIASBYTES, S_T + 2)
+            desc(S_RSR, S_R, S_RBYTES, S_CUR_R_OFF)
+
+        def take_next_offsets():
+            a(f"s_mov_b32 s{S_CUR_C_OFF}, s{S_NXC_OFF}")
+            a(f"s_mov_b32 s{S_CUR_N0}, s{S_NXN0}")
+            a(f"s_mov_b32 s{S_CUR_R_OFF}, s{S_NXR_OFF}")
+
+        # ---- kernel prologue: tile 0's descriptors, its first two K-steps, 32 null stores (the first K-step's vmcnt count assumes an epilogue
+        # before it; side-input variants: + the 4 loads of side block 7), its first fragments
+        load_next()
+        next_to_cur()
+        take_next_offsets()
+        load_next()
+        cur_output_descriptors()
+        a(f"s_mov_b32 s{S_KA}, 0")
+        a(f"s_mov_b32 s{S_KB}, 0")
+        a("s_nop 4")
+        for p in range(16):
+            self.dma_piece(p, 0)
+        a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
+        a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
+        for p in range(16):
+            self.dma_piece(p, 1)
+        a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
+        a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
+        a("s_waitcnt vmcnt(16)")
+        a("s_barrier")
+        n_epi_vm = 32 + (4 if self.side else 0)              # VMEM operations between a tile's last DMA piece and the next tile's first K-step
+        for _ in range(n_epi_vm):
+            a(f"buffer_store_dword v{V_T}, v{V_CST}, s[{S_NULL}:{S_NULL + 3}], 0 offen")
+        a("s_nop 1")
+        if not self.side:
+            self.first_frags(0)
+
+        # ---- tile loop
+        l_tile, l_mid, l_last, l_done = a.label("tile"), a.label("mid"), a.label("last"), a.label("done")
+        a(f"{l_tile}:")
+        if self.side:
+            self.first_frags(0)                               # (the last K-step of the previous tile used these registers for its side tile)
+        a(f"s_mov_b32 s{S_PAIRS}, s{S_NPAIRS}")
+        # first pair.  vmcnt of its first barrier E: younger than this tile's second K-step (issued during the previous tile's last step) are
+        # the previous epilogue's VMEM operations, the 8 bias loads of phase 0 and the 8 DMA pieces issued before the barrier
+        self.step(0, first=True, n_e=n_epi_vm + 8 + 8, bias_loads=True)
+        self.step(1)
+        tail_state = [(t[0],) + t[2:] for t in a.lds[-24:]]
+        a(f"s_sub_u32 s{S_PAIRS}, s{S_PAIRS}, 1")
+        a(f"s_cmp_eq_u32 s{S_PAIRS}, 1")
+        a(f"s_cbranch_scc1 {l_last}")
+        a(f"{l_mid}:")
+        self.step(0)
+        self.step(1)
+        assert tail_state == [(t[0],) + t[2:] for t in a.lds[-24:]]
+        a(f"s_sub_u32 s{S_PAIRS}, s{S_PAIRS}, 1")
+        a(f"s_cmp_eq_u32 s{S_PAIRS}, 1")
+        a(f"s_cbranch_scc0 {l_mid}")
+        a(f"{l_last}:")
+        next_to_cur()                                         # last pair: its DMA slots carry the next tile's first two K-steps
+        a(f"s_mov_b32 s{S_KA}, 0")
+        a(f"s_mov_b32 s{S_KB}, 0")
+        self.step(0)
+        self.step(1, last_of_tile=True)
+        if not self.side:
+            assert tail_state == [(t[0],) + t[2:] for t in a.lds[-24:]]
+
+        # ---- epilogue of the finished tile (descriptor S_RSC still its own)
+        a("s_nop 15")
+        a(f"s_mov_b32 s{S_SOFF}, 0")
+        T = V_T
+        n_store = 0
+        for i in range(8):
+            if self.side:
+                if i == 0:
+                    a("s_waitcnt vmcnt(12)")                  # side blocks 0-6 are back (younger: DMA pieces 8-15 of the last step, block 7)
+                if i == 7:
+                    a(f"s_waitcnt vmcnt({n_store})")          # block 7 (everything older than the stores issued so far)
+            for slab in range(2):
+                if self.side:
+                    # the lane's side chunks of this (block, slab): rows 0-7 / 8-15 in line order -> q' = 0 / 1 chunks of row t (swap with lane t ^ 8)
+                    L0, L1 = R_BLOCK[i] + 8 * slab, R_BLOCK[i] + 8 * slab + 4
+                    for r in range(4):
+                        a(f"v_mov_b32 v{T + 16 + r}, v{L0 + r}")
+                    a("s_nop 1")
+                    for r in range(4):
+                        a(f"v_mov_b32_dpp v{L0 + r}, v{L1 + r} row_ror:8 row_mask:0xf bank_mask:0xc")
+                    for r in range(4):
+                        a(f"v_mov_b32_dpp v{L1 + r}, v{T + 16 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
+                # P0 / P1: the lane's 8 consecutive columns of column groups q' = 0 / 1 of the slab (fragments 4 slab + 2 q' + e, e = 0, 1)
+                for qp in range(2):
+                    for e in range(2):
+                        j = 4 * slab + 2 * qp + e
+                        d = acc(i, j)
+                        for r in range(4):
+                            a(f"v_accvgpr_read_b32 v{T + 8 + r}, a{d + r}")
+                        if self.epi != "mulaux":
+                            a(f"v_pk_add_f32 v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 1}]")
+                            a(f"v_pk_add_f32 v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{V_BIAS + 4 * j + 2}:{V_BIAS + 4 * j + 3}]")
+                        if self.side:
+                            src = (R_BLOCK[i] + 8 * slab + (4 if qp else 0)) + 2 * e          # two dwords: columns 4e..4e+3 of the chunk
+                            a(f"v_lshlrev_b32 v{T + 20}, 16, v{src}")
+                            a(f"v_and_b32 v{T + 21}, 0xffff0000, v{src}")
+                            a(f"v_lshlrev_b32 v{T + 22}, 16, v{src + 1}")
+                            a(f"v_and_b32 v{T + 23}, 0xffff0000, v{src + 1}")
+                            op = "v_pk_mul_f32" if self.epi == "mulaux" else "v_pk_add_f32"
+                            a(f"{op} v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{T + 20}:{T + 21}]")
+                            a(f"{op} v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{T + 22}:{T + 23}]")
+                        a(f"v_cvt_pk_bf16_f32 v{T + 4 * qp + 2 * e}, v{T + 8}, v{T + 9}")
+                        a(f"v_cvt_pk_bf16_f32 v{T + 4 * qp + 2 * e + 1}, v{T + 10}, v{T + 11}")
+                # D0 = P0 with lanes t >= 8 taking P1 of lane t - 8; D1 = P1 with lanes t < 8 taking P0 of lane t + 8
+                for r in range(4):
+                    a(f"v_mov_b32 v{T + 12 + r}, v{T + r}")
+                a("s_nop 1")
+                for r in range(4):
+                    a(f"v_mov_b32_dpp v{T + r}, v{T + 4 + r} row_ror:8 row_mask:0xf bank_mask:0xc")
+                for r in range(4):
+                    a(f"v_mov_b32_dpp v{T + 4 + r}, v{T + 12 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
+                a(f"s_add_u32 s{S_T}, s{S_SOFF}, {128 * slab}")
+                a(f"buffer_store_dwordx4 v[{T}:{T + 3}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen")
+                a(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDC8}")
+                a(f"buffer_store_dwordx4 v[{T + 4}:{T + 7}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen")
+                a("s_nop 1")
+                n_store += 2
+            a(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, s{S_LDC16}")
+        # ---- next tile
+        a(f"s_sub_u32 s{S_TILE}, s{S_TILE}, 1")
+        a(f"s_cmp_eq_u32 s{S_TILE}, 0")
+        a(f"s_cbranch_scc1 {l_done}")
+        take_next_offsets()
+        cur_output_descriptors()
+        load_next()
+        a(f"s_branch {l_tile}")
+        a(f"{l_done}:")
+        a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        return a.l
 
 
 def main():
-    a = Asm()
-    a("s_nop 4")
-    a(f"v_mov_b32 v{V_TBL}, {OP['tbl']}")
-    a(f"v_mov_b32 v{V_VOA}, {OP['voA0']}")
-    for p in range(1, 8):                                  # A pieces are 32 rows apart (piece q = 4 p + wave), same swizzle key
-        a(f"v_add_u32 v{V_VOA + p}, v{V_VOA + p - 1}, {OP['lda64']}")
-    for j in range(8):                                     # B piece j: rows 8 j further, key bits 1-2 = j & 3
-        a(f"v_xor_b32 v{V_T}, {2 * (j & 3)}, {OP['chunkx']}")
-        a(f"v_lshlrev_b32 v{V_T}, 4, v{V_T}")
-        a(f"s_mul_i32 s{S_TMP}, {OP['ldb16']}, {j}")
-        a(f"v_add3_u32 v{V_VOB + j}, {OP['voBbase']}, v{V_T}, s{S_TMP}")
-    a(f"v_mov_b32 v{V_AA[0]}, {OP['aA0']}")
-    a(f"v_xor_b32 v{V_AA[1]}, 64, {OP['aA0']}")
-    a(f"v_mov_b32 v{V_AB[0]}, {OP['aB0']}")
-    a(f"v_xor_b32 v{V_AB[1]}, 64, {OP['aB0']}")
-    a(f"v_mov_b32 v{V_CST}, {OP['cst']}")
-    a(f"v_mov_b32 v{V_BOFF}, {OP['boff']}")
-    a(f"s_mov_b32 s{S_M0A}, {OP['m0A']}")
-    a(f"s_mov_b32 s{S_M0B}, {OP['m0B']}")
-    a(f"s_lshl_b32 s{S_LDC8}, {OP['ldc2']}, 3")
-    a(f"s_lshl_b32 s{S_LDC16}, {OP['ldc2']}, 4")
-    a(f"s_mov_b32 s{S_TILE}, {OP['ntiles']}")
-    a(f"s_mov_b32 s{S_NULL}, 0")
-    a(f"s_mov_b32 s{S_NULL + 1}, 0")
-    a(f"s_mov_b32 s{S_NULL + 2}, 0")
-    a(f"s_mov_b32 s{S_NULL + 3}, 0x00020000")
-    a(f"s_mov_b32 s{S_TIDX}, 0")
-    a(f"s_mov_b32 s{S_BIASB}, {OP['bias_lo']}")
-    a(f"s_mov_b32 s{S_BIASB + 1}, {OP['bias_hi']}")
-    a(f"s_or_b32 s{S_TMP}, {OP['bias_lo']}, {OP['bias_hi']}")
-    a(f"s_cmp_eq_u32 s{S_TMP}, 0")
-    a(f"s_cselect_b32 s{S_BIASB + 2}, 0, {OP['bias_bytes']}")           # no bias: zero records -> every bias load reads 0
-
-    def load_next():
-        """table entry S_TIDX -> next-tile descriptors (null descriptors past the end); entry = {a_off, b_off, c_off, n0}"""
-        l_no, l_done = a.label("nonext"), a.label("nextdone")
-        a(f"s_cmp_lt_u32 s{S_TIDX}, {OP['ntiles']}")
-        a(f"s_cbranch_scc0 {l_no}")
-        a(f"s_lshl_b32 s{S_TMP}, s{S_TIDX}, 4")
-        a(f"v_add_u32 v{V_T}, s{S_TMP}, v{V_TBL}")
-        a(f"ds_read_b128 v[{V_T + 4}:{V_T + 7}], v{V_T}")
-        a("s_waitcnt lgkmcnt(0)")
-        for k in range(4):
-            a(f"v_readfirstlane_b32 s{S_TMP + 1 + k}, v{V_T + 4 + k}")     # a_off, b_off, c_off, n0
-        a("s_nop 3")
-        a(f"s_add_u32 s{S_NXA}, {OP['A_lo']}, s{S_TMP + 1}")
-        a(f"s_addc_u32 s{S_NXA + 1}, {OP['A_hi']}, 0")
-        a(f"s_sub_u32 s{S_NXA + 2}, {OP['a_bytes']}, s{S_TMP + 1}")
-        a(f"s_mov_b32 s{S_NXA + 3}, 0x00020000")
-        a(f"s_add_u32 s{S_NXB}, {OP['B_lo']}, s{S_TMP + 2}")
-        a(f"s_addc_u32 s{S_NXB + 1}, {OP['B_hi']}, 0")
-        a(f"s_sub_u32 s{S_NXB + 2}, {OP['b_bytes']}, s{S_TMP + 2}")
-        a(f"s_mov_b32 s{S_NXB + 3}, 0x00020000")
-        a(f"s_mov_b32 s{S_NXC_OFF}, s{S_TMP + 3}")
-        a(f"s_mov_b32 s{S_NXN0}, s{S_TMP + 4}")
-        a(f"s_branch {l_done}")
-        a(f"{l_no}:")
-        for k in range(4):
-            a(f"s_mov_b32 s{S_NXA + k}, s{S_NULL + k}")
-            a(f"s_mov_b32 s{S_NXB + k}, s{S_NULL + k}")
-        a(f"{l_done}:")
-        a(f"s_add_u32 s{S_TIDX}, s{S_TIDX}, 1")
-
-    def next_to_cur():
-        for k in range(4):
-            a(f"s_mov_b32 s{S_RSA + k}, s{S_NXA + k}")
-            a(f"s_mov_b32 s{S_RSB + k}, s{S_NXB + k}")
-
-    def cur_output_descriptors():
-        """C / bias descriptors of the tile whose K loop starts now"""
-        a(f"s_add_u32 s{S_RSC}, {OP['C_lo']}, s{S_CUR_C_OFF}")
-        a(f"s_addc_u32 s{S_RSC + 1}, {OP['C_hi']}, 0")
-        a(f"s_sub_u32 s{S_RSC + 2}, {OP['c_bytes']}, s{S_CUR_C_OFF}")
-        a(f"s_mov_b32 s{S_RSC + 3}, 0x00020000")
-        a(f"s_lshl_b32 s{S_TMP}, s{S_CUR_N0}, 2")
-        a(f"s_add_u32 s{S_RSBIAS}, s{S_BIASB}, s{S_TMP}")
-        a(f"s_addc_u32 s{S_RSBIAS + 1}, s{S_BIASB + 1}, 0")
-        a(f"s_sub_u32 s{S_RSBIAS + 2}, s{S_BIASB + 2}, s{S_TMP}")
-        a(f"s_max_i32 s{S_RSBIAS + 2}, s{S_RSBIAS + 2}, 0")
-        a(f"s_mov_b32 s{S_RSBIAS + 3}, 0x00020000")
-
-    # ---- kernel prologue: tile 0's descriptors, its first two K-steps, 32 null stores (the first K-step's vmcnt count assumes an epilogue
-    # before it), its first fragments
-    load_next()
-    next_to_cur()
-    a(f"s_mov_b32 s{S_CUR_C_OFF}, s{S_NXC_OFF}")
-    a(f"s_mov_b32 s{S_CUR_N0}, s{S_NXN0}")
-    load_next()
-    cur_output_descriptors()
-    a(f"s_mov_b32 s{S_K}, 0")
-    a("s_nop 4")
-    for p in range(16):
-        dma_piece(a, p, 0)
-    a(f"s_add_u32 s{S_K}, s{S_K}, 128")
-    for p in range(16):
-        dma_piece(a, p, 1)
-    a(f"s_add_u32 s{S_K}, s{S_K}, 128")
-    a("s_waitcnt vmcnt(16)")
-    a("s_barrier")
-    GEN[0] = 0
-    for j in range(8):
-        read_b(a, j, 0, 0, 0)
-    for i in range(7):
-        read_a(a, i, 0, 0, 0)
-    for _ in range(32):
-        a(f"buffer_store_dword v{V_T}, v{V_CST}, s[{S_NULL}:{S_NULL + 3}], 0 offen")
-    a("s_nop 1")
-
-    # ---- tile loop
-    l_tile, l_pair, l_noswap, l_done = a.label("tile"), a.label("pair"), a.label("noswap"), a.label("done")
-    a(f"{l_tile}:")
-    a(f"s_mov_b32 s{S_PAIRS}, {OP['pairs']}")
-    # first pair.  vmcnt of the first barrier E: younger than this tile's second K-step (issued during the previous tile's last step) are
-    # the previous epilogue's 32 stores, the 8 bias loads of phase 0 and the 8 DMA pieces issued before the barrier
-    gen_step(a, 0, True, 32 + 8 + 8, bias_loads=True)
-    gen_step(a, 1, False, 8)
-    a(f"s_sub_u32 s{S_PAIRS}, s{S_PAIRS}, 1")
-    lds_state = list(a.lds)
-    a(f"{l_pair}:")
-    a(f"s_cmp_eq_u32 s{S_PAIRS}, 1")
-    a(f"s_cbranch_scc0 {l_noswap}")
-    next_to_cur()                                           # last pair: its DMA slots carry the next tile's first two K-steps
-    a(f"s_mov_b32 s{S_K}, 0")
-    a(f"{l_noswap}:")
-    gen_step(a, 0, False, 8)
-    gen_step(a, 1, False, 8)
-    a(f"s_sub_u32 s{S_PAIRS}, s{S_PAIRS}, 1")
-    a(f"s_cmp_eq_u32 s{S_PAIRS}, 0")
-    a(f"s_cbranch_scc0 {l_pair}")
-    # (the read-tracking state at the loop's back edge and at its entry must describe the same tail: both are "end of a step on stage 1")
-    assert [t[0] + str(t[2:]) for t in lds_state[-24:]] == [t[0] + str(t[2:]) for t in a.lds[-24:]]
-
-    # ---- epilogue of the finished tile (descriptor S_RSC still its own); the next tile's first fragments are already in v[0:95]
-    a("s_nop 15")
-    a(f"s_mov_b32 s{S_SOFF}, 0")
-    T = V_T
-    for i in range(8):
-        for slab in range(2):
-            # P0 / P1: the lane's 8 consecutive columns of column groups q' = 0 / 1 of the slab (fragments 4 slab + 2 q' + e, e = 0, 1)
-            for qp in range(2):
-                for e in range(2):
-                    j = 4 * slab + 2 * qp + e
-                    d = acc(i, j)
-                    for r in range(4):
-                        a(f"v_accvgpr_read_b32 v{T + 8 + r}, a{d + r}")
-                    a(f"v_pk_add_f32 v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 1}]")
-                    a(f"v_pk_add_f32 v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{V_BIAS + 4 * j + 2}:{V_BIAS + 4 * j + 3}]")
-                    a(f"v_cvt_pk_bf16_f32 v{T + 4 * qp + 2 * e}, v{T + 8}, v{T + 9}")
-                    a(f"v_cvt_pk_bf16_f32 v{T + 4 * qp + 2 * e + 1}, v{T + 10}, v{T + 11}")
-            # D0 = P0 with lanes t >= 8 taking P1 of lane t - 8; D1 = P1 with lanes t < 8 taking P0 of lane t + 8
-            for r in range(4):
-                a(f"v_mov_b32 v{T + 12 + r}, v{T + r}")
-            a("s_nop 1")
-            for r in range(4):
-                a(f"v_mov_b32_dpp v{T + r}, v{T + 4 + r} row_ror:8 row_mask:0xf bank_mask:0xc")
-            for r in range(4):
-                a(f"v_mov_b32_dpp v{T + 4 + r}, v{T + 12 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
-            a(f"s_add_u32 s{S_TMP}, s{S_SOFF}, {128 * slab}")
-            a(f"buffer_store_dwordx4 v[{T}:{T + 3}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_TMP} offen")
-            a(f"s_add_u32 s{S_TMP}, s{S_TMP}, s{S_LDC8}")
-            a(f"buffer_store_dwordx4 v[{T + 4}:{T + 7}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_TMP} offen")
-            a("s_nop 1")
-        a(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, s{S_LDC16}")
-    # ---- next tile
-    a(f"s_sub_u32 s{S_TILE}, s{S_TILE}, 1")
-    a(f"s_cmp_eq_u32 s{S_TILE}, 0")
-    a(f"s_cbranch_scc1 {l_done}")
-    a(f"s_mov_b32 s{S_CUR_C_OFF}, s{S_NXC_OFF}")
-    a(f"s_mov_b32 s{S_CUR_N0}, s{S_NXN0}")
-    cur_output_descriptors()
-    load_next()
-    a(f"s_branch {l_tile}")
-    a(f"{l_done}:")
-    a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
     with open(out, "w") as f:
         f.write("// GENERATED by scripts/gen_w4a.py -- do not edit; the schedule is described there\n")
         f.write(f"#define W4A_N_OPERANDS {len(OPS)}\n")
         f.write("// operand order: " + " ".join(OPS) + "\n")
         f.write("#define W4A_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(V_LAST + 1)] + [f'"a{i}"' for i in range(256)] +
-                                                    [f'"s{i}"' for i in range(S0, S_LAST + 1)] + ['"scc"', '"m0"', '"memory"']) + "\n")
-        f.write("#define W4A_ASM_BODY \\\n")
-        f.write(" \\\n".join('    "%s\\n\\t"' % x for x in a.l))
-        f.write("\n")
-    print(f"{len(a.l)} asm lines", file=sys.stderr)
+                                                    [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"scc"', '"m0"', '"memory"']) + "\n")
+        for bkm in (False, True):
+            for epi in ("plain", "resid", "mulaux"):
+                lines = Gen(bkm, epi).body()
+                name = f"W4A_BODY_{'KM' if bkm else 'KC'}_{epi.upper()}"
+                f.write(f"#define {name} \\\n")
+                f.write(" \\\n".join('    "%s\\n\\t"' % x for x in lines))
+                f.write("\n")
+                print(f"{name}: {len(lines)} asm lines", file=sys.stderr)
 
 
 if __name__ == "__main__":
