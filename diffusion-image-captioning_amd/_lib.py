@@ -19,7 +19,7 @@ DIC_F32, DIC_BF16 = 0, 1
 EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [
-    "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_set_w4a", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
+    "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_set_w4a", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_head_center", "dic_head_center_ws_bytes", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_colsum_pair", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end", "dic_prof_algorithmic_bytes", "dic_prof_get",
@@ -134,7 +134,10 @@ def lib():
         L.dic_emb_loss.argtypes = [I, I, P, P, I, P, P, P, P, I, I, I, I, P]
         L.dic_add_rows.argtypes = [P, P, I, I, I, I, P]
         L.dic_add_rows_scaled.argtypes = [P, P, P, C.c_float, I, I, I, I, P]
-        L.dic_ce_target_logit.argtypes = [P, P, P, I, I, I, C.c_float, P, P, P]
+        L.dic_ce_target_logit.argtypes = [P, P, P, I, I, I, C.c_float, P, P, P, P]
+        L.dic_head_center.argtypes = [P, I, P, I, I, I, I, P, I, P, P, P, P, P]
+        L.dic_head_center_ws_bytes.argtypes = [I]
+        L.dic_head_center_ws_bytes.restype = C.c_size_t
         L.dic_ce_exp_combine.argtypes = [P, I, P, P, P, I, I, P, I, P, P, P, P]
         L.dic_seg_sum.argtypes = [P, I, I, F, F, P, P, P]
         L.dic_step_prep.argtypes = [P, P, P, P, I, I, I, I, P, P, P, P, P, P, F, F, P]

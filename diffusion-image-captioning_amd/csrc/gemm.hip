@@ -1260,7 +1260,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #define DIC_GEMM_XT 0          // measured in round 3 (profiles/r03_gemm_xt_ab.txt): 3-7 % SLOWER on every shape, K loop included -- off
 #endif
     constexpr bool XT = DIC_GEMM_XT != 0;
-    constexpr bool BIAS_INIT = !XT && !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D);
+    // (the rounding-head epilogues take a per-column bias too: the row-common part of the logits of a mean-centred head input, dic_head_center)
+    constexpr bool BIAS_INIT = !XT && !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D ||
+                                                                 EPI == DIC_EPI_CE_PARTIAL || EPI == DIC_EPI_CE_EXP);
     f32x4 binit[BIAS_INIT ? G::FN : 1];
     auto load_bias = [&](const TileId& t_) {
         if constexpr (BIAS_INIT) {

@@ -379,9 +379,89 @@ __global__ void ce_combine_kernel(const float* partial, const float* tgt_logit, 
         }
     }
 }
+// ---- mean-centred rounding-head input (dic_head_center).  logits = x W^T is evaluated as (x - xbar) W^T + xbar W^T: the row-common part in fp32
+// (one 768 x V matrix-vector product per step, handed to the head GEMM as its bias), only the deviations through bf16.  Why: an early-training
+// denoiser predicts nearly the same vector for every row (measured after 200 steps: |xbar| = 27, rms |x - xbar| = 0.009), so the bf16 rounding
+// error of x is the SAME for every row and the batch-mean loss does not average it out (-2.9e-4 on the rounding loss against the fp32 head on
+// identical encoder outputs; centred: 7e-10 -- profiles/r04_trained_gap_split.txt).  The deviations' rounding errors are independent again.
+constexpr int HC_BLOCKS = 1024;
+__device__ __forceinline__ const float* head_row(const float* xa, int na, const float* xb, int L, int Tk, int D, long long r) {
+    const long long n = r / L;
+    const int t = (int)(r - n * L);
+    return (n < na ? xa + n * (long long)Tk * D : xb + (n - na) * (long long)Tk * D) + (long long)t * D;
+}
+// stage 1: 1024 blocks x 192 lanes (one float4 column each), four independent row loads in flight; stage 2 is colsum_small over the 1024 partial rows
+__global__ __launch_bounds__(192) void head_colsum_kernel(const float* xa, int na, const float* xb, int nb, int L, int Tk, int D, float* ws) {
+    const long long rows = (long long)(na + nb) * L;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    f32x4 a{0.f, 0.f, 0.f, 0.f};
+    long long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(head_row(xa, na, xb, L, Tk, D, r + u) + threadIdx.x * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += v[u];
+    }
+    for (; r < r1; ++r) a += *(const f32x4*)(head_row(xa, na, xb, L, Tk, D, r) + threadIdx.x * 4);
+    *(f32x4*)(ws + (size_t)blockIdx.x * D + threadIdx.x * 4) = a;
+}
+__global__ void head_bias_kernel(const float* W, int Vpad, int D, const float* xsum, float inv_rows, float* cvec) {    // one wave per vocabulary row
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (v >= Vpad) return;
+    float a = 0.f;
+#pragma unroll
+    for (int d = lane * 4; d < 768; d += 256) {
+        const f32x4 w = *(const f32x4*)(W + (size_t)v * D + d), x = *(const f32x4*)(xsum + d) * inv_rows;
+        a = __builtin_fmaf(w[0], x[0], a); a = __builtin_fmaf(w[1], x[1], a); a = __builtin_fmaf(w[2], x[2], a); a = __builtin_fmaf(w[3], x[3], a);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) cvec[v] = a;
+}
+__global__ void head_xr_kernel(const float* xa, int na, const float* xb, int nb, int L, int Tk, int D, const float* xsum, float inv_rows, bf16_t* xr,
+                               float* xbar) {
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const long long rows = (long long)(na + nb) * L;
+    f32x4 m[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[c] = *(const f32x4*)(xsum + c * 256 + lane * 4) * inv_rows;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *(f32x4*)(xbar + c * 256 + lane * 4) = m[c];
+    }
+    for (long long r = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * wpb) {
+        const float* x = head_row(xa, na, xb, L, Tk, D, r);
+        f32x4 v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = *(const f32x4*)(x + c * 256 + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Elem<bf16_t>::st4(xr + (size_t)r * D + c * 256 + lane * 4, v[c] - m[c]);
+    }
+}
+__global__ __launch_bounds__(64 * 16) void colsum_small(const float* in, int rows, int cols, int ld, float* out, int accumulate, const float* in2, float* out2);
+extern "C" size_t dic_head_center_ws_bytes(int D) { return ((size_t)HC_BLOCKS * D + D) * sizeof(float); }
+extern "C" int dic_head_center(const float* x_a, int n_a, const float* x_b, int n_b, int L, int Tk, int D, const float* W32, int Vpad, float* ws,
+                               float* xbar, float* cvec, void* xr, void* stream) {
+    DIC_REQUIRE(D == 768 && n_a >= 0 && n_b >= 0 && n_a + n_b > 0 && L > 0 && Tk >= L && x_a && W32 && ws && xbar && cvec && xr && (n_b == 0 || x_b),
+                "dic_head_center: D must be 768; x_a / W32 / ws / xbar / cvec / xr must be given");
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)(n_a + n_b) * L;
+    float* xsum = ws + (size_t)HC_BLOCKS * D;
+    const float inv = 1.0f / (float)rows;
+    hipLaunchKernelGGL(head_colsum_kernel, dim3(HC_BLOCKS), dim3(192), 0, st, x_a, n_a, x_b, n_b, L, Tk, D, ws);
+    hipLaunchKernelGGL(colsum_small, dim3((D + 255) / 256), dim3(64 * 16), 0, st, (const float*)ws, HC_BLOCKS, D, D, xsum, 0, (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(head_bias_kernel, dim3((Vpad + 3) / 4), dim3(256), 0, st, W32, Vpad, D, (const float*)xsum, inv, cvec);
+    hipLaunchKernelGGL(head_xr_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, st, x_a, n_a, x_b, n_b, L, Tk, D, (const float*)xsum, inv, (bf16_t*)xr, xbar);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- rounding loss, training form (include/dic_hip.h: dic_ce_target_logit -> dic_gemm(CE_EXP) -> dic_ce_exp_combine)
 // one wave per row: t = <xr[m], W[tgt[m]]>, c = t + shift
-__global__ void ce_target_logit_kernel(const bf16_t* xr, const bf16_t* W, const int64_t* tgt, int M, int V, int D, float shift, float* t_out, float* c_out) {
+__global__ void ce_target_logit_kernel(const bf16_t* xr, const bf16_t* W, const int64_t* tgt, int M, int V, int D, float shift, float* t_out, float* c_out,
+                                       const float* col_bias) {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     for (int m = blockIdx.x * wpb + (threadIdx.x >> 6); m < M; m += gridDim.x * wpb) {
         const long long tg = tgt[m];
@@ -397,12 +477,17 @@ __global__ void ce_target_logit_kernel(const bf16_t* xr, const bf16_t* W, const 
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-        if (lane == 0) { t_out[m] = a; c_out[m] = a + shift; }
+        if (lane == 0) {
+            if (col_bias && tg >= 0 && tg < V) a += col_bias[tg];          // (mean-centred head input: the row-common part of the logit)
+            t_out[m] = a; c_out[m] = a + shift;
+        }
     }
 }
-extern "C" int dic_ce_target_logit(const void* xr, const void* W, const int64_t* tgt, int M, int V, int D, float shift, float* t, float* c, void* stream) {
+extern "C" int dic_ce_target_logit(const void* xr, const void* W, const int64_t* tgt, int M, int V, int D, float shift, float* t, float* c,
+                                   const float* col_bias, void* stream) {
     DIC_REQUIRE(M > 0 && D % 8 == 0 && xr && W && tgt && t && c, "dic_ce_target_logit: bad arguments");
-    hipLaunchKernelGGL(ce_target_logit_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xr, (const bf16_t*)W, tgt, M, V, D, shift, t, c);
+    hipLaunchKernelGGL(ce_target_logit_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xr, (const bf16_t*)W, tgt, M, V, D, shift, t, c,
+                       col_bias);
     DIC_CHECK_LAUNCH();
     return 0;
 }

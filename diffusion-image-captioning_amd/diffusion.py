@@ -402,13 +402,16 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     tgt_t = tgt_t.contiguous()
     x_0c = x_0.contiguous()
     es = model.es
+    xr_copy = not (cfg.USE_PROB_LOSS and model.head_centered)          # (a mean-centred head input is written by dic_head_center below instead)
     _lib.check(lib.dic_emb_loss(model.dt, kind, _p(x_out), _p(tgt_t), tgt_rows, _p(sc["per_seq"]), _p(dx) if want_grad else 0,
-                                _p(sc["gscale"]), _p(cw["xr"]), Nt, L, Tk, 768, st), "emb_loss")
+                                _p(sc["gscale"]), _p(cw["xr"]) if xr_copy else 0, Nt, L, Tk, 768, st), "emb_loss")
     off = (Nt + Ng) * row * 4
     _lib.check(lib.dic_emb_loss(model.dt, kind, _p(x_out) + off, _p(x_0c), B, _p(sc["per_seq"]) + Nt * 4, (_p(dx) + off) if want_grad else 0,
-                                _p(sc["gscale"]) + Nt * 4, _p(cw["xr"]) + Nt * L * 768 * es, B, L, Tk, 768, st), "emb_loss")
+                                _p(sc["gscale"]) + Nt * 4, (_p(cw["xr"]) + Nt * L * 768 * es) if xr_copy else 0, B, L, Tk, 768, st), "emb_loss")
     _lib.check(lib.dic_seg_sum(_p(sc["per_seq"]), Nt + B, Nt, sa, sb, _p(out), 0, st), "seg_sum")
     model._last_total = out[3]
+    if cfg.USE_PROB_LOSS:
+        model.center_head_input(cw, _p(x_out), Nt, _p(x_out) + off, B, L, Tk)          # (bf16 engines: xr <- bf16(x - mean row), its logits -> the head's bias)
 
     # ---- rounding loss (ref :432-445): streaming GEMM + logsumexp + gather, logits never materialised
     if cfg.USE_PROB_LOSS:
@@ -672,6 +675,11 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
     # dic_gemm_set_two_heights; 7.56 -> 7.47 ms per pass at B = 2048 -- the training step keeps the switch off)
     lib = _lib.lib()
     prev_two = lib.dic_gemm_set_two_heights(0 if _os.environ.get("DIC_GEMM_TWO_HEIGHTS") == "0" else 1)
+    # ... and its k-contiguous GEMMs without dropout (QKV, out-proj + residual, FFN-2 + residual, the MLM-head transform) run on the hand-scheduled
+    # four-wave kernel where their shape allows (include/dic_hip.h, dic_gemm_set_w4a: token count a multiple of 256): 8.06 -> 7.90 ms per pass at
+    # B = 2048 (profiles/r04_sampling_w4a_ab.txt).  The training step keeps it off: at the 1400 W package limit its denser MFMA stream is paid back
+    # in clock (profiles/r04_power_probe.txt)
+    prev_w4a = lib.dic_gemm_set_w4a(0 if _os.environ.get("DIC_GEMM_W4A") == "0" else 1)
     try:
         for k in range(steps):
             if graph is not None:
@@ -696,6 +704,7 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
             x_out = run()
     finally:
         lib.dic_gemm_set_two_heights(prev_two)
+        lib.dic_gemm_set_w4a(prev_w4a)
     x = x_out[:, :L, :].contiguous()
     _, ids, _ = model.rounding(x.reshape(B * L, 768), B * L, dtype=_lib.DIC_F32)
     ids = ids.clone().reshape(B, L)

@@ -76,7 +76,10 @@ _GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GEL
 # bf16 engine: FFN-1's forward epilogue leaves gelu'(u) behind instead of u (same bytes), so the backward's epilogue is one multiply (MUL_AUX)
 # instead of erf + exp per element (round-3 review item 3; "0": the round-3 form, kept as the A/B partner and for the fp32 engine)
 _GELU_D = _os.environ.get("DIC_GELU_D", "1") != "0"
-_PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"   # the two LayerNorm-gradient folds of a layer in one launch (A/B switch)
+_PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"
+# mean-centred rounding-head input (Denoiser.center_head_input): "auto" = on in the split-weight parity mode (bf16w), off in the plain bf16
+# throughput mode (it costs 4 small launches, ~0.1 ms of a 14 ms step); "1" / "0" force it for both (A/B switch)
+_HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "auto")   # the two LayerNorm-gradient folds of a layer in one launch (A/B switch)
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
@@ -350,7 +353,10 @@ class Denoiser:
                       argmax=torch.empty(M, dtype=torch.int64, device=dev), nll=torch.empty(M, dtype=torch.float32, device=dev),
                       tgt=torch.empty(M, dtype=torch.int64, device=dev), dxr=torch.empty(M, 768, dtype=torch.float32, device=dev),
                       dlogits=None, cref=torch.empty(M, dtype=torch.float32, device=dev), inv_z=torch.empty(M, dtype=torch.float32, device=dev),
-                      fused=False)
+                      fused=False, centered=False,
+                      # mean-centred head input (center_head_input): mean row, its logits (the head GEMM's bias), partial column sums
+                      xbar=torch.zeros(768, dtype=torch.float32, device=dev), cvec=torch.zeros(self.vpad + 256, dtype=torch.float32, device=dev),
+                      hc_ws=torch.empty(self.ops.L.dic_head_center_ws_bytes(768) // 4, dtype=torch.float32, device=dev))
             self._ce_ws[M] = ws
         return ws
 
@@ -652,18 +658,36 @@ class Denoiser:
             main.wait_stream(side)                    # every weight gradient is in G before anything downstream (AdamW, all-reduce tail)
 
     # ------------------------------------------------------------------ rounding head: streaming CE / argmax (ref :323, 436-437, 620)
+    @property
+    def head_centered(self):
+        return self.bf16 and not self.te and (_HEAD_CENTER == "1" or (_HEAD_CENTER == "auto" and self.split_w))
+
+    def center_head_input(self, cw, x_a, n_a, x_b, n_b, L, Tk):
+        """bf16 engines: rewrite cw["xr"] as bf16(x - xbar) over the head rows (rows t < L of the n_a sequences at x_a and the n_b at x_b, fp32
+        [n][Tk][768]) and leave xbar W^T (fp32) in cw["cvec"]: `rounding` / `rounding_train` then hand it to the head GEMM as its bias
+        (include/dic_hip.h, dic_head_center -- why: DESIGN.md section 4).  DIC_HEAD_CENTER=0 switches it off (A/B)."""
+        if not self.head_centered:
+            cw["centered"] = False
+            return
+        o = self.ops
+        o.begin()
+        _lib.check(o.L.dic_head_center(x_a, n_a, x_b, n_b, L, Tk, 768, _p(self.W_lm), self.vpad, _p(cw["hc_ws"]), _p(cw["xbar"]), _p(cw["cvec"]),
+                                       _p(cw["xr"]), o.stream), "head_center")
+        cw["centered"] = True
+
     def rounding(self, xr, M, tgt=None, ce_ws=None, dtype=None):
         """xr [M,768] (compute dtype) -> (lse[M], argmax[M], nll[M] or None) without materialising the logits."""
         cw = ce_ws or self._ce_workspace(M)
         cw["fused"] = False
         o = self.ops
         o.begin()
+        cbias = _p(cw["cvec"]) if (cw.get("centered") and ce_ws is not None and dtype is None) else 0
         W = self.W_lm_c if dtype is None else (self.W_lm if dtype == DIC_F32 else self.W_lm_c)
         f32 = dtype == DIC_F32 or (dtype is None and not self.bf16)
         tile = 128 if (f32 or _V1_BF16) else choose_tile(M, self.vocab, 1, EPI_CE_PARTIAL)
         np_ = o.L.dic_ce_n_partials(self.vocab, tile)
         o.gemm(_p(xr), _p(W), 0, M, self.vocab, 768, 768, 768, 0, epi=EPI_CE_PARTIAL, tgt=_p(tgt) if tgt is not None else 0,
-               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), dtype=dtype, tile=tile)
+               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), dtype=dtype, tile=tile, bias=cbias)
         _lib.check(o.L.dic_ce_combine(_p(cw["partial"]), _p(cw["tgt_logit"]), M, np_, _p(cw["lse"]), _p(cw["argmax"]),
                                       _p(cw["nll"]) if tgt is not None else 0, o.stream), "ce_combine")
         return cw["lse"], cw["argmax"], (cw["nll"] if tgt is not None else None)
@@ -690,10 +714,11 @@ class Denoiser:
         L = o.L
         tile = choose_tile(M, self.vocab, 1, EPI_CE_EXP)
         np_ = L.dic_ce_n_partials(self.vocab, tile)
+        cbias = _p(cw["cvec"]) if (cw.get("centered") and ce_ws is not None) else 0
         _lib.check(L.dic_ce_target_logit(_p(xr), _p(self.W_lm_c), _p(tgt), M, self.vocab, 768, self.CE_REF_SHIFT, _p(cw["tgt_logit"]), _p(cw["cref"]),
-                                         o.stream), "ce_target_logit")
+                                         cbias, o.stream), "ce_target_logit")
         o.gemm(_p(xr), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_EXP, tgt=_p(tgt), lse=_p(cw["cref"]),
-               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), tile=tile)
+               partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), tile=tile, bias=cbias)
         _lib.check(L.dic_ce_exp_combine(_p(cw["partial"]), np_, _p(cw["cref"]), _p(cw["tgt_logit"]), _p(tgt), M, self.vocab, _p(cw["dlogits"]), self.vpad,
                                         _p(cw["lse"]), _p(cw["nll"]), _p(cw["inv_z"]), o.stream), "ce_exp_combine")
         cw["fused"] = True

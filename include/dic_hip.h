@@ -177,7 +177,18 @@ int dic_ce_combine(const float* partial, const float* tgt_logit, int M, int n_pa
  *     rounding per element -- what CE_DLOGITS writes after a second GEMM.
  *  The gradient w.r.t. xr is then  row_scale[m] * inv_z[m] * (E @ W)[m]:  dic_gemm (k-contiguous A = E, k-major B = W, fp32 out) followed by
  *  dic_add_rows_scaled.                                                                                                            */
-int dic_ce_target_logit(const void* xr_bf16, const void* W_bf16, const int64_t* tgt, int M, int V, int D, float shift, float* t, float* c, void* stream);
+int dic_ce_target_logit(const void* xr_bf16, const void* W_bf16, const int64_t* tgt, int M, int V, int D, float shift, float* t, float* c,
+                        const float* col_bias /* [V] or NULL: added to t (the bias the head GEMM is given, dic_head_center) */, void* stream);
+
+/* Mean-centred input of the rounding head (ref:323 `lm_head(x_out[:, :L])` evaluated as (x - xbar) W^T + xbar W^T; bf16 engines).  The head rows are
+ * rows t < L of the n_a sequences at x_a and the n_b sequences at x_b (each [n][Tk][D] fp32; x_b optional).  Writes xbar [D] = their mean,
+ * cvec [Vpad] = W32 xbar (fp32; W32 is [Vpad][D], rows >= V zero) -- pass it to the head's dic_gemm (CE_PARTIAL / CE_EXP) as `bias` and to
+ * dic_ce_target_logit as col_bias -- and xr [(n_a + n_b) L][D] = bf16(x - xbar).  The logits are the same function of x as before (the backward is
+ * unchanged); what changes is that the part every row shares is no longer rounded to bf16: when the rows are nearly equal, as an early-training
+ * denoiser's are, that rounding error is the same for every row and a batch-mean loss does not average it out.  ws: dic_head_center_ws_bytes(D). */
+size_t dic_head_center_ws_bytes(int D);
+int dic_head_center(const float* x_a, int n_a, const float* x_b, int n_b, int L, int Tk, int D, const float* W32, int Vpad, float* ws,
+                    float* xbar, float* cvec, void* xr_bf16, void* stream);
 int dic_ce_exp_combine(const float* partial, int n_partials, const float* c, const float* tgt_logit, const int64_t* tgt, int M, int V,
                        void* E_bf16, int ldE, float* lse, float* nll, float* inv_z, void* stream);
 

@@ -25,5 +25,10 @@ kst sampling python $R/scripts/bench_sample.py --steps 100 --reps 1 --bleu-batch
 TILE=256 python scripts/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_microbench.txt
 COLD=1 TILE=256 python scripts/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_microbench_cold.txt
 (for tk in 18 34; do echo "Tk=$tk"; TK=$tk python scripts/attn_bench.py 2>&1 | grep p_drop; done) > $O/${TAG}_attn_microbench.txt
+python scripts/gemm_in_step.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16.txt
+python scripts/gemm_in_step.py --dtype bf16w 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16w.txt
+timeout 300 python scripts/experiments/w4a_check.py time 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_w4a_check.txt
+bash scripts/experiments/power_probe.sh > $O/${TAG}_power_probe.txt 2>&1
+python bench.py --quick --dtype bf16w 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16w.json
 if [ -f ab/libdic_trace.so ]; then DIC_HIP_LIB=$R/ab/libdic_trace.so python scripts/experiments/gemm_trace.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_phase_trace.txt; fi
 ls -la $O/${TAG}_*

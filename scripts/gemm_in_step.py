@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--layers", type=int, default=12)
+ap.add_argument("--positions", action="store_true", help="also print every launch of the step in order")
 a = ap.parse_args()
 B, S, L = 512, 1, 16
 dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=30522, CLASSIFIER_FREE_WEIGHT=0.0,
@@ -46,6 +47,10 @@ for pos in range(per):
     key = (round(rs[0][1] / 1e9, 2), round(rs[0][2] / 1e6, 1))
     agg.setdefault(key, []).append(us)
     tot += us
+if a.positions:
+    for pos in range(per):
+        rs = [recs[s * per + pos] for s in range(a.steps)]
+        print(f"pos {pos:3d}  {rs[0][1] / 1e9:8.2f} GFLOP {rs[0][2] / 1e6:8.1f} MB  {sum(r[0] for r in rs) / a.steps * 1e3:8.1f} us")
 for (gf, mb), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     m = sum(v) / len(v)
     print(f"{gf:9.2f} GFLOP {mb:8.1f} MB  x{len(v):3d}/step  {m:8.1f} us  {gf / m * 1e3:7.1f} TFLOP/s  frac {gf / m * 1e3 / 2500:.3f}   {sum(v) / 1e3:6.3f} ms/step  ({mb / m:5.2f} TB/s algorithmic)")
