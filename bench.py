@@ -52,7 +52,7 @@ def relaunch(n):
         have = torch.cuda.device_count()
     except Exception:
         have = 0
-    if have < n:
+    if have < n and os.environ.get("DIC_DIST_SHARE_GPU", "0") != "1":          # (the shared-GPU gloo rig of the tests puts every rank on GPU 0)
         sys.exit(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

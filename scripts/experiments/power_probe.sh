@@ -15,3 +15,14 @@ for v in "-" "DIC_GEMM_W4A=1"; do
   wait $pid
   tail -1 /tmp/pp_bench.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   ->', d['value'], 'captions/s', d['ms_per_step'], 'ms/step')"
 done
+for shape in "8192 8192 8192" "17408 2304 768"; do
+  for m in 0 1; do
+    echo "== GEMM loop, w4a=$m, shape $shape"
+    python scripts/experiments/gemm_power_loop.py $m $shape 9 > /tmp/pp_gemm.log 2>&1 &
+    pid=$!
+    sleep 4
+    for i in 1 2 3; do smi; sleep 1.2; done
+    wait $pid
+    grep sustained /tmp/pp_gemm.log | tail -3
+  done
+done
