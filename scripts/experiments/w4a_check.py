@@ -11,7 +11,7 @@ L = dic.lib()
 GP = dic._lib.GemmParams
 bf = torch.bfloat16
 st = lambda: torch.cuda.current_stream().cuda_stream
-EPI_OF = {"plain": 0, "resid": 0, "mulaux": 7}
+EPI_OF = {"plain": 0, "resid": 0, "mulaux": 7, "dropres": 0}
 
 
 def make(M, N, K, bkm, kind, seed=0):
@@ -25,8 +25,10 @@ def make(M, N, K, bkm, kind, seed=0):
 
 def params(M, N, K, bkm, kind, A, B, bias, side, Cc):
     g = GP(A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, lda=K, ldb=(N if bkm else K), ldc=N, bias=bias.data_ptr() if bias is not None else 0, tile=256)
-    if kind == "resid":
+    if kind in ("resid", "dropres"):
         g.R, g.ldr = side.data_ptr(), N
+    if kind == "dropres":
+        g.p_drop, g.seed = 0.1, 0x1234567890 + M
     if kind == "mulaux":
         g.aux, g.ldaux = side.data_ptr(), N
     return g
@@ -46,7 +48,7 @@ def check():
     ok = True
     shapes = [(256, 256, 256), (512, 256, 256), (256, 512, 768), (1024, 768, 768), (17408, 2304, 768), (4352, 3072, 768), (2048, 2048, 2048), (17408, 768, 3072), (2304, 768, 2304)]
     for bkm in (0, 1):
-        for kind in ("plain", "resid", "mulaux"):
+        for kind in ("plain", "resid", "mulaux") + (() if bkm else ("dropres",)):
             for n_, (M, N, K) in enumerate(shapes):
                 ops = make(M, N, K, bkm, kind, n_)
                 ref = run(M, N, K, bkm, kind, ops, 0)
@@ -95,6 +97,8 @@ if __name__ == "__main__":
             bench(17408, 768, 2304, 1, "resid", cold)           # QKV dX + residual
             bench(17408, 3072, 768, 1, "mulaux", cold)          # FFN-2 dX x gelu'
             bench(17408, 768, 3072, 0, "resid", cold)           # FFN-2 forward without dropout (eval / sampling)
+            bench(17408, 768, 3072, 0, "dropres", cold)         # FFN-2 forward as trained (dropout 0.1 + residual)
+            bench(17408, 768, 768, 0, "dropres", cold)          # out-proj forward as trained
             bench(4096, 4096, 4096, 0, "plain", cold)
             bench(8192, 8192, 8192, 0, "plain", cold, iters=5)
     sys.exit(0 if good else 1)

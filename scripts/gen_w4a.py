@@ -12,7 +12,8 @@ output mapping those of the 8-wave kernel in gemm.hip (same swizzle keys, same B
 loads), so the two kernels produce the same results (the bias is added after the K loop here: last-bit differences).
 
 Variants (one asm body each): B operand k-contiguous (KC: nn.Linear forward) or k-major (KM: input gradients, read with
-ds_read_b64_tr_b16) x epilogue `plain` (+ bias), `resid` (+ bias + residual R), `mulaux` (x aux, the GELU' factor left by the forward).
+ds_read_b64_tr_b16) x epilogue `plain` (+ bias), `resid` (+ bias + residual R), `mulaux` (x aux, the GELU' factor left by the forward), `dropres` (k-contiguous B
+only: dropout(acc + bias) + R, the mask regenerated bit for bit from common.h's pair hash).
 
 LDS (bytes): A stage 0 [0, 32K), A stage 1 [32K, 64K), B stage 0 [64K, 96K), B stage 1 [96K, 128K), tile table [128K, +16K: 512 tiles x {16 B of A / B / C offsets + first column, 16 B holding the side-input offset}).
 
@@ -50,7 +51,8 @@ V_CST = 174              # store lane offset (bytes)
 V_BOFF = 175             # bias lane offset (bytes)
 V_TBL = 176              # LDS address of the tile table (same in every lane)
 V_RST = 177              # side-input lane offset (bytes)
-V_LAST = 241             # (v242..v255 stay with the compiler: the statement's nine vector operands live there)
+V_PAIRB = 242            # dropout: the lane's element-pair index inside the tile
+V_LAST = 242             # (v243..v255 stay with the compiler: the statement's ten vector operands live there)
 R_BLOCK = [0, 16, 178, 194, 210, 226, 64, 80]     # first register of side-input block i (16 registers: slab 0 {rows 0-7, rows 8-15}, slab 1 {..})
 
 S0 = 24
@@ -60,12 +62,13 @@ S_LDR, S_ABYTES, S_BBYTES, S_CBYTES, S_RBYTES, S_KSTEPB, S_NPAIRS, S_LDA64, S_LD
 S_RSA, S_RSB, S_NXA, S_NXB, S_RSC, S_RSBIAS, S_RSR, S_NULL = 52, 56, 60, 64, 68, 72, 76, 80
 S_NXC_OFF, S_NXN0, S_CUR_C_OFF, S_CUR_N0, S_KA, S_KB, S_PAIRS, S_TILE, S_TIDX, S_M0A, S_M0B, S_LDC16, S_LDC8, S_SOFF = range(84, 98)
 S_T = 98                 # 98..101 scratch
-S_LDR16, S_LDR8, S_NXR_OFF, S_CUR_R_OFF = 19, 20, 22, 23     # (below S0: listed separately in the clobbers)
-S_EXTRA = [19, 20, 21, 22, 23]
+S_LDR16, S_LDR8, S_NXPAIR, S_NXR_OFF, S_CUR_R_OFF = 19, 20, 21, 22, 23     # (below S0: listed separately in the clobbers)
+S_N8, S_HC2, S_HC1, S_CURPAIR = 15, 16, 17, 18           # dropout: 8 N (pairs per 16 rows), the hash multipliers, the tile's first pair index
+S_EXTRA = [15, 16, 17, 18, 19, 20, 21, 22, 23]
 S_LAST = 101
 
-OPS = ["tbl", "voA0", "voBbase", "chunkx", "aA0", "aB0", "cst", "boff", "rst",          # "v"
-       "karg", "ntiles", "m0A", "m0B"]                                                 # "s" (karg: 64-bit)
+OPS = ["tbl", "voA0", "voBbase", "chunkx", "aA0", "aB0", "cst", "boff", "rst", "pairb",  # "v"
+       "karg", "ntiles", "m0A", "m0B", "dkey", "dthr", "dinv"]                         # "s" (karg: 64-bit)
 OP = {n: f"%{i}" for i, n in enumerate(OPS)}
 
 
@@ -114,7 +117,8 @@ class Gen:
         self.bkm, self.epi = bkm, epi
         self.a = Asm()
         self.gen = 0
-        self.side = epi in ("resid", "mulaux")
+        self.side = epi in ("resid", "mulaux", "dropres")
+        self.drop = epi == "dropres"
 
     # ---------------------------------------------------------------- fragment reads / DMA
     def read_b(self, j, kk, stage, gen):
@@ -265,6 +269,9 @@ class Gen:
         a(f"v_mov_b32 v{V_CST}, {OP['cst']}")
         a(f"v_mov_b32 v{V_BOFF}, {OP['boff']}")
         a(f"v_mov_b32 v{V_RST}, {OP['rst']}")
+        a(f"v_mov_b32 v{V_PAIRB}, {OP['pairb']}")
+        a(f"s_mov_b32 s{S_HC1}, 0x7feb352d")
+        a(f"s_mov_b32 s{S_HC2}, 0x846ca68b")
         a(f"v_mov_b32 v{V_AA[0]}, {OP['aA0']}")
         a(f"v_xor_b32 v{V_AA[1]}, 64, {OP['aA0']}")
         a(f"v_mov_b32 v{V_AB[0]}, {OP['aB0']}")
@@ -294,6 +301,7 @@ class Gen:
         else:
             a(f"s_mov_b32 s{S_KSTEPB}, 128")
         a(f"s_lshl_b32 s{S_BIASBYTES}, s{S_N}, 2")
+        a(f"s_lshl_b32 s{S_N8}, s{S_N}, 3")
 
         def bytes_of(dst, rows, ld, cols):                    # ((rows - 1) * ld + cols) * 2
             a(f"s_sub_u32 s{S_T}, s{rows}, 1")
@@ -338,13 +346,14 @@ class Gen:
             a(f"s_lshl_b32 s{S_T}, s{S_TIDX}, 4")
             a(f"v_add_u32 v{V_T}, s{S_T}, v{V_TBL}")
             a(f"ds_read_b128 v[{V_T + 4}:{V_T + 7}], v{V_T}")
-            a(f"ds_read_b32 v{V_T + 8}, v{V_T} offset:8192")
+            a(f"ds_read_b64 v[{V_T + 8}:{V_T + 9}], v{V_T} offset:8192")
             a("s_waitcnt lgkmcnt(0)")
             a(f"v_readfirstlane_b32 s{S_T}, v{V_T + 4}")
             a(f"v_readfirstlane_b32 s{S_T + 1}, v{V_T + 5}")
             a(f"v_readfirstlane_b32 s{S_NXC_OFF}, v{V_T + 6}")
             a(f"v_readfirstlane_b32 s{S_NXN0}, v{V_T + 7}")
             a(f"v_readfirstlane_b32 s{S_NXR_OFF}, v{V_T + 8}")
+            a(f"v_readfirstlane_b32 s{S_NXPAIR}, v{V_T + 9}")
             a("s_nop 3")
             a(f"s_add_u32 s{S_NXA}, s{S_A}, s{S_T}")
             a(f"s_addc_u32 s{S_NXA + 1}, s{S_A + 1}, 0")
@@ -385,6 +394,7 @@ class Gen:
             a(f"s_mov_b32 s{S_CUR_C_OFF}, s{S_NXC_OFF}")
             a(f"s_mov_b32 s{S_CUR_N0}, s{S_NXN0}")
             a(f"s_mov_b32 s{S_CUR_R_OFF}, s{S_NXR_OFF}")
+            a(f"s_mov_b32 s{S_CURPAIR}, s{S_NXPAIR}")
 
         # ---- kernel prologue: tile 0's descriptors, its first two K-steps, 32 null stores (the first K-step's vmcnt count assumes an epilogue
         # before it; side-input variants: + the 4 loads of side block 7), its first fragments
@@ -475,6 +485,33 @@ class Gen:
                         if self.epi != "mulaux":
                             a(f"v_pk_add_f32 v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 1}]")
                             a(f"v_pk_add_f32 v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{V_BIAS + 4 * j + 2}:{V_BIAS + 4 * j + 3}]")
+                        if self.drop:
+                            # dropout on (acc + bias), mask from the 2-multiply avalanche hash of (seed, element pair) -- common.h dropout4 / pair_hash,
+                            # bit for bit (ln_bwd regenerates the same mask): pair = (m N + n) / 2; one 32-bit hash decides two elements (16-bit thresholds)
+                            P, H0, H1, TT = T + 16, T + 17, T + 18, T + 19
+                            a(f"s_mul_i32 s{S_T}, s{S_N8}, {i}")
+                            a(f"s_add_u32 s{S_T}, s{S_T}, {32 * slab + 16 * qp + 2 * e}")
+                            a(f"s_add_u32 s{S_T}, s{S_T}, s{S_CURPAIR}")
+                            a(f"v_add_u32 v{P}, s{S_T}, v{V_PAIRB}")
+                            a(f"v_xor_b32 v{H0}, {OP['dkey']}, v{P}")
+                            a(f"v_add_u32 v{H1}, 1, v{P}")
+                            a(f"v_xor_b32 v{H1}, {OP['dkey']}, v{H1}")
+                            for sh, mul in ((16, S_HC1), (15, S_HC2), (16, None)):
+                                for H in (H0, H1):
+                                    a(f"v_lshrrev_b32 v{TT}, {sh}, v{H}")
+                                    a(f"v_xor_b32 v{H}, v{H}, v{TT}")
+                                    if mul is not None:
+                                        a(f"v_mul_lo_u32 v{H}, v{H}, s{mul}")
+                            for r in range(4):
+                                a(f"v_mul_f32 v{T + 8 + r}, {OP['dinv']}, v{T + 8 + r}")
+                            for r in range(4):
+                                H = H0 if r < 2 else H1
+                                if r & 1:
+                                    a(f"v_lshrrev_b32 v{TT}, 16, v{H}")
+                                else:
+                                    a(f"v_and_b32 v{TT}, 0xffff, v{H}")
+                                a(f"v_cmp_le_u32 vcc, {OP['dthr']}, v{TT}")
+                                a(f"v_cndmask_b32 v{T + 8 + r}, 0, v{T + 8 + r}, vcc")
                         if self.side:
                             src = (R_BLOCK[i] + 8 * slab + (4 if qp else 0)) + 2 * e          # two dwords: columns 4e..4e+3 of the chunk
                             a(f"v_lshlrev_b32 v{T + 20}, 16, v{src}")
@@ -521,9 +558,9 @@ def main():
         f.write(f"#define W4A_N_OPERANDS {len(OPS)}\n")
         f.write("// operand order: " + " ".join(OPS) + "\n")
         f.write("#define W4A_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(V_LAST + 1)] + [f'"a{i}"' for i in range(256)] +
-                                                    [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"scc"', '"m0"', '"memory"']) + "\n")
+                                                    [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"vcc"', '"scc"', '"m0"', '"memory"']) + "\n")
         for bkm in (False, True):
-            for epi in ("plain", "resid", "mulaux"):
+            for epi in ("plain", "resid", "mulaux") + (() if bkm else ("dropres",)):
                 lines = Gen(bkm, epi).body()
                 name = f"W4A_BODY_{'KM' if bkm else 'KC'}_{epi.upper()}"
                 f.write(f"#define {name} \\\n")

@@ -196,7 +196,7 @@ def test_gemm_split_weight_second_pass(L, tile, M, N, K, epi):
 
 
 @pytest.mark.parametrize("b_km", [0, 1])
-@pytest.mark.parametrize("kind", ["plain", "bias", "resid", "bias_resid", "mulaux"])
+@pytest.mark.parametrize("kind", ["plain", "bias", "resid", "bias_resid", "mulaux", "bias_resid_drop"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (768, 512, 384), (2304, 768, 3072), (4352, 2304, 768)])
 def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, N, K, kind, b_km):
     """dic_gemm_set_w4a(1): eligible launches (bf16, k-contiguous A, M and N multiples of 256, K of 128; AFFINE with optional bias / residual, MUL_AUX)
@@ -220,6 +220,10 @@ def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, 
         kw.update(R=p(Sd), ldr=N)
     if kind == "mulaux":
         kw.update(aux=p(Sd), ldaux=N)
+    if "drop" in kind:
+        if b_km:
+            pytest.skip("dropout exists on the forward (k-contiguous B) launches only")
+        kw.update(p_drop=0.1, seed=0xABCDEF0123 + M)
     epi = 7 if kind == "mulaux" else 0
     outs = []
     for mode in (0, 1):
@@ -230,6 +234,11 @@ def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, 
         finally:
             L.dic_gemm_set_w4a(prev)
         outs.append(Cd)
+    if "drop" in kind:
+        # the mask must be the 8-wave kernel's (ln_bwd regenerates it from the same hash): identical zero pattern of (out - R), kept elements scaled by 1 / 0.9
+        kept0, kept1 = (outs[0].float() - Sd.float()) != 0, (outs[1].float() - Sd.float()) != 0
+        assert torch.equal(kept0, kept1) and abs(float((~kept1).float().mean()) - 0.1) < 0.01
+        exact = torch.where(kept1.cpu(), (exact - Sd.float().cpu().double()) * (65536.0 / (65536.0 - 6554.0)) + Sd.float().cpu().double(), Sd.float().cpu().double())
     assert relerr(outs[1].float(), exact) < 6e-3
     d = (outs[1].float() - outs[0].float()).abs()
     assert int((d > outs[0].float().abs() * 2 ** -6 + 2e-3).sum()) == 0

@@ -381,3 +381,24 @@ def test_checkpointed_rng_streams_are_rederived_per_rank(monkeypatch):
     nxt2 = diffusion._guidance_uniform(3, "cpu")
     diffusion.set_rng_state(st2, m2)
     assert torch.equal(diffusion._guidance_uniform(3, "cpu"), nxt2)
+
+
+def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_path):
+    """csrc/gemm_w4a_asm.inc is generated (scripts/gen_w4a.py places every instruction of the four-wave GEMM's main loops and derives every counted
+    wait from its own issue order): the committed file must be exactly what the committed generator writes, and the schedule's invariants hold --
+    512 MFMAs per K-step pair and variant body in the steady-state loop, every lgkmcnt within the 4-bit counter."""
+    import re
+    import subprocess
+    import sys
+    out = tmp_path / "w4a.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_w4a.py"), str(out)], check=True, capture_output=True)
+    want = open(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "gemm_w4a_asm.inc")).read()
+    got = open(out).read()
+    assert got == want, "regenerate: python scripts/gen_w4a.py diffusion-image-captioning_amd/csrc/gemm_w4a_asm.inc"
+    bodies = re.findall(r"#define (W4A_BODY_\w+) \\\n((?:    \".*\n?)+)", got)
+    assert len(bodies) >= 6
+    for name, text in bodies:
+        assert text.count("v_mfma_f32_16x16x32_bf16") % 256 == 0 and text.count("v_mfma_f32_16x16x32_bf16") >= 6 * 128, name      # whole K-steps only
+        assert all(int(n) <= 15 for n in re.findall(r"lgkmcnt\((\d+)\)", text)), name
+        assert all(int(n) <= 63 for n in re.findall(r"vmcnt\((\d+)\)", text)), name
+        assert text.count("s_barrier") >= 2 * 6, name
