@@ -124,6 +124,12 @@ def fit(model, trainer, train_loader, val_loader, epochs=None, scheduler="linspa
 
 
 # ------------------------------------------------------------------ BLEU evaluation (ref :604-631)
+def caption_references(image_names, captions_by_image):
+    """ref :625-627: per image of the batch, every caption of that image as "[CLS] <caption, stripped, lower-cased> [SEP]" -- the
+    string form `tokenizer.decode` gives the sampled ids (special tokens kept), so both sides split into the same words."""
+    return [["[CLS] " + c.strip().lower() + " [SEP]" for c in captions_by_image[name]] for name in image_names]
+
+
 @torch.no_grad()
 def evaluate_bleu(model, val_loader, references_for, decode=None, steps=5):
     """For each validation batch: sample ids from pure noise (`steps` refinement passes), drop repeated columns
