@@ -9,8 +9,9 @@ sum of the reference lengths closest to each candidate's length.  Ties in |len(r
 in list order: torchmetrics' `_bleu_score_update` takes `target_len_list[target_len_diff.index(min(target_len_diff))]`, and
 `list.index` returns the first minimum (NLTK's corpus_bleu would take the shorter one -- the two differ exactly when a longer
 reference precedes an equally distant shorter one, which tests/test_next_rows.py pins).  Any zero precision gives 0 (no
-smoothing).  PARITY UNPINNED against torchmetrics itself (absent here, no network); pinned by hand-computed cases and a
-brute-force restatement in tests/test_next_rows.py.
+smoothing).  PARITY UNPINNED against torchmetrics itself (absent here, no network); held by hand-computed cases, a brute-force
+restatement and the two libraries' documented examples (0.7598 / 0.8408964276313782) in tests/test_next_rows.py.  The string side of the
+loop (tokenizer call, `tokenizer.decode`) is in wordpiece.py and IS pinned against transformers' tokenizer.
 """
 from __future__ import annotations
 

@@ -56,6 +56,21 @@ def test_bleu_hand_cases():
     assert bleu.corpus_bleu([torch.tensor([1, 2, 3, 4, 5])], [[torch.tensor([1, 2, 3, 4, 5])]]) == pytest.approx(1.0)
 
 
+def test_bleu_published_examples_of_the_two_libraries_the_reference_calls():
+    """The only outside anchors available offline: the worked examples in the documentation of the two BLEU functions the reference
+    calls.  torchmetrics.text.BLEUScore (ref CLIP-DDPM.py:604-606): preds ['the cat is on the mat'], target [['there is a cat on the mat',
+    'a cat is on the mat']] -> 0.7598 (= (1/3)^(1/4): clipped precisions 5/6, 4/5, 3/4, 2/3, no brevity penalty).
+    torchtext.data.metrics.bleu_score (ref COCO_BLEU.py:263): two candidates / references below -> 0.8408964276313782 (= 0.5^(1/4):
+    corpus-level sums 4/6, 3/4, 2/2, 1/1, c = r = 6).  Neither library is installed here, so these are known-answer vectors, not a run of them."""
+    got = bleu.corpus_bleu(["the cat is on the mat"], [["there is a cat on the mat", "a cat is on the mat"]])
+    assert got == pytest.approx((1 / 3) ** 0.25, rel=1e-12) and round(got, 4) == 0.7598
+    cands = [["My", "full", "pytorch", "test"], ["Another", "Sentence"]]
+    refs = [[["My", "full", "pytorch", "test"], ["Completely", "Different"]], [["No", "Match"]]]
+    got = bleu.corpus_bleu(cands, refs)
+    assert got == pytest.approx(0.8408964276313782, rel=1e-7)
+    assert brute_bleu(cands, refs) == pytest.approx(got, rel=1e-12)
+
+
 def test_bleu_length_tie_break_is_first_in_list_order():
     """torchmetrics `_bleu_score_update`: target_len_list[target_len_diff.index(min(target_len_diff))] -- the FIRST reference among
     those equally close in length, not the shorter one (NLTK's rule).  Candidate of 6 tokens, references of 7 and 5 tokens."""
