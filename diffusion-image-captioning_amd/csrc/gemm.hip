@@ -1262,7 +1262,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
     constexpr bool XT = DIC_GEMM_XT != 0;
     // (the rounding-head epilogues take a per-column bias too: the row-common part of the logits of a mean-centred head input, dic_head_center)
     constexpr bool BIAS_INIT = !XT && !GROUP && !AKM && !BKM && (EPI == DIC_EPI_AFFINE || EPI == DIC_EPI_BIAS_GELU || EPI == DIC_EPI_BIAS_GELU_D ||
-                                                                 EPI == DIC_EPI_CE_PARTIAL || EPI == DIC_EPI_CE_EXP);
+                                                                 EPI == DIC_EPI_CE_PARTIAL || EPI == DIC_EPI_CE_EXP || EPI == DIC_EPI_CE_DLOGITS);
     f32x4 binit[BIAS_INIT ? G::FN : 1];
     auto load_bias = [&](const TileId& t_) {
         if constexpr (BIAS_INIT) {

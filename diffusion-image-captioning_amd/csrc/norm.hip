@@ -278,8 +278,9 @@ __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const T* u, const floa
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(64 * LNB_WAVES) void gelu_ln_bwd_kernel(const float* dx_out, const T* u, const float* gamma, const float* mean, const float* rstd, T* du,
+// TU: type of the stored pre-activation u (fp32 in the bf16 engines when DIC_U_F32 is set: see dic_gelu_ln_fwd), T: type of the gradient written
+template <typename T, typename TU = T>
+__global__ __launch_bounds__(64 * LNB_WAVES) void gelu_ln_bwd_kernel(const float* dx_out, const TU* u, const float* gamma, const float* mean, const float* rstd, T* du,
                                                            float* partial, int rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gelu_ln_bwd_kernel(const float
         for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         f32x4 uu[NCH], v[NCH], d[NCH];
-        load_row<T>(u + (size_t)row * D, lane, uu);
+        load_row<TU>(u + (size_t)row * D, lane, uu);
         load_row<float>(dx_out + (size_t)row * D, lane, d);
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
@@ -414,6 +415,7 @@ extern "C" int dic_gelu_ln_fwd(int dtype, const void* u, const float* gamma, con
     DIC_REQUIRE(Dd == D && T > 0, "dic_gelu_ln_fwd: D must be 768");
     dim3 grid(rows_grid(T, 2048)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype & DIC_U_F32) dtype = DIC_F32;            // u was stored in fp32 (x_out always is): the fp32 kernel is the whole forward
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(gelu_ln_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)u, gamma, beta, x_out, mean, rstd, T, eps),
                hipLaunchKernelGGL(gelu_ln_fwd_kernel<float>, grid, block, 0, st, (const float*)u, gamma, beta, x_out, mean, rstd, T, eps));
@@ -429,9 +431,16 @@ extern "C" int dic_gelu_ln_bwd(int dtype, const float* dx_out, const void* u, co
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gelu_ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gelu_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gelu_ln_bwd_kernel<bf16_t, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == (DIC_BF16 | DIC_U_F32)) {             // fp32 u, bf16 gradient (the bf16 engines' default)
+        hipLaunchKernelGGL((gelu_ln_bwd_kernel<bf16_t, float>), grid, block, lds, st, dx_out, (const float*)u, gamma, mean, rstd, (bf16_t*)du, partial, T);
+        DIC_CHECK_LAUNCH();
+        return 0;
+    }
+    dtype &= ~DIC_U_F32;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(gelu_ln_bwd_kernel<bf16_t>, grid, block, lds, st, dx_out, (const bf16_t*)u, gamma, mean, rstd, (bf16_t*)du, partial, T),
                hipLaunchKernelGGL(gelu_ln_bwd_kernel<float>, grid, block, lds, st, dx_out, (const float*)u, gamma, mean, rstd, (float*)du, partial, T));

@@ -76,11 +76,14 @@ _GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GEL
 # bf16 engine: FFN-1's forward epilogue leaves gelu'(u) behind instead of u (same bytes), so the backward's epilogue is one multiply (MUL_AUX)
 # instead of erf + exp per element (round-3 review item 3; "0": the round-3 form, kept as the A/B partner and for the fp32 engine)
 _GELU_D = _os.environ.get("DIC_GELU_D", "1") != "0"
-_PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"
-# mean-centred rounding-head input (Denoiser.center_head_input): "auto" = on in the split-weight parity mode (bf16w), off in the plain bf16
-# throughput mode (it costs 4 small launches, ~0.1 ms of a 14 ms step); "1" / "0" force it for both (A/B switch)
-_HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "auto")   # the two LayerNorm-gradient folds of a layer in one launch (A/B switch)
+_PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"      # the two LayerNorm-gradient folds of a layer in one launch (A/B switch)
+# mean-centred rounding-head input (Denoiser.center_head_input): on in both bf16 engines (4 small launches, ~0.1 ms of a 14 ms step: without it
+# the rounding loss of a collapsed denoiser -- the first hundreds of training steps -- is 1.5-2.5e-4 off, profiles/r04_collapse_probe.txt
+# "only xr"); "0" switches it off, "w" keeps it to the split-weight mode as before (A/B switches)
+_HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "1")
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
+_UVT32 = _os.environ.get("DIC_UVT32", "1") != "0"
+DIC_U_F32 = 0x100
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
 
@@ -139,7 +142,11 @@ class Denoiser:
         if split_weights is None:
             split_weights = dtype == "bf16w" or _os0.environ.get("DIC_SPLIT_W", "0") == "1"
         self.split_w = bool(split_weights) and self.bf16
+        self.split_slots = None      # None: every forward Linear adds its lo half; else a predicate slot -> bool (precision-allocation probes)
         self.dt = DIC_BF16 if self.bf16 else DIC_F32
+        # bf16 engines keep the MLM-head pre-activation (vocab_transform's output) in fp32: include/dic_hip.h, DIC_U_F32 (DIC_UVT32=0: A/B)
+        self.uvt32 = self.bf16 and _UVT32
+        self.dt_u = (self.dt | DIC_U_F32) if self.uvt32 else self.dt
         self.tdtype = torch.bfloat16 if self.bf16 else torch.float32
         self.es = 2 if self.bf16 else 4
         self.concat = cfg.CLIP_ADDING_METHOD == "concat"
@@ -321,7 +328,7 @@ class Denoiser:
         ws["mean0"], ws["rstd0"] = f(T), f(T)
         ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=e(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
                              y2=e(T, D), m2=f(T), r2=f(T)) for _ in range(self.n_layers)]
-        ws["uvt"], ws["mv"], ws["rv"] = e(T, D), f(T), f(T)
+        ws["uvt"], ws["mv"], ws["rv"] = (f(T, D) if self.uvt32 else e(T, D)), f(T), f(T)
         ws["x_out"] = f(N, Tk, D)
         # backward scratch (shared by all layers)
         ws["dx_out"] = f(N, Tk, D)
@@ -384,7 +391,8 @@ class Denoiser:
         self._seed += 64
         seed = self._seed
         ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
-        lo = (lambda slot: P.ptr(slot, "Pl")) if self.split_w else (lambda slot: 0)       # low-order weight halves (split-weight mode)
+        sel = self.split_slots
+        lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if self.split_w else (lambda slot: 0)   # low-order weight halves
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
         ws["has_u"] = keep_u
         gelu_d = ws["gelu_d"] = self.bf16 and _GELU_D and not _V1_BF16          # Lw["u"] then holds gelu'(u), not u
@@ -433,8 +441,8 @@ class Denoiser:
                    p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"))
             _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
         # K9: MLM-head transform: Linear -> GELU -> LayerNorm
-        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"), B2=lo("Wvt"))
-        _lib.check(lib.dic_gelu_ln_fwd(self.dt, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
+        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"), B2=lo("Wvt"), out_f32=int(self.uvt32))
+        _lib.check(lib.dic_gelu_ln_fwd(self.dt_u, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
         self._saved = ws
         return ws["x_out"][:N]
 
@@ -574,7 +582,7 @@ class Denoiser:
         nl = self.n_layers
         sp = nl & 1
         dyb = ws["dy"][sp]
-        _lib.check(lib.dic_gelu_ln_bwd(self.dt, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), parts[2 * sp], NPART, T, D, st), "gelu_ln_bwd")
+        _lib.check(lib.dic_gelu_ln_bwd(self.dt_u, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), parts[2 * sp], NPART, T, D, st), "gelu_ln_bwd")
         fold(parts[2 * sp], 3 * D, P.ptr("vln_g", "G"))                                      # [vln_g | vln_b | bvt]
         wgrad(_p(dyb), _p(ws["h"][-1]), "Wvt", D, D, D, D)
         finish_layer(nl)
@@ -660,7 +668,7 @@ class Denoiser:
     # ------------------------------------------------------------------ rounding head: streaming CE / argmax (ref :323, 436-437, 620)
     @property
     def head_centered(self):
-        return self.bf16 and not self.te and (_HEAD_CENTER == "1" or (_HEAD_CENTER == "auto" and self.split_w))
+        return self.bf16 and not self.te and (_HEAD_CENTER == "1" or (_HEAD_CENTER in ("w", "auto") and self.split_w))
 
     def center_head_input(self, cw, x_a, n_a, x_b, n_b, L, Tk):
         """bf16 engines: rewrite cw["xr"] as bf16(x - xbar) over the head rows (rows t < L of the n_a sequences at x_a and the n_b at x_b, fp32
@@ -733,9 +741,10 @@ class Denoiser:
         if cw["dlogits"] is None:
             cw["dlogits"] = torch.empty(M, self.vpad, dtype=self.tdtype, device=self.device)
         ws_split = self._saved["splitk"]
-        if not cw.get("fused"):
+        if not cw.get("fused"):          # (a mean-centred head input: the recomputed logits need the same column bias as the forward's)
             o.gemm(_p(cw["xr"]), _p(self.W_lm_c), _p(cw["dlogits"]), M, self.vocab, 768, 768, 768, self.vpad, epi=EPI_CE_DLOGITS,
-                   tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b)
+                   tgt=_p(cw["tgt"]), lse=_p(cw["lse"]), ce_rows_a=rows_a, ce_scale_a=scale_a, ce_scale_b=scale_b,
+                   bias=_p(cw["cvec"]) if cw.get("centered") else 0)
         # 64 x 3 = 192 256-tiles are 0.75 of a round and x2 slices 1.5 rounds: four slices of the 30592-deep contraction fill
         # three rounds exactly (measured at M = 16384: 862 us vs 1064 us for two slices, 1032 us unsplit)
         sk = next((k for k in (4, 2) if M * 768 * k <= ws_split.numel() and M >= 2048), 1)

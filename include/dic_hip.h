@@ -27,6 +27,8 @@ extern "C" {
 
 #define DIC_F32 0
 #define DIC_BF16 1
+/* flag on the `dtype` of dic_gelu_ln_fwd / dic_gelu_ln_bwd: the MLM-head pre-activation u is stored in fp32 whatever the engine's type */
+#define DIC_U_F32 0x100
 
 int dic_version(void);
 const char* dic_last_error(void);
@@ -46,7 +48,7 @@ const char* dic_last_error(void);
  *   CE_PARTIAL  per (row, 64-col half tile): {max, sum exp(x-max), first argmax}; tgt_logit[m] = acc[m][tgt[m]]
  *               -- streaming form of softmax/gather/argmax over the 30522-wide logits (ref:323,436-437,620)
  *   CE_DLOGITS  C = (exp(acc - lse[m]) - [n == tgt[m]]) * (m < ce_rows_a ? ce_scale_a : ce_scale_b),
- *               zero for N <= n < ldc                                        -- backward of the rounding loss
+ *               zero for N <= n < ldc                                        -- backward of the rounding loss (recompute form)
  *   CE_EXP      C = exp(acc - lse[m]) (bf16; `lse` holds the caller's per-row REFERENCE POINT c[m], see dic_ce_target_logit), zero for
  *               N <= n < ldc; partial[m][n/64] = sum of the unrounded values over that 64-column slab (np floats per row, np =
  *               dic_ce_n_partials(N, tile)); tgt_logit[m] = acc[m][tgt[m]].  The training forward of the rounding loss: dic_ce_exp_combine
@@ -182,7 +184,7 @@ int dic_ce_target_logit(const void* xr_bf16, const void* W_bf16, const int64_t* 
 
 /* Mean-centred input of the rounding head (ref:323 `lm_head(x_out[:, :L])` evaluated as (x - xbar) W^T + xbar W^T; bf16 engines).  The head rows are
  * rows t < L of the n_a sequences at x_a and the n_b sequences at x_b (each [n][Tk][D] fp32; x_b optional).  Writes xbar [D] = their mean,
- * cvec [Vpad] = W32 xbar (fp32; W32 is [Vpad][D], rows >= V zero) -- pass it to the head's dic_gemm (CE_PARTIAL / CE_EXP) as `bias` and to
+ * cvec [Vpad] = W32 xbar (fp32; W32 is [Vpad][D], rows >= V zero) -- pass it to the head's dic_gemm (CE_PARTIAL / CE_EXP / CE_DLOGITS; bf16 LDS-DMA kernels) as `bias` and to
  * dic_ce_target_logit as col_bias -- and xr [(n_a + n_b) L][D] = bf16(x - xbar).  The logits are the same function of x as before (the backward is
  * unchanged); what changes is that the part every row shares is no longer rounded to bf16: when the rows are nearly equal, as an early-training
  * denoiser's are, that rounding error is the same for every row and a batch-mean loss does not average it out.  ws: dic_head_center_ws_bytes(D). */
@@ -241,7 +243,10 @@ int dic_ln_bwd(int dtype, const void* dh, const void* y, const float* gamma, con
                void* dx, void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks,
                int T, int D, void* stream);
 
-/* ---------------------------------------------------------------- MLM-head GELU + LayerNorm (hf:511-512) */
+/* ---------------------------------------------------------------- MLM-head GELU + LayerNorm (hf:511-512)
+ * dtype | DIC_U_F32: u is fp32 (the vocab_transform GEMM wrote it with out_f32) while du stays the engine's type.  The bf16 engines set it:
+ * in a denoiser whose output has (half-)collapsed onto one row -- the first few hundred steps of training -- the bf16 rounding of u is the
+ * same for every token, does not average out of the batch-mean L1 terms and alone moves them by 2-4e-4 (profiles/r04_collapse_probe.txt). */
 int dic_gelu_ln_fwd(int dtype, const void* u, const float* gamma, const float* beta, float* x_out,
                     float* mean, float* rstd, int T, int D, float eps, void* stream);
 /* du (T) from dx_out (f32); partial [nblocks][3*D] = {dgamma, dbeta, colsum(du)}                                   */

@@ -48,18 +48,19 @@ def run(points, P, E, batch, t, nz, layers, L=16):
     r = lambda name, x: bf(x) if name in points else x
     W = lambda n: r("w", P[n])
     B = batch["input_ids"].shape[0]
-    betas = torch.hstack([torch.zeros(1), torch.linspace(1e-4, 0.02, 100)])
+    dev = E.device                                                          # (round 4: the same what-if on the GPU, collapse_probe.py)
+    betas = torch.hstack([torch.zeros(1), torch.linspace(1e-4, 0.02, 100)]).to(dev)
     ac = torch.cumprod((1 - betas)[:-1], 0)
     x0 = E[batch["input_ids"]]
 
     def diffuse(x, tt, eps):
         return torch.sqrt(ac[tt]).reshape(-1, 1, 1) * x + eps * torch.sqrt(1 - ac[tt]).reshape(-1, 1, 1)
     x_t = diffuse(x0, t.reshape(-1), nz[0])
-    x_1 = diffuse(x0, torch.ones(1, dtype=torch.int64), nz[1])
+    x_1 = diffuse(x0, torch.ones(1, dtype=torch.int64, device=dev), nz[1])
     x = torch.cat([x_t, x_1])                                               # one stacked batch, like the engine
     n = x.shape[0]
     img = F.linear(batch["image_clip"].repeat(2, 1), P["image_linear.weight"], P["image_linear.bias"])
-    mask = torch.cat([batch["attention_mask"].repeat(2, 1), torch.ones(n, 1, dtype=torch.int64)], 1)       # text row dropped (masked, never read)
+    mask = torch.cat([batch["attention_mask"].repeat(2, 1), torch.ones(n, 1, dtype=torch.int64, device=dev)], 1)       # text row dropped (masked, never read)
     seg = P["segment_embedding.weight"]
     pre = "model.distilbert."
     h = torch.cat([x + seg[0], (img + seg[1]).unsqueeze(1)], 1) + P[pre + "embeddings.position_embeddings.weight"][:L + 1]
@@ -87,7 +88,7 @@ def run(points, P, E, batch, t, nz, layers, L=16):
     xt_loss, x1_loss = l1[:B].mean(), l1[B:].mean()
     Wl = r("wlm", E)
     ids = batch["input_ids"].repeat(2, 1)
-    nll = torch.empty(n, L)
+    nll = torch.empty(n, L, device=dev)
     xr = r("xr", xo)
     for a in range(0, n, 128):                                             # logits in row blocks (never 2 GB at once)
         lg = xr[a:a + 128].reshape(-1, 768) @ Wl.t()

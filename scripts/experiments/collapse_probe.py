@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Which bf16 rounding points carry the loss gap of the bf16 / bf16w engines ALONG a training run?
+
+split_alloc_probe.py --trajectory showed that between ~5 and ~60 AdamW steps (and again around 320) even dtype="bf16w" (every forward weight
+hi+lo) is 1-4e-4 away from fp32 on the x_t / x_1 terms: there the weights are not the cause.  This probe trains the bf16w engine along the same
+trajectory and, at each state, runs the host what-if of bf16_drift_sim.py ON THE GPU (torch fp32 matmuls, TF32 off) on a held-out batch with
+the engine's rounding points switched on one group at a time, so the rounding point that matters in a half-collapsed denoiser is named.
+    python scripts/experiments/collapse_probe.py [--trajectory 0,5,10,20,40,320]
+"""
+import argparse, importlib, os, sys
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sim = importlib.import_module("bf16_drift_sim")
+dic = importlib.import_module("diffusion-image-captioning_amd")
+ap = argparse.ArgumentParser()
+ap.add_argument("--trajectory", default="0,5,10,20,40,320")
+ap.add_argument("--layers", type=int, default=12)
+ap.add_argument("--batch", type=int, default=512)
+args = ap.parse_args()
+torch.backends.cuda.matmul.allow_tf32 = False
+B, L, NL = args.batch, 16, args.layers
+dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=1, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=30522, CLASSIFIER_FREE_WEIGHT=0.0,
+               CLIP_ADDING_METHOD="concat", LOSS_FUNC="series_sum_sample_mean", X_0_PREDICTION=True, ROUNDING_WEIGHT=0.5)
+dev = "cuda:0"
+E = torch.from_numpy(dic.synth.vocab_embedding(30522, 768, 0))
+bw = dic.DistilBertModel(E, E, dtype="bf16w", config=dict(n_layers=NL, dropout=0.0, attention_dropout=0.0), device=dev, seed=0)
+Ed = E.to(dev)
+held = {k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=1).items()}
+t = torch.from_numpy(dic.synth.timesteps(1, 100, 0)).to(dev)
+nz = [torch.from_numpy(dic.synth.noise((B, L, 768), 3, f"eps{i}")).to(dev) for i in range(2)]
+train = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=100 + i).items()} for i in range(8)]
+trainer = dic.AdamW(bw.parameters(), lr=1e-4)
+dic.seed_noise(1234)
+dic.diffusion.seed_timesteps(4321)
+ALL = set(sim.ALL)
+ACT = ALL - {"w", "wlm"}
+GROUPS = [("every point (= bf16)", ALL), ("all but the weights (= bf16w)", ACT),
+          ("only the weights", {"w", "wlm"})] + [(f"only {p}", {p}) for p in sorted(ACT)] + [
+          ("residual stream (h_res, sa_res, y1, y2)", {"h_res", "sa_res", "y1", "y2"}), ("GEMM operands (h_op, sa_op, ctx, g)", {"h_op", "sa_op", "ctx", "g"}),
+          ("bf16w minus uvt", ACT - {"uvt"}), ("bf16w minus uvt, h_op", ACT - {"uvt", "h_op"}), ("bf16w minus residual stream", ACT - {"h_res", "sa_res", "y1", "y2"}),
+          ("bf16w minus residual stream, uvt", ACT - {"h_res", "sa_res", "y1", "y2", "uvt"})]
+done = 0
+for upto in [int(v) for v in args.trajectory.split(",")]:
+    bw.train()
+    while done < upto:
+        dic.train_func(bw, trainer, train[done % 8])
+        done += 1
+    P = {k: v.to(dev, torch.float32) for k, v in bw.state_dict().items()}
+    with torch.no_grad():
+        ref, xo_ref = sim.run(set(), P, Ed, held, t, nz, NL)
+        print(f"## after {done} steps: fp32 losses total/x_t/x_1/prob = " + " ".join(f"{v:.4f}" for v in ref), flush=True)
+        c = xo_ref.reshape(-1, 768)
+        cm = c.mean(0)
+        print(f"   x_out: |mean row| {float(cm.norm()):.3f}, rms |row - mean row| {float((c - cm).norm(dim=1).pow(2).mean().sqrt()):.4f}")
+        for name, pts in GROUPS:
+            v, xo = sim.run(pts, P, Ed, held, t, nz, NL)
+            rel = [abs(a - b) / abs(b) for a, b in zip(v, ref)]
+            print(f"   {name:44s} rel total {rel[0]:.2e}  x_t {rel[1]:.2e}  x_1 {rel[2]:.2e}  prob {rel[3]:.2e}", flush=True)
