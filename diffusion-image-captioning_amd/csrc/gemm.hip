@@ -528,9 +528,50 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     }
     if constexpr (EPI == DIC_EPI_AFFINE) {
         const float inv_keep = drop_inv_keep(p.p_drop);
+        // fp32 output + fp32 residual (+ dropout): the fp32 residual stream of the bf16 engines (include/dic_hip.h, DIC_RES_F32)
+        const bool r32 = PF && p.R != nullptr && (p.out_f32 & DIC_RES_IS_F32) != 0 && (p.N & 7) == 0 && !p.accumulate;
         const bool general = p.accumulate || (p.R != nullptr && !PF) || ((p.N & 7) != 0 && (p.R != nullptr || !p.out_f32)) ||
-                             (p.out_f32 && (p.R != nullptr || p.p_drop > 0.f));         // fp32 output with a residual / dropout: nothing on the path asks for it
-        if (!general) {
+                             (p.out_f32 && (p.R != nullptr || p.p_drop > 0.f) && !r32);   // other fp32 outputs with a residual / dropout: nothing on the path asks for them
+        if (r32) {
+            // The residual tile in fp32 is as large as the accumulators (CNT x 16 registers): it is fetched in two halves, each with its own
+            // vmcnt(0) in front of its stores.  The second wait also drains the first half's stores (one counter for loads and stores, see the
+            // top of this function) -- once per tile; the next tile's first DMA goes out behind that second wait, so the wait does not cover it.
+            const LineBuf bF0 = line_buf(p.C, p.ldc, 4, n_first + fcol, p.N), bF1 = line_buf(p.C, p.ldc, 4, n_first + 32 + fcol, p.N);
+            const LineBuf bR0 = line_buf(p.R, p.ldr, 4, n_first + fcol, p.N), bR1 = line_buf(p.R, p.ldr, 4, n_first + 32 + fcol, p.N);
+            constexpr int H = (CNT + 1) / 2;
+            i32x4 pre[H][G::NP][2];
+            auto phase = [&](auto i0_c, auto i1_c, auto drop_c) {
+                constexpr int I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
+                constexpr bool DROP = decltype(drop_c)::value;
+#pragma unroll
+                for (int i = I0; i < I1; ++i) {
+                    get_lines_issue(i, bR0, pre[i - I0][0][0], pre[i - I0][0][1]);
+                    get_lines_issue(i, bR1, pre[i - I0][1][0], pre[i - I0][1][1]);
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if constexpr (I1 == CNT) issue_next();
+#pragma unroll
+                for (int i = I0; i < I1; ++i) {
+                    const int m = m_first + 16 * i + t;
+#pragma unroll
+                    for (int q = 0; q < G::NP; ++q) {
+                        get_lines_finish(pre[i - I0][q][0], pre[i - I0][q][1]);          // -> this lane's columns 8g..8g+3 / 8g+4..8g+7 of row t
+                        f32x4 x0 = acc[i][2 * q], x1 = acc[i][2 * q + 1];
+                        if constexpr (DROP) {
+                            x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + nc[q], p.p_drop, inv_keep);
+                            x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + nc[q] + 4, p.p_drop, inv_keep);
+                        }
+                        x0 += __builtin_bit_cast(f32x4, pre[i - I0][q][0]);
+                        x1 += __builtin_bit_cast(f32x4, pre[i - I0][q][1]);
+                        put_lines_f32(i, q == 0 ? bF0 : bF1, x0, x1);
+                    }
+                }
+            };
+            using I0c = std::integral_constant<int, 0>; using IHc = std::integral_constant<int, H>; using INc = std::integral_constant<int, CNT>;
+            if (p.p_drop > 0.f) { phase(I0c{}, IHc{}, std::true_type{}); if constexpr (H < CNT) phase(IHc{}, INc{}, std::true_type{}); }
+            else { phase(I0c{}, IHc{}, std::false_type{}); if constexpr (H < CNT) phase(IHc{}, INc{}, std::false_type{}); }
+            if constexpr (H == CNT) { /* one phase: issue_next() ran inside it */ }
+        } else if (!general) {
             // The launch-uniform switches (dropout, residual, fp32 output) select one of eight straight-line bodies: left as run-time tests
             // inside the unrolled (fragment, column group) loops they cost ~10 scalar branches per store instruction, with the dropout hash
             // code to jump over each time.
@@ -1326,7 +1367,8 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         }
         const int nk = tl.kt1;
         // (split weights: a second pass over the same K range; K-step kt >= nk reads A's step kt - (nk - kt0) again, against B2)
-        const int kend = (TWO_PASS && p.B2) ? nk + (nk - tl.kt0) : nk;
+        // (b2_col0: only the tiles at output columns >= b2_col0 run the second pass -- the value projection's third of a fused q|k|v weight)
+        const int kend = (TWO_PASS && p.B2 && tl.bn * G::BN >= p.b2_col0) ? nk + (nk - tl.kt0) : nk;
         const TileId done = tl;
         const int slab_done = slab;
         DicGemmParams pe = p;                        // (grouped launches: group_unit() below re-points p at the next problem)
@@ -2020,9 +2062,13 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (p.split_k > 1)
         DIC_REQUIRE(epi == DIC_EPI_AFFINE && p.out_f32 && p.split_ws && !p.bias && !p.R && p.p_drop == 0.f && p.ldc == p.N && p.split_k <= 64,
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
+    if (p.out_f32 & DIC_RES_IS_F32)
+        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && epi == DIC_EPI_AFFINE && (p.out_f32 & DIC_OUT_F32) && p.R != nullptr && p.N % 8 == 0 && !p.accumulate &&
+                    p.split_k <= 1 && gemm_variant() == 0,
+                    "dic_gemm: an fp32 residual (out_f32 = DIC_OUT_F32 | DIC_RES_IS_F32) is an option of the bf16 LDS-DMA kernels' AFFINE epilogue (row-major A, N % 8 == 0, fp32 C)");
     if (p.B2)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && !b_km && (epi == DIC_EPI_AFFINE || epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_BIAS_GELU_D) && p.split_k <= 1 &&
-                    ((uintptr_t)p.B2 % 16) == 0 && gemm_variant() == 0,
+                    ((uintptr_t)p.B2 % 16) == 0 && gemm_variant() == 0 && p.b2_col0 >= 0 && p.b2_col0 % 256 == 0,
                     "dic_gemm: B2 (low-order weight half) is an option of the bf16 forward GEMMs (k-contiguous A and B, AFFINE / BIAS_GELU, no split-K)");
     if (epi == DIC_EPI_CE_EXP)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && p.C && p.lse && p.partial && p.tgt_logit && p.ldc % 8 == 0 && p.ldc >= p.N &&

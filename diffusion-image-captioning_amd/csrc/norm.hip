@@ -180,15 +180,17 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void fuse_ln_bwd_kernel(int mode, c
 }
 
 // ---------------------------------------------------------------------------------------------- plain LayerNorm
-template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* y, const float* gamma, const float* beta, T* h, float* mean, float* rstd, int rows, float eps) {
+// TY: type of the pre-LayerNorm sum y (fp32 in the fp32-residual-stream mode of the bf16 engines, dic_ln_fwd_r32); h32: optional fp32 copy of the
+// output, the residual operand of the next GEMM (the bf16 copy h stays that GEMM's / the next Linear's MFMA operand)
+template <typename T, typename TY = T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TY* y, const float* gamma, const float* beta, T* h, float* h32, float* mean, float* rstd, int rows, float eps) {
     const int lane = threadIdx.x & 63;
     f32x4 g[NCH], b[NCH];
     load_row<float>(gamma, lane, g);
     load_row<float>(beta, lane, b);
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         f32x4 v[NCH];
-        load_row<T>(y + (size_t)row * D, lane, v);
+        load_row<TY>(y + (size_t)row * D, lane, v);
         float mu, rs;
         row_stats(v, eps, mu, rs);
 #pragma unroll
@@ -196,12 +198,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* y, const float* ga
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[c][k] = (v[c][k] - mu) * rs * g[c][k] + b[c][k];
         store_row<T>(h + (size_t)row * D, lane, v);
+        if (h32) store_row<float>(h32 + (size_t)row * D, lane, v);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, const T* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
+template <typename T, typename TY = T>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, const TY* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
                                                       float p_drop, SeedArg seed_, float* partial, int rows) {
     const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, con
     // contention with the weight-gradient GEMMs.)
     for (int row = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6); row < rows; row += gridDim.x * LNB_WAVES) {
         f32x4 v[NCH], d[NCH];
-        load_row<T>(y + (size_t)row * D, lane, v);
+        load_row<TY>(y + (size_t)row * D, lane, v);
         load_row<T>(dh + (size_t)row * D, lane, d);
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
@@ -387,8 +390,16 @@ extern "C" int dic_ln_fwd(int dtype, const void* y, const float* gamma, const fl
     dim3 grid(rows_grid(T, 2048)), block(256);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)y, gamma, beta, (bf16_t*)h, mean, rstd, T, eps),
-               hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, (const float*)y, gamma, beta, (float*)h, mean, rstd, T, eps));
+               hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)y, gamma, beta, (bf16_t*)h, (float*)nullptr, mean, rstd, T, eps),
+               hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, (const float*)y, gamma, beta, (float*)h, (float*)nullptr, mean, rstd, T, eps));
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_ln_fwd_r32(const float* y32, const float* gamma, const float* beta, void* h_bf16, float* h32, float* mean, float* rstd, int T,
+                              int Dd, float eps, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0 && h_bf16 != nullptr, "dic_ln_fwd_r32: D must be 768");
+    dim3 grid(rows_grid(T, 2048)), block(256);
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float>), grid, block, 0, (hipStream_t)stream, y32, gamma, beta, (bf16_t*)h_bf16, h32, mean, rstd, T, eps);
     DIC_CHECK_LAUNCH();
     return 0;
 }
@@ -401,9 +412,16 @@ extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float*
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<bf16_t, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == (DIC_BF16 | DIC_RES_F32)) {           // fp32 residual stream: y is fp32, the gradients stay bf16
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), grid, block, lds, st, (const bf16_t*)dh, (const float*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T);
+        DIC_CHECK_LAUNCH();
+        return 0;
+    }
+    dtype &= ~DIC_RES_F32;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T),
                hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, lds, st, (const float*)dh, (const float*)y, gamma, mean, rstd, (float*)dx, (float*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T));

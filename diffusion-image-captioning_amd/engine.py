@@ -47,7 +47,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0, B2=0):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0, B2=0, b2_col0=0):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -55,7 +55,7 @@ class Ops:
         g.p_drop, g.seed, g.out_f32, g.accumulate = p_drop, seed, out_f32, accumulate
         g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
         g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
-        g.split_k, g.split_ws, g.colsum_out, g.B2 = split_k, split_ws, colsum_out, B2
+        g.split_k, g.split_ws, g.colsum_out, g.B2, g.b2_col0 = split_k, split_ws, colsum_out, B2, b2_col0
         dt = self.dt if dtype is None else dtype
         if tile is None:
             tile = choose_tile(M, N, split_k, epi) if (dt == DIC_BF16 and epi != EPI_CE_PARTIAL and (not a_km or M % 256 == 0)) else 128
@@ -82,8 +82,11 @@ _PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"      # the two Layer
 # "only xr"); "0" switches it off, "w" keeps it to the split-weight mode as before (A/B switches)
 _HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "1")
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
+_SPLIT_SET = _os.environ.get("DIC_SPLIT_SET", "all")          # "vo2t" | "all": which forward Linears take the lo weight half in the split-weight mode
 _UVT32 = _os.environ.get("DIC_UVT32", "1") != "0"
-DIC_U_F32 = 0x100
+# fp32 residual stream (include/dic_hip.h, DIC_RES_F32): "auto" = with the split weights (the parity mode dtype="bf16w"), "1" / "0" force it (A/B)
+_RES32 = _os.environ.get("DIC_RES32", "auto")
+DIC_U_F32, DIC_RES_F32, OUT_F32_RES_F32 = 0x100, 0x200, 3
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
 
@@ -142,11 +145,20 @@ class Denoiser:
         if split_weights is None:
             split_weights = dtype == "bf16w" or _os0.environ.get("DIC_SPLIT_W", "0") == "1"
         self.split_w = bool(split_weights) and self.bf16
-        self.split_slots = None      # None: every forward Linear adds its lo half; else a predicate slot -> bool (precision-allocation probes)
+        # WHICH forward Linears take the lo half (DIC_SPLIT_SET; profiles/r04_split_alloc_trajectory_dense.txt: 19 states along a training run):
+        # "vo2t" (default) = the value third of q|k|v, the attention output projection, FFN lin2 and the MLM-head transform -- FFN lin1 and the
+        # query / key projections make no measurable difference to any loss term at any state (54 % of the second-pass flops); "all": every Linear.
+        # split_slots (slot -> bool) overrides the set, split_qk overrides the q / k choice (the probes use both).
+        self.split_set = _SPLIT_SET
+        self.split_slots = None
+        self.split_qk = None
         self.dt = DIC_BF16 if self.bf16 else DIC_F32
         # bf16 engines keep the MLM-head pre-activation (vocab_transform's output) in fp32: include/dic_hip.h, DIC_U_F32 (DIC_UVT32=0: A/B)
         self.uvt32 = self.bf16 and _UVT32
         self.dt_u = (self.dt | DIC_U_F32) if self.uvt32 else self.dt
+        # fp32 residual stream: the pre-LayerNorm sums and the residual operands of the two residual GEMMs of a block in fp32, bf16 MFMA operands
+        self.res32 = self.bf16 and (_RES32 == "1" or (_RES32 == "auto" and self.split_w))
+        self.dt_ln = (self.dt | DIC_RES_F32) if self.res32 else self.dt
         self.tdtype = torch.bfloat16 if self.bf16 else torch.float32
         self.es = 2 if self.bf16 else 4
         self.concat = cfg.CLIP_ADDING_METHOD == "concat"
@@ -326,8 +338,13 @@ class Denoiser:
         ws["tidx"] = torch.full((N,), -1, dtype=torch.int32, device=dev) if self.temb else None
         ws["h"] = [e(T, D) for _ in range(self.n_layers + 1)]
         ws["mean0"], ws["rstd0"] = f(T), f(T)
-        ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=e(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
-                             y2=e(T, D), m2=f(T), r2=f(T)) for _ in range(self.n_layers)]
+        ey = f if self.res32 else e                      # fp32 residual stream: pre-LayerNorm sums in fp32 + fp32 copies of the LayerNorm outputs
+        ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=ey(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
+                             y2=ey(T, D), m2=f(T), r2=f(T)) for _ in range(self.n_layers)]
+        if self.res32:
+            ws["h32"] = [f(T, D) for _ in range(self.n_layers)]          # residual operand of layer i's out-proj (the last LayerNorm's output has no reader)
+            for Lw in ws["layers"]:
+                Lw["sa32"] = f(T, D)
         ws["uvt"], ws["mv"], ws["rv"] = (f(T, D) if self.uvt32 else e(T, D)), f(T), f(T)
         ws["x_out"] = f(N, Tk, D)
         # backward scratch (shared by all layers)
@@ -392,7 +409,11 @@ class Denoiser:
         seed = self._seed
         ws["seed"], ws["ph"], ws["pa"] = seed, ph, pa
         sel = self.split_slots
+        if sel is None and self.split_set != "all":
+            sel = lambda slot: not slot.endswith("W1")
         lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if self.split_w else (lambda slot: 0)   # low-order weight halves
+        qk_lo = self.split_qk if self.split_qk is not None else (self.split_set == "all" or self.split_slots is not None)
+        v_col0 = 0 if qk_lo else 2 * D                     # q|k|v GEMM: first output column whose weight rows take the second pass
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
         ws["has_u"] = keep_u
         gelu_d = ws["gelu_d"] = self.bf16 and _GELU_D and not _V1_BF16          # Lw["u"] then holds gelu'(u), not u
@@ -424,22 +445,36 @@ class Denoiser:
         _lib.check(lib.dic_fuse_ln_fwd_x(self.dt, mode, x_ptr, x_stride, _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                          P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
                                          _p(ws["h"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
+        r32 = self.res32
+        if r32:          # the embedding LayerNorm once more in fp32 (same dropout mask: it is a function of seed and position): layer 0's residual
+            _lib.check(lib.dic_fuse_ln_fwd_x(DIC_F32, mode, x_ptr, x_stride, _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
+                                             P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
+                                             _p(ws["h32"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
+        of = OUT_F32_RES_F32 if r32 else 0
         for i in range(self.n_layers):
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
             # K5: q|k|v projections as one GEMM
-            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=P.ptr(pre + "bqkv"), B2=lo(pre + "Wqkv"))
+            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=P.ptr(pre + "bqkv"), B2=lo(pre + "Wqkv"), b2_col0=v_col0)
             # K6: attention
             _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
             # K7: out-proj + bias + residual, then LayerNorm
-            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(h), ldr=D, B2=lo(pre + "Wo"))
-            _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
+            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(ws["h32"][i]) if r32 else _p(h), ldr=D,
+                   B2=lo(pre + "Wo"), out_f32=of)
+            if r32:
+                _lib.check(lib.dic_ln_fwd_r32(_p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["sa32"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
+            else:
+                _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             # K8: FFN
             o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU, bias=P.ptr(pre + "b1"),
                    aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd, B2=lo(pre + "W1"))
-            o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa"]), ldr=D,
-                   p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"))
-            _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
+            o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa32"]) if r32 else _p(Lw["sa"]), ldr=D,
+                   p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"), out_f32=of)
+            if r32:
+                _lib.check(lib.dic_ln_fwd_r32(_p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]),
+                                              _p(ws["h32"][i + 1]) if i + 1 < self.n_layers else 0, _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
+            else:
+                _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
         # K9: MLM-head transform: Linear -> GELU -> LayerNorm
         o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"), B2=lo("Wvt"), out_f32=int(self.uvt32))
         _lib.check(lib.dic_gelu_ln_fwd(self.dt_u, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
@@ -597,7 +632,7 @@ class Denoiser:
                 main.wait_event(done[i + 2])          # the dW GEMMs of layer i+2 have finished with this parity's buffers
             dy_, dyd_, dy1_, du_, dqkv_ = ws["dy"][sp], ws["dyd"][sp], ws["dy1"][sp], ws["du"][sp], ws["dqkv"][sp]
             # output_layer_norm backward; bias grad of lin2 folded in
-            _lib.check(lib.dic_ln_bwd(self.dt, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
+            _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
                                       _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
             if not _PAIR_FOLDS:
                 fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                          # [ln2g | ln2b | b2]
@@ -611,7 +646,7 @@ class Denoiser:
             flush_side()                              # one launch per layer starts the side stream too late to hide behind this layer's chain
             o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
-            _lib.check(lib.dic_ln_bwd(self.dt, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
+            _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
                                       0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
             if _PAIR_FOLDS:                                                                   # [ln2g | ln2b | b2] and [ln1g | ln1b | bo] in one launch
                 fold2(parts[2 * sp], P.ptr(pre + "ln2g", "G"), parts[2 * sp + 1], P.ptr(pre + "ln1g", "G"), 3 * D)

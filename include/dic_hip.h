@@ -29,6 +29,15 @@ extern "C" {
 #define DIC_BF16 1
 /* flag on the `dtype` of dic_gelu_ln_fwd / dic_gelu_ln_bwd: the MLM-head pre-activation u is stored in fp32 whatever the engine's type */
 #define DIC_U_F32 0x100
+/* FP32 RESIDUAL STREAM of the bf16 engines (hf:236, 253: sa_layer_norm(attn + x), output_layer_norm(ffn + sa) with the sums and the residual
+ * operands in fp32, the MFMA operands in bf16).  The pre-LayerNorm sums y1 / y2 and the residual reads are the rounding points whose error is
+ * common to all tokens while the denoiser's rows are nearly equal (profiles/r04_collapse_probe.txt, "residual stream"):
+ *   - DicGemmParams.out_f32 = DIC_OUT_F32 | DIC_RES_IS_F32: C is fp32 AND the residual R is fp32 (AFFINE, bf16 forward layouts, N % 8 == 0);
+ *   - dic_ln_fwd_r32: LayerNorm of an fp32 y, writing the bf16 operand copy h and (optionally) the fp32 residual copy h32;
+ *   - dic_ln_bwd with dtype DIC_BF16 | DIC_RES_F32: y is fp32, dh / dx bf16.                                                                  */
+#define DIC_RES_F32 0x200
+#define DIC_OUT_F32 1
+#define DIC_RES_IS_F32 2
 
 int dic_version(void);
 const char* dic_last_error(void);
@@ -72,7 +81,7 @@ typedef struct DicGemmParams {
     const void* R; int ldr;     /* residual, dtype T, or NULL */
     void* aux; int ldaux;       /* BIAS_GELU: out pre-activation; GELU_BWD: in pre-activation */
     float p_drop; uint64_t seed;/* dropout on (acc+bias), mask keyed by (seed, m*N+n) */
-    int out_f32; int accumulate;
+    int out_f32; int accumulate;/* out_f32: 0 = C in T, DIC_OUT_F32 = fp32 C, | DIC_RES_IS_F32 = and R is fp32 (see DIC_RES_F32 above) */
     const int64_t* tgt;         /* [M] target ids (CE) */
     const float* lse;           /* [M] logsumexp (CE_DLOGITS) */
     float* partial;             /* [M][np][4] (CE_PARTIAL); np = 2*ceil(N/128) for 128-tiles, 4*ceil(N/256) for tile=256 */
@@ -92,6 +101,8 @@ typedef struct DicGemmParams {
                                    Replaces nn.Linear's fp32 weight in hf:183-185, 201, 221-223, 510 at bf16 MFMA rate x 1/2 */
     const int64_t* step_ctr;    /* RESERVED, leave 0: dic_gemm fills these two from the step context (dic_step_ctx_set) so that a launch */
     int64_t step_ctr0;          /* replayed inside a hipGraph shifts `seed` by 64 x (steps since capture), as the host does between eager steps */
+    int b2_col0;                /* with B2: only output columns >= b2_col0 (a multiple of 256) take the second pass, the others use B alone -- the
+                                   fused q|k|v projection with the low-order half on its value third only (b2_col0 = 2 D); 0: every column */
 } DicGemmParams;
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
@@ -237,6 +248,8 @@ int dic_temb_grad(const float* dy, const int32_t* tidx, int N, int Tk, int D, in
 /* ---------------------------------------------------------------- LayerNorm (hf:236,239,253,257; eps 1e-12) */
 int dic_ln_fwd(int dtype, const void* y, const float* gamma, const float* beta, void* h, float* mean, float* rstd,
                int T, int D, float eps, void* stream);
+int dic_ln_fwd_r32(const float* y32, const float* gamma, const float* beta, void* h_bf16, float* h32 /* or NULL */, float* mean, float* rstd,
+                   int T, int D, float eps, void* stream);
 /* dx (T) = LN backward; dx_drop (T, optional) = dx with the dropout mask of the producing GEMM epilogue applied
  * (mask keyed by (seed, row*D+col)); partial [nblocks][3*D] = {dgamma, dbeta, colsum(dx_drop if given else dx)}.       */
 int dic_ln_bwd(int dtype, const void* dh, const void* y, const float* gamma, const float* mean, const float* rstd,

@@ -17,6 +17,7 @@ ap.add_argument("--train-steps", type=int, default=300)
 ap.add_argument("--layers", type=int, default=12)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--seeds", type=int, default=3)
+ap.add_argument("--only", default="", help="comma-separated substrings: keep only the SHORT configs whose name contains one of them")
 ap.add_argument("--trajectory", default="", help="comma-separated step counts: the short config list at each of these training states instead")
 args = ap.parse_args()
 B, S, L, NL = args.batch, 1, 16, args.layers
@@ -35,7 +36,7 @@ def layer_of(slot):
     return int(slot[1:slot.index(".")]) if slot.startswith("L") else NL          # "Wvt" counts as the layer after the last
 
 
-CONFIGS = [("none (= bf16 + centred head)", lambda s: False), ("all (= bf16w)", None)]
+CONFIGS = [("none (= bf16 + centred head)", lambda s: False), ("all", lambda s: True), ("default set (= bf16w)", None)]
 for k in (1, 2, 3, 4, 6, 8):
     CONFIGS.append((f"last {k} layers + Wvt", (lambda k: lambda s: layer_of(s) >= NL - k)(k)))
 CONFIGS.append(("Wvt only", lambda s: s == "Wvt"))
@@ -50,14 +51,20 @@ CONFIGS += [("FFN (W1, W2) only", lambda s: s.endswith("W1") or s.endswith("W2")
 
 is_attn = lambda s: s.endswith("Wqkv") or s.endswith("Wo")
 # (name, slot predicate, zero the lo halves of the q / k rows of Wqkv first: "v" = only the value projection of Wqkv keeps its lo half)
-SHORT = [("none (= bf16 + centred head)", lambda s: False, False), ("all (= bf16w)", None, False),
+SHORT = [("none (= bf16 + centred head)", lambda s: False, False), ("all", lambda s: True, False), ("default set (= bf16w)", None, False),
          ("Wqkv + Wo + Wvt", lambda s: is_attn(s) or s == "Wvt", False), ("Wqkv + Wo", is_attn, False),
          ("Wv + Wo + Wvt", lambda s: is_attn(s) or s == "Wvt", True), ("Wv + Wo", is_attn, True),
          ("Wq,Wk + Wvt", lambda s: s.endswith("Wqkv") or s == "Wvt", "qk"),
          ("Wo + Wvt", lambda s: s.endswith("Wo") or s == "Wvt", False), ("Wqkv + Wvt", lambda s: s.endswith("Wqkv") or s == "Wvt", False),
          ("Wqkv + Wo + Wvt + W2", lambda s: is_attn(s) or s == "Wvt" or s.endswith("W2"), False),
+         ("all but W1", lambda s: not s.endswith("W1"), False), ("all but W1, Wq, Wk", lambda s: not s.endswith("W1"), True),
+         ("all but W1, W2", lambda s: not (s.endswith("W1") or s.endswith("W2")), False),
          ("last 4 layers + Wvt", lambda s: layer_of(s) >= NL - 4, False),
          ("Wqkv + Wo of last 6 + Wvt", lambda s: (is_attn(s) and layer_of(s) >= NL - 6) or s == "Wvt", False)]
+
+
+if args.only:
+    SHORT = [c for c in SHORT if any(k in c[0] for k in args.only.split(","))]
 
 
 def mask_qkv_lo(mode):

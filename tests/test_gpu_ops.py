@@ -188,6 +188,16 @@ def test_gemm_split_weight_second_pass(L, tile, M, N, K, epi):
         gemm(L, BF16, 0, 0, 1, A=p(Ad), B=p(hi), B2=p(lo), C=p(G_), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), aux=p(U), ldaux=N, tile=tile)
         assert torch.equal(U.cpu(), exact.float().to(torch.bfloat16)) or relerr(U.float(), exact) < 4e-3
         assert relerr(G_.float(), R.gelu(exact)) < 8e-3
+    if epi == 0 and N % 256 == 0:
+        # b2_col0: only the column tiles from b2_col0 on take the second pass (the value third of a fused q|k|v weight); the others are B alone
+        c0 = 512
+        Cp = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(hi), B2=p(lo), b2_col0=c0, C=p(Cp), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), out_f32=1, tile=tile)
+        assert torch.equal(Cp[:, :c0], C1[:, :c0]) and torch.equal(Cp[:, c0:], Cf[:, c0:])
+        gq = dic._lib.GemmParams()
+        for k, v in dict(A=p(Ad), B=p(hi), B2=p(lo), b2_col0=100, C=p(Cp), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=1, tile=tile).items():
+            setattr(gq, k, v)
+        assert L.dic_gemm(BF16, 0, 0, 0, C.byref(gq), stream()) != 0             # not a multiple of the tile width
     # refused where it is not built: k-major operands, split-K
     gp = dic._lib.GemmParams()
     for k, v in dict(A=p(Ad), B=p(hi), B2=p(lo), C=p(hi), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile).items():
@@ -310,6 +320,78 @@ def test_gemm_line_store_edges(L, tile, M):
     R.gelu(uu).sum().backward()
     assert relerr(Dd[:M, :N].float(), acc * uu.grad) < 1e-2
     assert bool((Dd[:M, N:] == 7.0).all()) and bool((Dd[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("tile,M", [(128, 301), (256, 509), (256, 1792)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_gemm_fp32_residual_stream_epilogue(L, tile, M, p_drop):
+    """out_f32 = DIC_OUT_F32 | DIC_RES_IS_F32 (include/dic_hip.h, DIC_RES_F32): C = dropout(A B^T + bias) + R with C and R in fp32 -- the residual
+    GEMMs of a block in the fp32-residual-stream mode.  Against float64 on the bf16-rounded operands to fp32 accuracy (the bf16-residual form is
+    only good to 4e-3), ragged last rows, guard rows / columns untouched; the dropout mask is the one the bf16 epilogue draws (same seed, same
+    (row, column) keys): the kept elements agree with the bf16-output launch."""
+    N, K = 768, 192
+    g = torch.Generator().manual_seed(M + tile)
+    A, B = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3
+    bias, Rr = torch.randn(N, generator=g), torch.randn(M, N, generator=g) * 3
+    Ad, Bd, Rd = dev(A, torch.bfloat16), dev(B, torch.bfloat16), dev(Rr)
+    acc = Ad.float().cpu().double() @ Bd.float().cpu().double().t() + bias.double()
+    Cf = torch.full((M + 9, N + 8), 7.0, dtype=torch.float32, device="cuda")
+    gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cf), M=M, N=N, K=K, lda=K, ldb=K, ldc=N + 8, bias=p(dev(bias)), R=p(Rd), ldr=N, out_f32=3, tile=tile,
+         p_drop=p_drop, seed=77)
+    assert bool((Cf[:M, N:] == 7.0).all()) and bool((Cf[M:] == 7.0).all())
+    got = Cf[:M, :N].cpu().double() - Rr.double()
+    if p_drop == 0.0:
+        assert relerr(Cf[:M, :N], acc + Rr.double()) < 2e-6
+    else:
+        Cb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        gemm(L, BF16, 0, 0, 0, A=p(Ad), B=p(Bd), C=p(Cb), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), tile=tile, p_drop=p_drop, seed=77)
+        keep = Cb.float().cpu() != 0
+        assert 0.85 < keep.float().mean() < 0.95
+        assert float((got[~keep]).abs().max()) < 2e-5                                   # dropped: only the residual is left
+        assert float(((got - acc / (1 - p_drop))[keep]).abs().max()) < 2e-5 * float(acc.abs().max())
+
+
+def test_ln_and_gelu_ln_with_fp32_inputs_in_the_bf16_engine(L):
+    """dic_ln_fwd_r32 / dic_ln_bwd(DIC_BF16 | DIC_RES_F32) and dic_gelu_ln_fwd / _bwd(DIC_BF16 | DIC_U_F32): fp32 y / u in, bf16 operand copy
+    (+ fp32 residual copy) out, bf16 gradients -- the statistics and the fp32 outputs to fp32 accuracy, the bf16 outputs to bf16 rounding."""
+    T = 333
+    y, gamma, beta, dh = _ln_inputs(T, 5)
+    yd, dhd = dev(y), dev(dh, torch.bfloat16)
+    h = torch.zeros(T, 768, dtype=torch.bfloat16, device="cuda")
+    h32 = torch.zeros(T, 768, device="cuda")
+    mean, rstd = torch.zeros(T, device="cuda"), torch.zeros(T, device="cuda")
+    ok(L.dic_ln_fwd_r32(p(yd), p(dev(gamma)), p(dev(beta)), p(h), p(h32), p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+    yy = y.double().requires_grad_(True)
+    gg, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = R.layer_norm(yy, gg, bb)
+    assert relerr(h32, ref) < 2e-6 and torch.equal(h, h32.to(torch.bfloat16))
+    h2 = torch.zeros_like(h)
+    ok(L.dic_ln_fwd_r32(p(yd), p(dev(gamma)), p(dev(beta)), p(h2), 0, p(mean), p(rstd), T, 768, 1e-12, stream()), L)       # no fp32 copy asked for
+    torch.cuda.synchronize()
+    assert torch.equal(h, h2)
+    ref.backward(dhd.float().cpu().double())
+    dx = torch.zeros(T, 768, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(64, 3 * 768, device="cuda")
+    ok(L.dic_ln_bwd(BF16 | 0x200, p(dhd), p(yd), p(dev(gamma)), p(mean), p(rstd), p(dx), 0, 0.0, 0, p(part), 64, T, 768, stream()), L)
+    s = _colsum(L, part, 3 * 768)
+    assert relerr(dx.float(), yy.grad) < 1e-2
+    assert relerr(s[:768], gg.grad) < 1e-5 and relerr(s[768:1536], bb.grad) < 1e-5
+    # GELU + LayerNorm of the MLM head with an fp32 pre-activation
+    u, gamma, beta, dxo = _ln_inputs(T, 6)
+    ud = dev(u)
+    xo = torch.zeros(T, 768, device="cuda")
+    ok(L.dic_gelu_ln_fwd(BF16 | 0x100, p(ud), p(dev(gamma)), p(dev(beta)), p(xo), p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+    uu = u.double().requires_grad_(True)
+    gg, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = R.layer_norm(R.gelu(uu), gg, bb)
+    assert relerr(xo, ref) < 3e-6
+    ref.backward(dxo.double())
+    du = torch.zeros(T, 768, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(32, 3 * 768, device="cuda")
+    ok(L.dic_gelu_ln_bwd(BF16 | 0x100, p(dev(dxo)), p(ud), p(dev(gamma)), p(mean), p(rstd), p(du), p(part), 32, T, 768, stream()), L)
+    s = _colsum(L, part, 3 * 768)
+    assert relerr(du.float(), uu.grad) < 1e-2
+    assert relerr(s[:768], gg.grad) < 1e-5 and relerr(s[768:1536], bb.grad) < 1e-5
 
 
 @pytest.mark.parametrize("split", [1, 3])
