@@ -83,6 +83,7 @@ _PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"      # the two Layer
 _HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "1")
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
 _SPLIT_SET = _os.environ.get("DIC_SPLIT_SET", "all")          # "vo2t" | "all": which forward Linears take the lo weight half in the split-weight mode
+_BWD_PARITY = max(2, int(_os.environ.get("DIC_BWD_PARITY", "2")))   # gradient-buffer sets shared by the main and the weight-gradient stream (A/B switch)
 _UVT32 = _os.environ.get("DIC_UVT32", "1") != "0"
 # fp32 residual stream (include/dic_hip.h, DIC_RES_F32): "auto" = with the split weights (the parity mode dtype="bf16w"), "1" / "0" force it (A/B)
 _RES32 = _os.environ.get("DIC_RES32", "auto")
@@ -352,11 +353,12 @@ class Denoiser:
         ws["dHa"], ws["dHb"] = e(T, D), e(T, D)
         # gradients that a weight-gradient GEMM consumes exist twice (layer parity): those GEMMs run on a second stream and may
         # still be reading layer i+1's copy while the main stream produces layer i's
-        ws["dy"], ws["dyd"], ws["dy1"] = [e(T, D), e(T, D)], [e(T, D), e(T, D)], [e(T, D), e(T, D)]
-        ws["du"], ws["dqkv"] = [e(T, Hd), e(T, Hd)], [e(T, 3 * D), e(T, 3 * D)]
+        npar = _BWD_PARITY              # sets of the gradient buffers the weight-gradient stream reads: layer i reuses the set of layer i + npar
+        ws["dy"], ws["dyd"], ws["dy1"] = [e(T, D) for _ in range(npar)], [e(T, D) for _ in range(npar)], [e(T, D) for _ in range(npar)]
+        ws["du"], ws["dqkv"] = [e(T, Hd) for _ in range(npar)], [e(T, 3 * D) for _ in range(npar)]
         ws["dsa"], ws["dctx"] = e(T, D), e(T, D)
         ws["dy0"] = f(N, Tk, D)
-        ws["partial"] = [f(NPART, 3 * D) for _ in range(5)]       # [layer parity][which LayerNorm] (folded on the side stream) + embeddings LN
+        ws["partial"] = [f(NPART, 3 * D) for _ in range(2 * npar + 1)]       # [layer parity][which LayerNorm] (folded on the side stream) + embeddings LN
         ws["cs_ws"] = f(64 * max(Tk * D, Hd))
         ws["dimg"], ws["dtxt"] = f(N, D), f(N, D)
         ws["splitk_tail"] = f(8 * (768 * 512 + 768))   # fp32 CLIP-projection weight gradients (main stream, while the side stream owns "splitk")
@@ -615,7 +617,8 @@ class Denoiser:
 
         # head: GELU+LN backward, vocab_transform
         nl = self.n_layers
-        sp = nl & 1
+        npar = len(ws["dy"])
+        sp = nl % npar
         dyb = ws["dy"][sp]
         _lib.check(lib.dic_gelu_ln_bwd(self.dt_u, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), parts[2 * sp], NPART, T, D, st), "gelu_ln_bwd")
         fold(parts[2 * sp], 3 * D, P.ptr("vln_g", "G"))                                      # [vln_g | vln_b | bvt]
@@ -627,9 +630,9 @@ class Denoiser:
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
             use_drop = ph > 0.0
-            sp = i & 1
-            if (i + 2) in done:
-                main.wait_event(done[i + 2])          # the dW GEMMs of layer i+2 have finished with this parity's buffers
+            sp = i % npar
+            if (i + npar) in done:
+                main.wait_event(done[i + npar])       # the dW GEMMs of layer i + npar have finished with this set's buffers
             dy_, dyd_, dy1_, du_, dqkv_ = ws["dy"][sp], ws["dyd"][sp], ws["dy1"][sp], ws["du"][sp], ws["dqkv"][sp]
             # output_layer_norm backward; bias grad of lin2 folded in
             _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
@@ -665,7 +668,7 @@ class Denoiser:
         _lib.check(lib.dic_fuse_ln_bwd(self.dt, mode, _p(ws["xin"]), _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                        P.ptr("seg") if self.concat else 0, P.ptr("pos"), P.ptr("temb") if self.temb else 0,
                                        _p(ws["tidx"]) if self.temb else 0, P.ptr("eln_g"), _p(dH), _p(ws["mean0"]), _p(ws["rstd0"]),
-                                       _p(ws["dy0"]), parts[4], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
+                                       _p(ws["dy0"]), parts[2 * npar], NPART, N, L, D, ph, seed, st), "fuse_ln_bwd")
         dy0 = _p(ws["dy0"])
         if self.temb:
             _lib.check(lib.dic_temb_grad(dy0, _p(ws["tidx"]), N, Tk, D, P.temb_steps, P.ptr("temb", "G"), st), "temb_grad")
@@ -673,7 +676,7 @@ class Denoiser:
 
         def embedding_grads():                   # feed only G: under the CLIP-projection GEMMs below, on the side stream
             s_ = o.stream
-            _lib.check(lib.dic_colsum(DIC_F32, parts[4], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"), 0, csw, s_), "colsum")   # [eln_g | eln_b]
+            _lib.check(lib.dic_colsum(DIC_F32, parts[2 * npar], NPART, 2 * D, 2 * D, P.ptr("eln_g", "G"), 0, csw, s_), "colsum")   # [eln_g | eln_b]
             _lib.check(lib.dic_colsum(DIC_F32, dy0, N, Tk * D, Tk * D, P.ptr("pos", "G"), 0, csw, s_), "colsum")             # dpos[0:Tk]
             if self.concat:
                 gpos = P.ptr("pos", "G")

@@ -41,3 +41,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "head":
     print("--- first kernels of the step (offset from step start, us)")
     for s_, e_, name, q_ in sorted(win)[:45]:
         print(f"  q{q_} start {(s_ - t0)/1e3:9.1f} end {(e_ - t0)/1e3:9.1f} dur {(e_-s_)/1e3:7.1f}  {name[:100]}")
+if len(sys.argv) > 2 and sys.argv[2] == "mid":
+    print("--- kernels around the middle of the backward (offset from step start, us; both queues, by start time)")
+    lnb = [e for e in sorted(win) if "ln_bwd_kernel" in e[2]]
+    c = lnb[len(lnb) // 2][0]
+    near = [e for e in sorted(win) if abs(e[0] - c) < 700e3]
+    for s_, e_, name, q_ in near:
+        import re
+        nm = re.sub(r"\(anonymous namespace\)::", "", name)
+        print(f"  q{q_} start {(s_ - t0)/1e3:9.1f} end {(e_ - t0)/1e3:9.1f} dur {(e_-s_)/1e3:7.1f}  {nm[:80]}")
