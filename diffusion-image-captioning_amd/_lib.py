@@ -20,7 +20,7 @@ EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_
 
 EXPORTS = [
     "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_set_w4a", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_head_center", "dic_head_center_ws_bytes", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
-    "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_fwd_r32", "dic_ln_bwd", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
+    "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_fwd_r32", "dic_ln_bwd", "dic_lo_mean_bias", "dic_lo_mean_bias_ws_bytes", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_colsum_pair", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end", "dic_prof_algorithmic_bytes", "dic_prof_get",
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
@@ -128,6 +128,9 @@ def lib():
         L.dic_temb_grad.argtypes = [P, P, I, I, I, I, P, P]
         L.dic_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]
         L.dic_ln_fwd_r32.argtypes = [P, P, P, P, P, P, P, I, I, F, P]
+        L.dic_lo_mean_bias.argtypes = [P, I, I, I, I, P, I, I, P, P, P, P]
+        L.dic_lo_mean_bias_ws_bytes.argtypes = [I]
+        L.dic_lo_mean_bias_ws_bytes.restype = C.c_size_t
         L.dic_ln_bwd.argtypes = [I, P, P, P, P, P, P, P, F, U64, P, I, I, I, P]
         L.dic_gelu_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]
         L.dic_gelu_ln_bwd.argtypes = [I, P, P, P, P, P, P, P, I, I, I, P]

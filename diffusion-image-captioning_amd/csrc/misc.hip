@@ -734,6 +734,84 @@ extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ mean-row correction of a bf16-rounded weight
+// bias_eff[n] = bias[n] + sum_k lo[n][k] * abar[k],  abar = column mean of (a sample of) the rows of the Linear's input A, lo = bf16(W - bf16(W)).
+// A (W_hi + W_lo)^T = A W_hi^T + A W_lo^T: the second product is 2^-9 of the first, and what it contributes to a batch-mean loss is almost
+// entirely its row-common part abar W_lo^T (the token-specific part is independent from row to row and averages out, like the activations'
+// roundings: DESIGN.md section 4).  That part is ONE vector per Linear: a GEMV, handed to the GEMM as its bias, instead of a second pass of
+// the K loop over every row.  Stage 1 = column sums of the sampled rows in LMB_SLABS slabs, summed in fixed order by stage 2: deterministic.
+constexpr int LMB_OUT = 8, LMB_SLABS = 16;    // outputs per block; row slabs of stage 1
+// stage 1: grid (K / 256, LMB_SLABS); wave w of slab s sums the sampled rows s*4 + w, + 4*LMB_SLABS, ... (four loads in flight); LDS fold of the 4 waves
+__global__ __launch_bounds__(256) void lo_mean_rows_kernel(const bf16_t* in, int rows, int cols, long long ld, float* ws) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    f32x4 a0{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (c < cols) {
+        const int step = 4 * LMB_SLABS;
+        int r = blockIdx.y * 4 + w;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            const f32x4 v0 = Elem<bf16_t>::ld4(in + (size_t)r * ld + c), v1 = Elem<bf16_t>::ld4(in + (size_t)(r + step) * ld + c);
+            const f32x4 v2 = Elem<bf16_t>::ld4(in + (size_t)(r + 2 * step) * ld + c), v3 = Elem<bf16_t>::ld4(in + (size_t)(r + 3 * step) * ld + c);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; r < rows; r += step) a0 += Elem<bf16_t>::ld4(in + (size_t)r * ld + c);
+    }
+    red[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && c < cols) *(f32x4*)(ws + (size_t)blockIdx.y * cols + c) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+// stage 2: a block owns LMB_OUT outputs and splits K over its 256 threads (every weight row of the block is in flight at once)
+__global__ __launch_bounds__(256) void lo_mean_bias_kernel(const float* slabs, float inv_rows, const bf16_t* lo, int ldb, int K, int N,
+                                                           const float* bias, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float abar[];            // [K], then [4][LMB_OUT] partial sums
+    float* red = abar + K;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        f32x4 a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < LMB_SLABS; ++sl) a += *(const f32x4*)(slabs + (size_t)sl * K + k);
+        *(f32x4*)(abar + k) = a * inv_rows;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * LMB_OUT;
+    float acc[LMB_OUT];
+#pragma unroll
+    for (int q = 0; q < LMB_OUT; ++q) acc[q] = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const f32x4 sv = *(const f32x4*)(abar + k);
+#pragma unroll
+        for (int q = 0; q < LMB_OUT; ++q) {
+            const int n = n0 + q < N ? n0 + q : N - 1;                      // (clamped: the surplus sums are not stored)
+            const f32x4 wv = Elem<bf16_t>::ld4(lo + (size_t)n * ldb + k);
+            acc[q] += (wv[0] * sv[0] + wv[1] * sv[1]) + (wv[2] * sv[2] + wv[3] * sv[3]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < LMB_OUT; ++q) {
+        const float t = wave_sum(acc[q]);
+        if (lane == 0) red[w * LMB_OUT + q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < LMB_OUT && n0 + (int)threadIdx.x < N) {
+        const int q = threadIdx.x;
+        out[n0 + q] = (bias ? bias[n0 + q] : 0.f) + ((red[q] + red[LMB_OUT + q]) + (red[2 * LMB_OUT + q] + red[3 * LMB_OUT + q]));
+    }
+}
+extern "C" size_t dic_lo_mean_bias_ws_bytes(int K) { return (size_t)LMB_SLABS * K * sizeof(float); }
+extern "C" int dic_lo_mean_bias(const void* A, int T, int lda, int row_stride, int K, const void* lo, int ldb, int N, const float* bias, float* bias_eff,
+                                float* ws, void* stream) {
+    DIC_REQUIRE(A && lo && bias_eff && ws && T > 0 && row_stride > 0 && K % 4 == 0 && K > 0 && N > 0 && lda % 4 == 0 && ldb % 4 == 0 && K <= 8192,
+                "dic_lo_mean_bias: bf16 A [T][lda] and lo [N][ldb], K a multiple of 4 (<= 8192), ws of dic_lo_mean_bias_ws_bytes(K)");
+    const int rows = (T + row_stride - 1) / row_stride;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lo_mean_rows_kernel, dim3((K + 255) / 256, LMB_SLABS), dim3(256), 0, st, (const bf16_t*)A, rows, K, (long long)lda * row_stride, ws);
+    hipLaunchKernelGGL(lo_mean_bias_kernel, dim3((N + LMB_OUT - 1) / LMB_OUT), dim3(256), (size_t)(K + 4 * LMB_OUT) * sizeof(float), st, ws, 1.0f / (float)rows,
+                       (const bf16_t*)lo, ldb, K, N, bias, bias_eff);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ K15 AdamW
 // torch.optim.AdamW semantics (ref :335): p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  One pass over the flat buffers: 16 B/param read, 12(+2) B written.

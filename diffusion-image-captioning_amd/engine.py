@@ -138,14 +138,19 @@ class Denoiser:
         self.p_attn = float(get("attention_dropout", 0.1)) if config is not None else 0.1
         self.n_heads, self.dim, self.hidden = 12, 768, 3072
         self.device = torch.device(device)
-        self.bf16 = dtype in ("bf16", "bf16w", torch.bfloat16)
+        self.bf16 = dtype in ("bf16", "bf16w", "bf16m", torch.bfloat16)
         # SPLIT WEIGHTS (dtype="bf16w" / split_weights=True / DIC_SPLIT_W=1; bf16 engine only): the forward Linears multiply by hi + lo bf16 halves
         # of the fp32 master weights (two passes of the GEMM's K loop, include/dic_hip.h DicGemmParams.B2) instead of by their bf16 rounding.
         # This is the fast mode that meets north_star's 1e-4 loss tolerance: the weights' rounding error is the same for every sample and does
         # not average out of a batch-mean loss, the activations' does (profiles/r04_weight_rounding_probe.txt).  The backward is unchanged.
         if split_weights is None:
-            split_weights = dtype == "bf16w" or _os0.environ.get("DIC_SPLIT_W", "0") == "1"
+            split_weights = dtype in ("bf16w", "bf16m") or _os0.environ.get("DIC_SPLIT_W", "0") == "1"
         self.split_w = bool(split_weights) and self.bf16
+        # HOW the lo halves enter (DIC_LO_MODE): "pass2" = a second pass of the K loop (DicGemmParams.B2, dtype="bf16w"); "mean" = only their
+        # row-common part, mean row of the Linear's input times the lo half, added to the bias (dic_lo_mean_bias, dtype="bf16m"): two small
+        # launches per Linear instead of doubling its flops
+        self.lo_mode = _os0.environ.get("DIC_LO_MODE", "mean" if dtype == "bf16m" else "pass2") if self.split_w else None
+        self.lo_row_stride = int(_os0.environ.get("DIC_LO_ROW_STRIDE", "16"))      # rows sampled for the mean row: every 16th
         # WHICH forward Linears take the lo half (DIC_SPLIT_SET; profiles/r04_split_alloc_trajectory_dense.txt: 19 states along a training run):
         # "vo2t" (default) = the value third of q|k|v, the attention output projection, FFN lin2 and the MLM-head transform -- FFN lin1 and the
         # query / key projections make no measurable difference to any loss term at any state (54 % of the second-pass flops); "all": every Linear.
@@ -342,6 +347,9 @@ class Denoiser:
         ey = f if self.res32 else e                      # fp32 residual stream: pre-LayerNorm sums in fp32 + fp32 copies of the LayerNorm outputs
         ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=ey(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
                              y2=ey(T, D), m2=f(T), r2=f(T)) for _ in range(self.n_layers)]
+        if self.lo_mode == "mean":
+            ws["beff"] = f(self.n_layers * (6 * D + Hd) + D)       # effective biases of the forward Linears (bias + mean-row lo correction)
+            ws["lomean_ws"] = f(64 * Hd)
         if self.res32:
             ws["h32"] = [f(T, D) for _ in range(self.n_layers)]          # residual operand of layer i's out-proj (the last LayerNorm's output has no reader)
             for Lw in ws["layers"]:
@@ -413,7 +421,19 @@ class Denoiser:
         sel = self.split_slots
         if sel is None and self.split_set != "all":
             sel = lambda slot: not slot.endswith("W1")
-        lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if self.split_w else (lambda slot: 0)   # low-order weight halves
+        lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if (self.split_w and self.lo_mode == "pass2") else (lambda slot: 0)   # low-order weight halves
+        lo_mean = self.split_w and self.lo_mode == "mean"
+        beff_off = [0]
+
+        def bias_of(wslot, bslot, a_ptr, K, Nn):
+            """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows), two small launches"""
+            if not lo_mean or (sel is not None and not sel(wslot)):
+                return P.ptr(bslot)
+            out = _p(ws["beff"]) + beff_off[0] * 4
+            beff_off[0] += Nn
+            _lib.check(lib.dic_lo_mean_bias(a_ptr, T, K, self.lo_row_stride, K, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot), out, _p(ws["lomean_ws"]), st),
+                       "lo_mean_bias")
+            return out
         qk_lo = self.split_qk if self.split_qk is not None else (self.split_set == "all" or self.split_slots is not None)
         v_col0 = 0 if qk_lo else 2 * D                     # q|k|v GEMM: first output column whose weight rows take the second pass
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
@@ -457,20 +477,21 @@ class Denoiser:
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
             # K5: q|k|v projections as one GEMM
-            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=P.ptr(pre + "bqkv"), B2=lo(pre + "Wqkv"), b2_col0=v_col0)
+            o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=bias_of(pre + "Wqkv", pre + "bqkv", _p(h), D, 3 * D),
+                   B2=lo(pre + "Wqkv"), b2_col0=v_col0)
             # K6: attention
             _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
             # K7: out-proj + bias + residual, then LayerNorm
-            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=P.ptr(pre + "bo"), R=_p(ws["h32"][i]) if r32 else _p(h), ldr=D,
+            o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D), R=_p(ws["h32"][i]) if r32 else _p(h), ldr=D,
                    B2=lo(pre + "Wo"), out_f32=of)
             if r32:
                 _lib.check(lib.dic_ln_fwd_r32(_p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["sa32"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             else:
                 _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             # K8: FFN
-            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU, bias=P.ptr(pre + "b1"),
+            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU, bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd),
                    aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd, B2=lo(pre + "W1"))
-            o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=P.ptr(pre + "b2"), R=_p(Lw["sa32"]) if r32 else _p(Lw["sa"]), ldr=D,
+            o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=bias_of(pre + "W2", pre + "b2", _p(Lw["g"]), Hd, D), R=_p(Lw["sa32"]) if r32 else _p(Lw["sa"]), ldr=D,
                    p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"), out_f32=of)
             if r32:
                 _lib.check(lib.dic_ln_fwd_r32(_p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]),
@@ -478,7 +499,7 @@ class Denoiser:
             else:
                 _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
         # K9: MLM-head transform: Linear -> GELU -> LayerNorm
-        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=P.ptr("bvt"), B2=lo("Wvt"), out_f32=int(self.uvt32))
+        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=bias_of("Wvt", "bvt", _p(ws["h"][-1]), D, D), B2=lo("Wvt"), out_f32=int(self.uvt32))
         _lib.check(lib.dic_gelu_ln_fwd(self.dt_u, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
         self._saved = ws
         return ws["x_out"][:N]

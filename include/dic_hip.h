@@ -332,6 +332,15 @@ int dic_colsum(int in_dtype, const void* in, int rows, int cols, int ld, float* 
  * partial buffers of an encoder layer (hf:236, 253 backward: gamma / beta / bias gradients) */
 int dic_colsum_pair(const float* in0, float* out0, const float* in1, float* out1, int rows, int cols, int ld, void* stream);
 
+/* ---------------------------------------------------------------- mean-row correction of a bf16-rounded weight (hf:183-185, 201, 221-223, 510)
+ * bias_eff [N] = bias [N] (or 0) + lo [N][K] . abar [K], abar = column mean of the rows 0, row_stride, 2 row_stride, ... of the bf16 input A [T][lda]
+ * of an nn.Linear, lo = bf16(W - bf16(W)) (dic_adamw_hl / dic_cast_bf16_hl).  Passed to dic_gemm as `bias`, it gives the Linear the part of
+ * A W_lo^T that all rows share -- the part of the weights' rounding a batch-mean loss does not average out -- for one GEMV instead of a second
+ * pass of the K loop (DicGemmParams.B2).  Deterministic; ws: dic_lo_mean_bias_ws_bytes(K).                                                    */
+size_t dic_lo_mean_bias_ws_bytes(int K);
+int dic_lo_mean_bias(const void* A, int T, int lda, int row_stride, int K, const void* lo, int ldb, int N, const float* bias, float* bias_eff,
+                     float* ws, void* stream);
+
 /* ---------------------------------------------------------------- AdamW (ref:335 -- torch defaults, decoupled wd on every tensor)
  * p,g,m,v flat f32 [n]; g is multiplied by grad_scale first (1/world_size after the RCCL sum);
  * shadow (bf16, optional) receives the updated parameters for the bf16 GEMM operands.                              */

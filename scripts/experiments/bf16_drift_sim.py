@@ -47,6 +47,21 @@ def bf(x):
 def run(points, P, E, batch, t, nz, layers, L=16):
     r = lambda name, x: bf(x) if name in points else x
     W = lambda n: r("w", P[n])
+
+    def lin(x, wname, bname):
+        """nn.Linear with the weight rounded to bf16 when "w" is on.  "wcm" / "wcmp" (round 4, collapse_probe.py): add back the part of the
+        rounding's effect that is common to the rows -- mean row (of all rows / of the rows at each sequence position of each pass) times the
+        lo half: one GEMV (or a [2T x K] GEMM) per Linear instead of a second pass over every row."""
+        y = F.linear(x, W(wname), P[bname])
+        if "w" in points and ("wcm" in points or "wcmp" in points):
+            lo = P[wname] - bf(P[wname])
+            if "wcmp" in points and x.dim() == 3:
+                half = x.shape[0] // 2
+                xm = torch.cat([x[:half].mean(0, keepdim=True).expand(half, -1, -1), x[half:].mean(0, keepdim=True).expand(x.shape[0] - half, -1, -1)])
+                y = y + F.linear(xm, lo)
+            else:
+                y = y + F.linear(x.reshape(-1, x.shape[-1]).mean(0), lo)
+        return y
     B = batch["input_ids"].shape[0]
     dev = E.device                                                          # (round 4: the same what-if on the GPU, collapse_probe.py)
     betas = torch.hstack([torch.zeros(1), torch.linspace(1e-4, 0.02, 100)]).to(dev)
@@ -70,18 +85,18 @@ def run(points, P, E, batch, t, nz, layers, L=16):
     for i in range(layers):
         lp = pre + f"transformer.layer.{i}."
         ho = r("h_op", h)
-        q, k, v = (r("qkv", F.linear(ho, W(lp + f"attention.{s}_lin.weight"), P[lp + f"attention.{s}_lin.bias"])) for s in "qkv")
+        q, k, v = (r("qkv", lin(ho, lp + f"attention.{s}_lin.weight", lp + f"attention.{s}_lin.bias")) for s in "qkv")
         sh = lambda z: z.view(n, T, 12, 64).transpose(1, 2)
         s_ = torch.matmul(sh(q), sh(k).transpose(2, 3)) * 0.125
         s_ = s_.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
         p_ = r("p", F.softmax(s_, -1))
         ctx = r("ctx", torch.matmul(p_, sh(v)).transpose(1, 2).reshape(n, T, 768))
-        y1 = r("y1", F.linear(ctx, W(lp + "attention.out_lin.weight"), P[lp + "attention.out_lin.bias"]) + r("h_res", h))
+        y1 = r("y1", lin(ctx, lp + "attention.out_lin.weight", lp + "attention.out_lin.bias") + r("h_res", h))
         sa = ln(y1, lp + "sa_layer_norm")
-        g = r("g", F.gelu(F.linear(r("sa_op", sa), W(lp + "ffn.lin1.weight"), P[lp + "ffn.lin1.bias"])))
-        y2 = r("y2", F.linear(g, W(lp + "ffn.lin2.weight"), P[lp + "ffn.lin2.bias"]) + r("sa_res", sa))
+        g = r("g", F.gelu(lin(r("sa_op", sa), lp + "ffn.lin1.weight", lp + "ffn.lin1.bias")))
+        y2 = r("y2", lin(g, lp + "ffn.lin2.weight", lp + "ffn.lin2.bias") + r("sa_res", sa))
         h = ln(y2, lp + "output_layer_norm")
-    u = r("uvt", F.linear(r("h_op", h), W("model.vocab_transform.weight"), P["model.vocab_transform.bias"]))
+    u = r("uvt", lin(r("h_op", h), "model.vocab_transform.weight", "model.vocab_transform.bias"))
     xo = ln(F.gelu(u), "model.vocab_layer_norm")[:, :L]
     tgt = x0.repeat(2, 1, 1)
     l1 = (xo - tgt).abs().sum(1)

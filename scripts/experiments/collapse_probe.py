@@ -17,6 +17,7 @@ dic = importlib.import_module("diffusion-image-captioning_amd")
 ap = argparse.ArgumentParser()
 ap.add_argument("--trajectory", default="0,5,10,20,40,320")
 ap.add_argument("--layers", type=int, default=12)
+ap.add_argument("--groups", default="", help="'cm': only the common-mode weight-correction what-if (mean row x lo half instead of a second pass)")
 ap.add_argument("--batch", type=int, default=512)
 args = ap.parse_args()
 torch.backends.cuda.matmul.allow_tf32 = False
@@ -41,6 +42,13 @@ GROUPS = [("every point (= bf16)", ALL), ("all but the weights (= bf16w)", ACT),
           ("residual stream (h_res, sa_res, y1, y2)", {"h_res", "sa_res", "y1", "y2"}), ("GEMM operands (h_op, sa_op, ctx, g)", {"h_op", "sa_op", "ctx", "g"}),
           ("bf16w minus uvt", ACT - {"uvt"}), ("bf16w minus uvt, h_op", ACT - {"uvt", "h_op"}), ("bf16w minus residual stream", ACT - {"h_res", "sa_res", "y1", "y2"}),
           ("bf16w minus residual stream, uvt", ACT - {"h_res", "sa_res", "y1", "y2", "uvt"})]
+if args.groups == "cm":
+    NOW = ACT - {"uvt", "xr"}                     # the activations' rounding points of today's bf16 engine (fp32 uvt, centred head)
+    GROUPS = [("only the weights", {"w", "wlm"}), ("weights + mean-row correction", {"w", "wlm", "wcm"}),
+              ("weights + per-position mean-row correction", {"w", "wlm", "wcmp"}),
+              ("bf16 engine (weights + activations)", NOW | {"w", "wlm"}), ("bf16 engine + mean-row correction", NOW | {"w", "wlm", "wcm"}),
+              ("bf16 engine + per-position correction", NOW | {"w", "wlm", "wcmp"}), ("bf16w without res32 (activations only)", NOW),
+              ("bf16w with res32", NOW - {"h_res", "sa_res", "y1", "y2"})]
 done = 0
 for upto in [int(v) for v in args.trajectory.split(",")]:
     bw.train()

@@ -351,6 +351,34 @@ def test_gemm_fp32_residual_stream_epilogue(L, tile, M, p_drop):
         assert float(((got - acc / (1 - p_drop))[keep]).abs().max()) < 2e-5 * float(acc.abs().max())
 
 
+@pytest.mark.parametrize("T,K,N,stride", [(17408, 768, 2304, 16), (17408, 3072, 768, 16), (300, 768, 772, 1), (1000, 3072, 3072, 7)])
+def test_lo_mean_bias_is_bias_plus_lo_times_the_mean_of_the_sampled_rows(L, T, K, N, stride):
+    """dic_lo_mean_bias: bias_eff = bias + lo . mean(A[0::stride]) -- the row-common part of A W_lo^T, handed to the GEMM as its bias instead of
+    a second pass of the K loop (include/dic_hip.h).  Against float64 on the same bf16 operands; a second call gives the same bits."""
+    g = torch.Generator().manual_seed(T + K + N)
+    A = torch.randn(T, K, generator=g) * 0.7 + torch.randn(1, K, generator=g) * 0.4            # rows with a common part, like LayerNorm outputs
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    Ad, Wd = dev(A, torch.bfloat16), dev(W)
+    hi, lo = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda"), torch.zeros(N, K, dtype=torch.bfloat16, device="cuda")
+    ok(L.dic_cast_bf16_hl(p(Wd), p(hi), p(lo), N * K, stream()), L)
+    ws = torch.zeros(L.dic_lo_mean_bias_ws_bytes(K) // 4, device="cuda")
+    outs = []
+    for _ in range(2):
+        out = torch.full((N + 4,), 7.0, device="cuda")
+        ok(L.dic_lo_mean_bias(p(Ad), T, K, stride, K, p(lo), K, N, p(dev(bias)), p(out), p(ws), stream()), L)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1]) and bool((outs[0][N:] == 7.0).all())
+    abar = Ad.float().cpu().double()[::stride].mean(0)
+    ref = bias.double() + lo.float().cpu().double() @ abar
+    corr = (ref - bias.double()).abs().max()
+    assert float((outs[0][:N].cpu().double() - ref).abs().max()) < 1e-4 * float(corr) + 1e-7
+    out0 = torch.zeros(N, device="cuda")                                                      # no bias given: the correction alone
+    ok(L.dic_lo_mean_bias(p(Ad), T, K, stride, K, p(lo), K, N, 0, p(out0), p(ws), stream()), L)
+    assert float((out0.cpu().double() - (ref - bias.double())).abs().max()) < 1e-4 * float(corr) + 1e-7
+
+
 def test_ln_and_gelu_ln_with_fp32_inputs_in_the_bf16_engine(L):
     """dic_ln_fwd_r32 / dic_ln_bwd(DIC_BF16 | DIC_RES_F32) and dic_gelu_ln_fwd / _bwd(DIC_BF16 | DIC_U_F32): fp32 y / u in, bf16 operand copy
     (+ fp32 residual copy) out, bf16 gradients -- the statistics and the fp32 outputs to fp32 accuracy, the bf16 outputs to bf16 rounding."""
