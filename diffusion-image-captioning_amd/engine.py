@@ -152,8 +152,9 @@ class Denoiser:
         self.lo_mode = _os0.environ.get("DIC_LO_MODE", "mean" if dtype == "bf16m" else "pass2") if self.split_w else None
         self.lo_row_stride = int(_os0.environ.get("DIC_LO_ROW_STRIDE", "16"))      # rows sampled for the mean row: every 16th
         # WHICH forward Linears take the lo half (DIC_SPLIT_SET; profiles/r04_split_alloc_trajectory_dense.txt: 19 states along a training run):
-        # "vo2t" (default) = the value third of q|k|v, the attention output projection, FFN lin2 and the MLM-head transform -- FFN lin1 and the
-        # query / key projections make no measurable difference to any loss term at any state (54 % of the second-pass flops); "all": every Linear.
+        # "all" (default): every Linear; "vo2t" = only the value third of q|k|v, the attention output projection, FFN lin2 and the MLM-head
+        # transform -- at B = 512 FFN lin1 and the query / key projections make no measurable difference to any loss term at any state (54 % of the
+        # second-pass flops), at small batches they do, hence not the default.
         # split_slots (slot -> bool) overrides the set, split_qk overrides the q / k choice (the probes use both).
         self.split_set = _SPLIT_SET
         self.split_slots = None
