@@ -467,9 +467,10 @@ def main():
             dtype_delta[tags[1]] = res[tags[1]][args.dtype]
             dtype_delta["mode"] = args.dtype
             dtype_delta["note"] = ("the benchmarked mode against the fp32 HIP engine (itself within 1e-4 of the CPU oracle at this shape, tests/); first four keys: at "
-                                   "the initial weights.  What separates the PLAIN bf16 engine (throughput_mode) from fp32 there is the bf16 rounding of the WEIGHTS: "
-                                   "one perturbation shared by every sample, whose first-order effect a batch-mean loss does not average out "
-                                   "(profiles/r04_weight_rounding_probe.txt); the benchmarked bf16m mode adds its row-common part back (dic_lo_mean_bias)")
+                                   "the initial weights.  What separates the PLAIN bf16 engine from fp32 there is the bf16 rounding of the WEIGHTS: one perturbation "
+                                   "shared by every sample, whose first-order effect a batch-mean loss does not average out (profiles/r04_weight_rounding_probe.txt); "
+                                   + ("parity_fast_mode (bf16m) adds its row-common part back (dic_lo_mean_bias) and keeps the residual stream in fp32"
+                                      if args.dtype == "bf16" else "this mode adds its row-common part back (dic_lo_mean_bias); throughput_mode is the plain engine"))
             # ALONG A TRAINING RUN (8 cycled synthetic batches, a fresh split-weight model trains; the three engines evaluate a held-out batch on its
             # weights at a few states): between the first and some hundreds of steps the denoiser's rows are nearly equal, and bf16 roundings of
             # row-common quantities no longer average out of a batch mean -- tests/test_gpu_e2e.py::test_bf16_engines_stay_near_fp32_along_a_training_run

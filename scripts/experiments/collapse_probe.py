@@ -16,6 +16,7 @@ sim = importlib.import_module("bf16_drift_sim")
 dic = importlib.import_module("diffusion-image-captioning_amd")
 ap = argparse.ArgumentParser()
 ap.add_argument("--trajectory", default="0,5,10,20,40,320")
+ap.add_argument("--draws", type=int, default=1, help="noise / timestep draws per state (worst over them is printed)")
 ap.add_argument("--layers", type=int, default=12)
 ap.add_argument("--groups", default="", help="'cm': only the common-mode weight-correction what-if (mean row x lo half instead of a second pass)")
 ap.add_argument("--batch", type=int, default=512)
@@ -49,6 +50,11 @@ if args.groups == "cm":
               ("bf16 engine (weights + activations)", NOW | {"w", "wlm"}), ("bf16 engine + mean-row correction", NOW | {"w", "wlm", "wcm"}),
               ("bf16 engine + per-position correction", NOW | {"w", "wlm", "wcmp"}), ("bf16w without res32 (activations only)", NOW),
               ("bf16w with res32", NOW - {"h_res", "sa_res", "y1", "y2"})]
+if args.groups == "r32":                         # which half of the fp32 residual stream carries its effect (weights exact: the bf16m / bf16w case)
+    NOW = ACT - {"uvt", "xr"}
+    GROUPS = [("no fp32 residual stream", NOW), ("fp32 residual stream (both residual GEMMs)", NOW - {"h_res", "sa_res", "y1", "y2"}),
+              ("FFN half only (y2, sa_res)", NOW - {"sa_res", "y2"}), ("attention half only (y1, h_res)", NOW - {"h_res", "y1"}),
+              ("sums only (y1, y2)", NOW - {"y1", "y2"}), ("residual reads only (h_res, sa_res)", NOW - {"h_res", "sa_res"})]
 done = 0
 for upto in [int(v) for v in args.trajectory.split(",")]:
     bw.train()
@@ -62,7 +68,14 @@ for upto in [int(v) for v in args.trajectory.split(",")]:
         c = xo_ref.reshape(-1, 768)
         cm = c.mean(0)
         print(f"   x_out: |mean row| {float(cm.norm()):.3f}, rms |row - mean row| {float((c - cm).norm(dim=1).pow(2).mean().sqrt()):.4f}")
+        draws = [(t, nz, ref)]
+        for d in range(1, args.draws):
+            td = torch.from_numpy(dic.synth.timesteps(1, 100, d)).to(dev)
+            nd = [torch.from_numpy(dic.synth.noise((B, L, 768), 3 + d, f"eps{i}")).to(dev) for i in range(2)]
+            draws.append((td, nd, sim.run(set(), P, Ed, held, td, nd, NL)[0]))
         for name, pts in GROUPS:
-            v, xo = sim.run(pts, P, Ed, held, t, nz, NL)
-            rel = [abs(a - b) / abs(b) for a, b in zip(v, ref)]
+            rel = [0.0] * 4
+            for td, nd, rf in draws:
+                v, xo = sim.run(pts, P, Ed, held, td, nd, NL)
+                rel = [max(r_, abs(a - b) / abs(b)) for r_, a, b in zip(rel, v, rf)]
             print(f"   {name:44s} rel total {rel[0]:.2e}  x_t {rel[1]:.2e}  x_1 {rel[2]:.2e}  prob {rel[3]:.2e}", flush=True)
