@@ -64,6 +64,7 @@ class Ops:
         _lib.check(self.L.dic_gemm(self.dt if dtype is None else dtype, a_km, b_km, epi, C.byref(g), self.stream), "gemm")
 
 
+import math
 import os as _os
 
 _TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "auto" (A/B switch for measurements)
@@ -425,6 +426,9 @@ class Denoiser:
         lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if (self.split_w and self.lo_mode == "pass2") else (lambda slot: 0)   # low-order weight halves
         lo_mean = self.split_w and self.lo_mode == "mean"
         beff_off = [0]
+        lo_stride = self.lo_row_stride          # rows are [sequence][token]: a stride that shares a factor with Tk would visit only some token positions
+        while math.gcd(lo_stride, Tk) != 1:
+            lo_stride += 1
 
         def bias_of(wslot, bslot, a_ptr, K, Nn):
             """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows), two small launches"""
@@ -432,7 +436,7 @@ class Denoiser:
                 return P.ptr(bslot)
             out = _p(ws["beff"]) + beff_off[0] * 4
             beff_off[0] += Nn
-            _lib.check(lib.dic_lo_mean_bias(a_ptr, T, K, self.lo_row_stride, K, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot), out, _p(ws["lomean_ws"]), st),
+            _lib.check(lib.dic_lo_mean_bias(a_ptr, T, K, lo_stride, K, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot), out, _p(ws["lomean_ws"]), st),
                        "lo_mean_bias")
             return out
         qk_lo = self.split_qk if self.split_qk is not None else (self.split_set == "all" or self.split_slots is not None)
