@@ -3,6 +3,7 @@
 // statistics by wave shuffles in fp32 (two-pass mean/variance in registers), eps = 1e-12 as hf:100,236,239,439.
 // Backward kernels are persistent: each wave walks rows with a grid stride, keeps its dgamma/dbeta/bias-grad partial
 // sums in registers, and the block writes ONE partial row; dic_colsum folds the partial rows (deterministic).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/dic_hip.h"
 
@@ -256,6 +257,70 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, con
     fold_partials<3, LNB_WAVES>(acc, partial, lds);
 }
 
+// "Thin" form (experiment, DIC_LN_BWD_ROWS = 2 / 4): a wave takes ROWS rows per iteration and issues all their loads before the first store, so
+// the same bytes are in flight from 1/ROWS of the waves -- the kernel can then saturate HBM from a fraction of the CUs (fewer persistent blocks,
+// DIC_LN_NPART) and leave the rest to a GEMM on another stream instead of time-slicing whole CUs with it (what comes next).
+template <typename T, typename TY, int ROWS>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_thin_kernel(const T* dh, const TY* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
+                                                           float p_drop, SeedArg seed_, float* partial, int rows) {
+    const unsigned long long seed = seed_.resolve();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    f32x4 g[NCH];
+    load_row<float>(gamma, lane, g);
+    f32x4 acc[3][NCH];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_keep = drop_inv_keep(p_drop);
+    const int nw = gridDim.x * LNB_WAVES, w = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6);
+    for (int row0 = w; row0 < rows; row0 += nw * ROWS) {
+        f32x4 v[ROWS][NCH], d[ROWS][NCH];
+        float mu[ROWS], rs[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int row = row0 + j * nw;
+            const int rr = row < rows ? row : rows - 1;              // (clamped: surplus rows are computed and dropped)
+            load_row<TY>(y + (size_t)rr * D, lane, v[j]);
+            load_row<T>(dh + (size_t)rr * D, lane, d[j]);
+            mu[j] = mean[rr]; rs[j] = rstd[rr];
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int row = row0 + j * nw;
+            if (row >= rows) break;
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float xh = (v[j][c][k] - mu[j]) * rs[j];
+                    float gg = d[j][c][k] * g[c][k];
+                    acc[0][c][k] += d[j][c][k] * xh;
+                    acc[1][c][k] += d[j][c][k];
+                    c1 += gg; c2 += gg * xh;
+                    v[j][c][k] = xh; d[j][c][k] = gg;
+                }
+            c1 = wave_sum(c1) * (1.0f / D);
+            c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[j][c][k] = rs[j] * (d[j][c][k] - c1 - v[j][c][k] * c2);
+            store_row<T>(dx + (size_t)row * D, lane, d[j]);
+            if (dx_drop) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) d[j][c] = dropout4(d[j][c], seed, (unsigned long long)row * D + c * 256 + lane * 4, p_drop, inv_keep);
+                store_row<T>(dx_drop + (size_t)row * D, lane, d[j]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[2][c] += d[j][c];
+        }
+    }
+    fold_partials<3, LNB_WAVES>(acc, partial, lds);
+}
+
 // ---------------------------------------------------------------------------------------------- GELU + LayerNorm (hf:511-512)
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_ln_fwd_kernel(const T* u, const float* gamma, const float* beta, float* x_out, float* mean, float* rstd, int rows, float eps) {
@@ -416,6 +481,21 @@ extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float*
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    static const int thin_rows = [] { const char* e = getenv("DIC_LN_BWD_ROWS"); return e ? atoi(e) : 1; }();
+    if (dtype == DIC_BF16 && (thin_rows == 2 || thin_rows == 4)) {          // experiment: the thin form (bf16 engine only)
+        static bool thin_attr = false;
+        if (!thin_attr) {
+            (void)hipFuncSetAttribute((const void*)ln_bwd_thin_kernel<bf16_t, bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)ln_bwd_thin_kernel<bf16_t, bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            thin_attr = true;
+        }
+        if (thin_rows == 2)
+            hipLaunchKernelGGL((ln_bwd_thin_kernel<bf16_t, bf16_t, 2>), grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T);
+        else
+            hipLaunchKernelGGL((ln_bwd_thin_kernel<bf16_t, bf16_t, 4>), grid, block, lds, st, (const bf16_t*)dh, (const bf16_t*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T);
+        DIC_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == (DIC_BF16 | DIC_RES_F32)) {           // fp32 residual stream: y is fp32, the gradients stay bf16
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), grid, block, lds, st, (const bf16_t*)dh, (const float*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T);
         DIC_CHECK_LAUNCH();
