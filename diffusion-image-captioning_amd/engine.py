@@ -129,9 +129,15 @@ class Denoiser:
     embedding / projection: objects with `.weight` ([V,768]; nn.Embedding / nn.Linear work) or raw arrays/tensors.
     The projection bias is zeroed as ref :247 does.  `config` may be a HF DistilBertConfig-like object or a dict with
     `n_layers`, `dropout`, `attention_dropout`.
+    dtype (keyword-only; the reference is fp32): "fp32" exact-fp32 MFMA GEMMs (token ids identical to the CPU reference's); "bf16" bf16 MFMA
+    operands, the fastest; "bf16m" the same arithmetic minus the roundings a batch-mean loss does not average out (mean-row lo-weight
+    correction per Linear, fp32 residual stream): every loss term within 1e-4 of fp32 along a whole run; "bf16w" its exact form (lo weight
+    halves as a second GEMM pass).  An unknown value raises ValueError.
     """
 
     def __init__(self, embedding=None, projection=None, config=None, *, dtype="bf16", device="cuda:0", seed=0, split_weights=None):
+        if dtype not in ("fp32", "bf16", "bf16w", "bf16m", torch.float32, torch.bfloat16):
+            raise ValueError(f"dtype must be 'fp32', 'bf16', 'bf16m' or 'bf16w', not {dtype!r}")
         _lib.require_gpu()
         get = (lambda k, d: config.get(k, d)) if isinstance(config, dict) else (lambda k, d: getattr(config, k, d))
         self.n_layers = int(get("n_layers", 6)) if config is not None else 6

@@ -402,3 +402,9 @@ def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_pat
         assert all(int(n) <= 15 for n in re.findall(r"lgkmcnt\((\d+)\)", text)), name
         assert all(int(n) <= 63 for n in re.findall(r"vmcnt\((\d+)\)", text)), name
         assert text.count("s_barrier") >= 2 * 6, name
+
+
+def test_unknown_precision_mode_is_refused_before_anything_else():
+    """dtype is one of fp32 / bf16 / bf16m / bf16w; a typo used to fall through to the fp32 engine silently."""
+    with pytest.raises(ValueError):
+        dic.DistilBertModel(None, None, dtype="bf16x")
