@@ -15,6 +15,9 @@ ap.add_argument("--trajectory", default="0,1,2,3,5,7,10,15,20,30,40,60,80,120,16
 ap.add_argument("--layers", type=int, default=12)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--time", action="store_true", help="also time 20 training steps of each mode (dropout 0.1) at the end")
+ap.add_argument("--train-dropout", type=float, default=0.0, help="dropout of the TRAINING steps (the evaluations always run with dropout off)")
+ap.add_argument("--lr", type=float, default=1e-4)
+ap.add_argument("--seed-offset", type=int, default=0, help="shifts every data / noise / timestep seed: an independent run")
 args = ap.parse_args()
 B, S, L, NL = args.batch, 1, 16, args.layers
 dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, VOCAB_SIZE=30522, CLASSIFIER_FREE_WEIGHT=0.0,
@@ -33,11 +36,12 @@ def make(dtype, res32=None, drop=0.0):
         eng._RES32 = keep
 
 
-MODES = {"bf16": make("bf16"), "bf16m-r": make("bf16m", "0"), "bf16m": make("bf16m"), "bf16w": make("bf16w")}
+MODES = {"bf16": make("bf16"), "bf16m-r": make("bf16m", "0"), "bf16m": make("bf16m"), "bf16w": make("bf16w", drop=args.train_dropout)}
+SO = args.seed_offset
 f32 = make("fp32")
-held = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=1 + 7 * i).items()} for i in range(2)]
-train = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=100 + i).items()} for i in range(8)]
-draws = [(torch.from_numpy(dic.synth.timesteps(S, 100, i)), [torch.from_numpy(dic.synth.noise((B, L, 768), 3 + i, f"eps{j}")) for j in range(2)]) for i in range(3)]
+held = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=1 + 7 * i + SO).items()} for i in range(2)]
+train = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=100 + i + SO).items()} for i in range(8)]
+draws = [(torch.from_numpy(dic.synth.timesteps(S, 100, i + SO)), [torch.from_numpy(dic.synth.noise((B, L, 768), 3 + i + SO, f"eps{j}")) for j in range(2)]) for i in range(3)]
 
 
 def evals(m):
@@ -51,9 +55,10 @@ def evals(m):
 
 
 bw = MODES["bf16w"]
-trainer = dic.AdamW(bw.parameters(), lr=1e-4)
-dic.seed_noise(1234)
-dic.diffusion.seed_timesteps(4321)
+trainer = dic.AdamW(bw.parameters(), lr=args.lr)
+dic.seed_noise(1234 + SO)
+dic.diffusion.seed_timesteps(4321 + SO)
+print(f"# run: lr {args.lr}, training dropout {args.train_dropout}, seed offset {SO}")
 done = 0
 worst = {k: 0.0 for k in MODES}
 inside = {k: 0 for k in MODES}
