@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, con
     fold_partials<3, LNB_WAVES>(acc, partial, lds);
 }
 
+#ifdef DIC_LN_THIN      // measurement build only (scripts/build_variant.sh -DDIC_LN_THIN): the shipped library carries one LayerNorm backward
 // "Thin" form (experiment, DIC_LN_BWD_ROWS = 2 / 4): a wave takes ROWS rows per iteration and issues all their loads before the first store, so
 // the same bytes are in flight from 1/ROWS of the waves -- the kernel can then saturate HBM from a fraction of the CUs (fewer persistent blocks,
 // DIC_LN_NPART) and leave the rest to a GEMM on another stream instead of time-slicing whole CUs with it (what comes next).
@@ -320,6 +321,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_thin_kernel(const T* dh
     }
     fold_partials<3, LNB_WAVES>(acc, partial, lds);
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------- GELU + LayerNorm (hf:511-512)
 template <typename T>
@@ -481,6 +484,7 @@ extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float*
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
+#ifdef DIC_LN_THIN
     static const int thin_rows = [] { const char* e = getenv("DIC_LN_BWD_ROWS"); return e ? atoi(e) : 1; }();
     if (dtype == DIC_BF16 && (thin_rows == 2 || thin_rows == 4)) {          // experiment: the thin form (bf16 engine only)
         static bool thin_attr = false;
@@ -496,6 +500,7 @@ extern "C" int dic_ln_bwd(int dtype, const void* dh, const void* y, const float*
         DIC_CHECK_LAUNCH();
         return 0;
     }
+#endif
     if (dtype == (DIC_BF16 | DIC_RES_F32)) {           // fp32 residual stream: y is fp32, the gradients stay bf16
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), grid, block, lds, st, (const bf16_t*)dh, (const float*)y, gamma, mean, rstd, (bf16_t*)dx, (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T);
         DIC_CHECK_LAUNCH();

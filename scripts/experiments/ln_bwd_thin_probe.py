@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Standalone time of the bf16 LayerNorm backward (17 408 x 768, 108 MB of traffic) against the number of persistent blocks, for the shipped kernel
 (DIC_LN_BWD_ROWS unset) and the thin form (DIC_LN_BWD_ROWS=2 / 4: rows per wave iteration): can the kernel saturate HBM from a fraction of the CUs?
-    for r in 1 2 4; do DIC_LN_BWD_ROWS=$r python scripts/experiments/ln_bwd_thin_probe.py; done"""
+    scripts/build_variant.sh thin "-DDIC_LN_THIN"; for r in 1 2 4; do DIC_HIP_LIB=abl/libdic_thin.so DIC_LN_BWD_ROWS=$r python scripts/experiments/ln_bwd_thin_probe.py; done"""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
