@@ -246,6 +246,16 @@ def test_sampling_loop_ids_bit_exact_fp32_and_bf16_hidden():
     print("bf16 sampling: max |hidden - ref| =", err, " id agreement =", agree, " decision bound on the margin =", bound)
     assert err < 0.15 and agree > 0.6
     assert bool(same[margin > bound].all()), "a token whose reference margin exceeds what the hidden-state drift can flip must agree"
+    # the parity modes run the same loop (fp32-residual epilogues, per-Linear mean-row launches inside the captured passes): same bar
+    for dt in ("bf16m", "bf16w"):
+        mp = dic.DistilBertModel(E, E, config=dict(n_layers=m["n_layers"]), dtype=dt)
+        mp.load_state(synth.denoiser_state(m["n_layers"], m["wseed"]))
+        mp.eval()
+        idp, hp = dic.sample(mp, torch.from_numpy(xb["image_clip"]), steps=m["steps"], start=start, return_hidden=True)
+        errp = float((hp.cpu() - torch.from_numpy(z["final_hidden"])).abs().max())
+        samep = idp.cpu().numpy() == z["ids"]
+        print(f"{dt} sampling: max |hidden - ref| = {errp}, id agreement = {float(samep.mean())}")
+        assert errp < 0.15 and bool(samep[margin > bound].all())
 
 
 def test_training_with_dropout_runs_and_is_replayable():
