@@ -10,6 +10,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--batches", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", help="bf16 | bf16m | bf16w")
     args = ap.parse_args()
     import torch
     dic = importlib.import_module("diffusion-image-captioning_amd")
@@ -20,7 +21,7 @@ def main():
                    CLASSIFIER_FREE_PROB=0.2, CLIP_ADDING_METHOD="concat", LOSS_FUNC="series_sum_sample_mean", X_0_PREDICTION=True, ROUNDING_WEIGHT=0.5)
     E = dic.synth.vocab_embedding(30522, 768, 0)
     data = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=200 + i).items()} for i in range(args.batches)]
-    model = dic.DistilBertModel(E, E, config=dict(n_layers=12, dropout=0.1, attention_dropout=0.1), dtype="bf16", device=dev, seed=0)
+    model = dic.DistilBertModel(E, E, config=dict(n_layers=12, dropout=0.1, attention_dropout=0.1), dtype=args.dtype, device=dev, seed=0)
     trainer = dic.AdamW(model.parameters(), lr=1e-4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -37,7 +38,7 @@ def main():
         bad += not ok
         print(f"step {s:5d}: total {v[0]:10.4f}  x_t {v[1]:8.4f}  x_1 {v[2]:8.4f}  prob {v[3]:10.4f}{'' if ok else '   <-- non-finite'}")
     pn = float(torch.linalg.vector_norm(model.params.P.float()))
-    print(f"{args.steps} steps in {dt:.1f} s = {dt / args.steps * 1e3:.3f} ms/step incl. the logging syncs; parameter norm {pn:.3f}; non-finite samples: {bad}")
+    print(f"{args.dtype}: {args.steps} steps in {dt:.1f} s = {dt / args.steps * 1e3:.3f} ms/step incl. the logging syncs; parameter norm {pn:.3f}; non-finite samples: {bad}")
     sys.exit(1 if bad or pn != pn else 0)
 
 
