@@ -16,6 +16,7 @@ _AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another bui
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
+ABI_VERSION = 15          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
 EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [
@@ -26,6 +27,7 @@ EXPORTS = [
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
     "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep", "dic_step_ctx_set", "dic_step_advance",
+    "dic_lin_prep", "dic_lin_prep_ws_bytes", "dic_ln_fwd_cen", "dic_ln_bwd_cen",
 ]
 
 
@@ -45,6 +47,7 @@ class GemmParams(C.Structure):
         ("B2", C.c_void_p),                                          # low-order half of a split weight (bf16 forward GEMMs) or NULL
         ("step_ctr", C.c_void_p), ("step_ctr0", C.c_int64),          # reserved (filled by dic_gemm from the step context)
         ("b2_col0", C.c_int),                                        # with B2: first output column that takes the low-order pass
+        ("bias2", C.c_void_p),                                       # bias row behind the dropout (centred residual stream) or NULL
     ]
 
 
@@ -110,6 +113,9 @@ def lib():
             if not hasattr(L, name):
                 raise RuntimeError(f"{LIB_PATH} does not export {name}")
         L.dic_last_error.restype = C.c_char_p
+        if L.dic_version() != ABI_VERSION:
+            raise RuntimeError(f"{_AB_LIB or LIB_PATH} reports ABI version {L.dic_version()}, this binding was written for {ABI_VERSION} "
+                               "(struct layouts / signatures differ): rebuild with __graft_entry__.build()")
         for fn, args in (("dic_gemm_split_ws_bytes", 4), ("dic_ce_partial_bytes", 3), ("dic_colsum_ws_bytes", 3), ("dic_ln_partial_bytes", 3)):
             getattr(L, fn).restype = C.c_size_t
             getattr(L, fn).argtypes = [C.c_int] * args
@@ -132,6 +138,11 @@ def lib():
         L.dic_lo_mean_bias_ws_bytes.argtypes = [I]
         L.dic_lo_mean_bias_ws_bytes.restype = C.c_size_t
         L.dic_ln_bwd.argtypes = [I, P, P, P, P, P, P, P, F, U64, P, I, I, I, P]
+        L.dic_lin_prep.argtypes = [P, I, I, I, I, P, P, I, I, P, P, I, P, P, P, P, P]
+        L.dic_lin_prep_ws_bytes.argtypes = [I]
+        L.dic_lin_prep_ws_bytes.restype = C.c_size_t
+        L.dic_ln_fwd_cen.argtypes = [P, P, P, P, P, P, P, P, P, I, I, F, P]
+        L.dic_ln_bwd_cen.argtypes = [P, P, P, P, P, P, P, P, F, U64, P, I, I, I, P]
         L.dic_gelu_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]
         L.dic_gelu_ln_bwd.argtypes = [I, P, P, P, P, P, P, P, I, I, I, P]
         L.dic_attn_fwd.argtypes = [I, P, P, P, I, I, I, I, F, U64, P]

@@ -576,9 +576,18 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             // inside the unrolled (fragment, column group) loops they cost ~10 scalar branches per store instruction, with the dropout hash
             // code to jump over each time.
             const T* R = (const T*)p.R;
-            auto body = [&](auto drop_c, auto resid_c, auto f32_c) {
+            auto body = [&](auto drop_c, auto resid_c, auto f32_c, auto post_c) {
                 constexpr bool DROP = decltype(drop_c)::value, RESID = decltype(resid_c)::value, F32 = decltype(f32_c)::value;
+                constexpr bool POST = decltype(post_c)::value;            // DicGemmParams.bias2: a second bias row BEHIND the dropout (centred residual stream)
                 i32x4 pre[RESID ? CNT : 1][RESID ? G::NP : 1];
+                f32x4 post[POST ? G::NP : 1][2];
+                if constexpr (POST) {
+#pragma unroll
+                    for (int q = 0; q < G::NP; ++q) {
+                        post[q][0] = v0[q] ? *(const f32x4*)(p.bias2 + nc[q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        post[q][1] = v1[q] ? *(const f32x4*)(p.bias2 + nc[q] + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
                 const LineBuf bC = F32 ? LineBuf{} : line_buf(p.C, p.ldc, 2, n_first + lcol, p.N);
                 const LineBuf bF0 = F32 ? line_buf(p.C, p.ldc, 4, n_first + fcol, p.N) : LineBuf{};
                 const LineBuf bF1 = F32 ? line_buf(p.C, p.ldc, 4, n_first + 32 + fcol, p.N) : LineBuf{};
@@ -605,6 +614,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                             x0 = dropout4(x0, p.seed, (unsigned long long)m * p.N + nc[q], p.p_drop, inv_keep);
                             x1 = dropout4(x1, p.seed, (unsigned long long)m * p.N + nc[q] + 4, p.p_drop, inv_keep);
                         }
+                        if constexpr (POST) { x0 += post[q][0]; x1 += post[q][1]; }
                         if constexpr (RESID) { f32x4 r0, r1; unpack8(pre[i][q], r0, r1); x0 += r0; x1 += r1; }
                         if constexpr (F32) put_lines_f32(i, q == 0 ? bF0 : bF1, x0, x1);
                         else P[q] = pack8f(x0, x1);
@@ -614,11 +624,12 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             };
             const bool drop = p.p_drop > 0.f, resid = PF && R != nullptr, f32o = p.out_f32 != 0;
             using Tt = std::true_type; using Ff = std::false_type;
-            if (f32o) body(Ff{}, Ff{}, Tt{});
+            if (f32o) body(Ff{}, Ff{}, Tt{}, Ff{});
             else if constexpr (PF) {
-                if (resid) { if (drop) body(Tt{}, Tt{}, Ff{}); else body(Ff{}, Tt{}, Ff{}); } else { if (drop) body(Tt{}, Ff{}, Ff{}); else body(Ff{}, Ff{}, Ff{}); }
+                if (resid) { if (drop) { if (p.bias2) body(Tt{}, Tt{}, Ff{}, Tt{}); else body(Tt{}, Tt{}, Ff{}, Ff{}); } else body(Ff{}, Tt{}, Ff{}, Ff{}); }
+                else { if (drop) body(Tt{}, Ff{}, Ff{}, Ff{}); else body(Ff{}, Ff{}, Ff{}, Ff{}); }
             } else {                                            // weight gradients: never a residual in this path
-                if (drop) body(Tt{}, Ff{}, Ff{}); else body(Ff{}, Ff{}, Ff{});
+                if (drop) body(Tt{}, Ff{}, Ff{}, Ff{}); else body(Ff{}, Ff{}, Ff{}, Ff{});
             }
         } else {
             // rare combinations (accumulating into an fp32 C; a residual with N % 8 != 0): loads inside the loop.  Still fully unrolled:
@@ -2070,6 +2081,11 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && !b_km && (epi == DIC_EPI_AFFINE || epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_BIAS_GELU_D) && p.split_k <= 1 &&
                     ((uintptr_t)p.B2 % 16) == 0 && gemm_variant() == 0 && p.b2_col0 >= 0 && p.b2_col0 % 256 == 0,
                     "dic_gemm: B2 (low-order weight half) is an option of the bf16 forward GEMMs (k-contiguous A and B, AFFINE / BIAS_GELU, no split-K)");
+    if (p.bias2)
+        DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && epi == DIC_EPI_AFFINE && p.R != nullptr && p.p_drop > 0.f && !p.out_f32 && !p.accumulate && p.N % 8 == 0 &&
+                    p.split_k <= 1 && ((uintptr_t)p.bias2 % 16) == 0 && (p.tile == 256 || p.tile == 0 || p.tile == 128) && gemm_variant() == 0,
+                    "dic_gemm: bias2 (a bias row behind the dropout) is an option of the bf16 forward AFFINE epilogue with dropout and a bf16 residual (N % 8 == 0); "
+                    "without dropout add it to `bias`");
     if (epi == DIC_EPI_CE_EXP)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && p.C && p.lse && p.partial && p.tgt_logit && p.ldc % 8 == 0 && p.ldc >= p.N &&
                     p.ldc <= ((p.N + BN - 1) / BN) * BN && p.split_k <= 1,

@@ -8,7 +8,7 @@
 static thread_local char g_err[256] = "";
 extern "C" void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* dic_last_error(void) { return g_err; }
-extern "C" int dic_version(void) { return 13; }
+extern "C" int dic_version(void) { return DIC_HIP_VERSION; }
 
 // ---- step context (see common.h): process-global, set by the code that captures a training step into a hipGraph --------------------
 static DicStepCtx g_step_ctx = {nullptr, 0, 0, nullptr};
@@ -740,26 +740,44 @@ extern "C" int dic_colsum(int in_dtype, const void* in, int rows, int cols, int 
 // entirely its row-common part abar W_lo^T (the token-specific part is independent from row to row and averages out, like the activations'
 // roundings: DESIGN.md section 4).  That part is ONE vector per Linear: a GEMV, handed to the GEMM as its bias, instead of a second pass of
 // the K loop over every row.  Stage 1 = column sums of the sampled rows in LMB_SLABS slabs, summed in fixed order by stage 2: deterministic.
-constexpr int LMB_OUT = 8, LMB_SLABS = 16;    // outputs per block; row slabs of stage 1
-// stage 1: grid (K / 256, LMB_SLABS); wave w of slab s sums the sampled rows s*4 + w, + 4*LMB_SLABS, ... (four loads in flight); LDS fold of the 4 waves
-__global__ __launch_bounds__(256) void lo_mean_rows_kernel(const bf16_t* in, int rows, int cols, long long ld, float* ws) {
-    __shared__ f32x4 red[4][64];
+constexpr int LMB_OUT = 8, LMB_SLABS = 4, LMB_WAVES = 16;    // outputs per block of stage 2; row slabs of stage 1 and waves per slab
+// stage 1: grid (K / 256, LMB_SLABS), 1024 threads; wave w of slab s sums the sampled rows s * LMB_WAVES + w, + LMB_WAVES * LMB_SLABS, ... (all of
+// them in flight at once); LDS fold of the 16 waves.  (Round 5: 4 slabs of 16 waves instead of 16 slabs of 4 -- every block of stage 2 reads all
+// the slabs, 196 KB each at K = 3072: 20 -> 10 us for the FFN lin2 preparation.)
+__global__ __launch_bounds__(1024) void lo_mean_rows_kernel(const bf16_t* in, int rows, int cols, long long ld, float* ws) {
+    __shared__ f32x4 red[LMB_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
     f32x4 a0{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     if (c < cols) {
-        const int step = 4 * LMB_SLABS;
-        int r = blockIdx.y * 4 + w;
-        for (; r + 3 * step < rows; r += 4 * step) {
-            const f32x4 v0 = Elem<bf16_t>::ld4(in + (size_t)r * ld + c), v1 = Elem<bf16_t>::ld4(in + (size_t)(r + step) * ld + c);
-            const f32x4 v2 = Elem<bf16_t>::ld4(in + (size_t)(r + 2 * step) * ld + c), v3 = Elem<bf16_t>::ld4(in + (size_t)(r + 3 * step) * ld + c);
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        const int step = LMB_WAVES * LMB_SLABS;
+        constexpr int DEPTH = 20;                         // (17 408 tokens / 16 = 1 088 sampled rows = 17 per wave: all in flight at once)
+        for (int r = blockIdx.y * LMB_WAVES + w; r < rows; r += DEPTH * step) {
+            uint2 v[DEPTH];
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                const int rj = r + j * step;
+                v[j] = *(const uint2*)(in + (size_t)(rj < rows ? rj : r) * ld + c);          // (clamped: surplus rows are loaded and dropped)
+            }
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                if (r + j * step < rows) {
+                    f32x4 x;
+                    x[0] = __uint_as_float(v[j].x << 16); x[1] = __uint_as_float(v[j].x & 0xffff0000u);
+                    x[2] = __uint_as_float(v[j].y << 16); x[3] = __uint_as_float(v[j].y & 0xffff0000u);
+                    if ((j & 3) == 0) a0 += x; else if ((j & 3) == 1) a1 += x; else if ((j & 3) == 2) a2 += x; else a3 += x;
+                }
+            }
         }
-        for (; r < rows; r += step) a0 += Elem<bf16_t>::ld4(in + (size_t)r * ld + c);
     }
     red[w][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (w == 0 && c < cols) *(f32x4*)(ws + (size_t)blockIdx.y * cols + c) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (w == 0 && c < cols) {
+        f32x4 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = (red[4 * q][lane] + red[4 * q + 1][lane]) + (red[4 * q + 2][lane] + red[4 * q + 3][lane]);
+        *(f32x4*)(ws + (size_t)blockIdx.y * cols + c) = (t[0] + t[1]) + (t[2] + t[3]);
+    }
 }
 // stage 2: a block owns LMB_OUT outputs and splits K over its 256 threads (every weight row of the block is in flight at once)
 __global__ __launch_bounds__(256) void lo_mean_bias_kernel(const float* slabs, float inv_rows, const bf16_t* lo, int ldb, int K, int N,
@@ -805,9 +823,142 @@ extern "C" int dic_lo_mean_bias(const void* A, int T, int lda, int row_stride, i
                 "dic_lo_mean_bias: bf16 A [T][lda] and lo [N][ldb], K a multiple of 4 (<= 8192), ws of dic_lo_mean_bias_ws_bytes(K)");
     const int rows = (T + row_stride - 1) / row_stride;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(lo_mean_rows_kernel, dim3((K + 255) / 256, LMB_SLABS), dim3(256), 0, st, (const bf16_t*)A, rows, K, (long long)lda * row_stride, ws);
+    hipLaunchKernelGGL(lo_mean_rows_kernel, dim3((K + 255) / 256, LMB_SLABS), dim3(64 * LMB_WAVES), 0, st, (const bf16_t*)A, rows, K, (long long)lda * row_stride, ws);
     hipLaunchKernelGGL(lo_mean_bias_kernel, dim3((N + LMB_OUT - 1) / LMB_OUT), dim3(256), (size_t)(K + 4 * LMB_OUT) * sizeof(float), st, ws, 1.0f / (float)rows,
                        (const bf16_t*)lo, ldb, K, N, bias, bias_eff);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ Linear preparation of the parity mode (round 5)
+// dic_lo_mean_bias extended by the reference rows of the CENTRED residual stream, in front of a forward Linear y = drop(A W^T + b) + R
+// (hf:183-185, 201, 221-223, 236, 253, 510):
+//   abar      = column mean of every row_stride-th row of A                                   (stage 1: lo_mean_rows_kernel, LMB_SLABS slabs)
+//   s_lo, s_hi = W_lo abar, W_hi abar                                                          (stage 2: GEMVs, LMB_OUT outputs per block)
+//   bias_in   = b + s_lo                          the mean-row lo-weight correction: what the GEMM adds in front of the dropout
+//   y_ref     = b + s_lo + s_hi + r_ref           (residual Linears) the PREDICTED mean row of the sum: the stored sum is bf16(y - y_ref)
+//   bias_post = r_ref - y_ref                     what the GEMM adds behind the dropout so that acc + bias_in + bias_post + R_c = y - y_ref
+//               (R_c = bf16(R - r_ref), the centred residual copy); fold_post: no dropout in between, bias_in += bias_post (= -s_hi)
+// Two launches.  ONE launch with a grid barrier between the stages was built and measured three ways this round (slab stores + agent-scope
+// release / acquire fences around a counter: 15-20 us; column sums and arrival counts as 64-bit fixed-point atomics polled by the readers:
+// 18-27 us; an empty kernel back to back: 4.5 us): on this chip anything that crosses workgroups inside a kernel goes through memory
+// (eight XCDs, eight L2s) at ~2 us per dependent round trip, and a kernel boundary is the cheapest such crossing there is
+// (profiles/r05_lin_prep_probe.txt).
+template <bool HI>
+__global__ __launch_bounds__(256) void lin_prep_bias_kernel(const float* slabs, float inv_rows, const bf16_t* w_hi, const bf16_t* w_lo, int ldb, int K, int N,
+                                                            const float* bias, const float* r_ref, int fold_post, float* bias_in, float* bias_post, float* y_ref) {
+    extern __shared__ __attribute__((aligned(16))) float abar[];            // [K], then [4][2 * LMB_OUT] partial sums
+    float* red = abar + K;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * LMB_OUT;
+    // the block's weight rows do not depend on stage 1: requested first, their latency overlaps the slab reads (K <= 3072: all in registers)
+    constexpr int KPT = 3;
+    uint2 pre_lo[KPT][LMB_OUT], pre_hi[HI ? KPT : 1][HI ? LMB_OUT : 1];
+    const bool pre_ok = K <= 1024 * KPT;
+    if (pre_ok) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = threadIdx.x * 4 + j * 1024;
+            if (k < K) {
+#pragma unroll
+                for (int q = 0; q < LMB_OUT; ++q) {
+                    const int n = n0 + q < N ? n0 + q : N - 1;              // (clamped: the surplus sums are not stored)
+                    pre_lo[j][q] = *(const uint2*)(w_lo + (size_t)n * ldb + k);
+                    if constexpr (HI) pre_hi[j][q] = *(const uint2*)(w_hi + (size_t)n * ldb + k);
+                }
+            }
+        }
+    }
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        f32x4 a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < LMB_SLABS; ++sl) a += *(const f32x4*)(slabs + (size_t)sl * K + k);
+        *(f32x4*)(abar + k) = a * inv_rows;
+    }
+    __syncthreads();
+    auto bfx4 = [](const uint2& u) {
+        f32x4 x;
+        x[0] = __uint_as_float(u.x << 16); x[1] = __uint_as_float(u.x & 0xffff0000u);
+        x[2] = __uint_as_float(u.y << 16); x[3] = __uint_as_float(u.y & 0xffff0000u);
+        return x;
+    };
+    float alo[LMB_OUT], ahi[LMB_OUT];
+#pragma unroll
+    for (int q = 0; q < LMB_OUT; ++q) alo[q] = ahi[q] = 0.f;
+    if (pre_ok) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = threadIdx.x * 4 + j * 1024;
+            if (k < K) {
+                const f32x4 sv = *(const f32x4*)(abar + k);
+#pragma unroll
+                for (int q = 0; q < LMB_OUT; ++q) {
+                    const f32x4 wl = bfx4(pre_lo[j][q]);
+                    alo[q] += (wl[0] * sv[0] + wl[1] * sv[1]) + (wl[2] * sv[2] + wl[3] * sv[3]);
+                    if constexpr (HI) {
+                        const f32x4 wh = bfx4(pre_hi[j][q]);
+                        ahi[q] += (wh[0] * sv[0] + wh[1] * sv[1]) + (wh[2] * sv[2] + wh[3] * sv[3]);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int k = threadIdx.x * 4; k < K; k += 1024) {
+            const f32x4 sv = *(const f32x4*)(abar + k);
+#pragma unroll
+            for (int q = 0; q < LMB_OUT; ++q) {
+                const int n = n0 + q < N ? n0 + q : N - 1;
+                const f32x4 wl = Elem<bf16_t>::ld4(w_lo + (size_t)n * ldb + k);
+                alo[q] += (wl[0] * sv[0] + wl[1] * sv[1]) + (wl[2] * sv[2] + wl[3] * sv[3]);
+                if constexpr (HI) {
+                    const f32x4 wh = Elem<bf16_t>::ld4(w_hi + (size_t)n * ldb + k);
+                    ahi[q] += (wh[0] * sv[0] + wh[1] * sv[1]) + (wh[2] * sv[2] + wh[3] * sv[3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < LMB_OUT; ++q) {
+        const float tl = wave_sum(alo[q]);
+        const float th = HI ? wave_sum(ahi[q]) : 0.f;
+        if (lane == 0) { red[(w * 2) * LMB_OUT + q] = tl; red[(w * 2 + 1) * LMB_OUT + q] = th; }
+    }
+    __syncthreads();
+    if (threadIdx.x < LMB_OUT && n0 + (int)threadIdx.x < N) {
+        const int q = threadIdx.x, n = n0 + q;
+        const float s_lo = (red[q] + red[2 * LMB_OUT + q]) + (red[4 * LMB_OUT + q] + red[6 * LMB_OUT + q]);
+        const float b_in = (bias ? bias[n] : 0.f) + s_lo;
+        if constexpr (HI) {
+            const float s_hi = (red[LMB_OUT + q] + red[3 * LMB_OUT + q]) + (red[5 * LMB_OUT + q] + red[7 * LMB_OUT + q]);
+            const float rr = r_ref ? r_ref[n] : 0.f;
+            const float yr = (b_in + s_hi) + rr;
+            const float post = rr - yr;
+            y_ref[n] = yr;
+            if (bias_post) bias_post[n] = post;
+            bias_in[n] = fold_post ? b_in + post : b_in;
+        } else {
+            bias_in[n] = b_in;
+        }
+    }
+}
+extern "C" size_t dic_lin_prep_ws_bytes(int K) { return (size_t)LMB_SLABS * K * sizeof(float); }
+extern "C" int dic_lin_prep(const void* A, int T, int lda, int row_stride, int K, const void* w_hi, const void* w_lo, int ldb, int N, const float* bias,
+                            const float* r_ref, int fold_post, float* bias_in, float* bias_post, float* y_ref, void* ws, void* stream) {
+    DIC_REQUIRE(A && w_lo && bias_in && ws && T > 0 && row_stride > 0 && K % 4 == 0 && K > 0 && N > 0 && lda % 4 == 0 && ldb % 4 == 0 && K <= 8192,
+                "dic_lin_prep: bf16 A [T][lda], lo [N][ldb], K a multiple of 4 (<= 8192), a ws of dic_lin_prep_ws_bytes(K)");
+    DIC_REQUIRE((y_ref != nullptr) == (w_hi != nullptr) && (y_ref || (!bias_post && !r_ref && !fold_post)),
+                "dic_lin_prep: the reference row y_ref needs the hi weights; bias_post / r_ref / fold_post only exist with it");
+    const int rows = (T + row_stride - 1) / row_stride;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lo_mean_rows_kernel, dim3((K + 255) / 256, LMB_SLABS), dim3(64 * LMB_WAVES), 0, st, (const bf16_t*)A, rows, K, (long long)lda * row_stride, (float*)ws);
+    const dim3 grid((N + LMB_OUT - 1) / LMB_OUT);
+    const size_t lds = (size_t)(K + 8 * LMB_OUT) * sizeof(float);
+    if (y_ref)
+        hipLaunchKernelGGL(lin_prep_bias_kernel<true>, grid, dim3(256), lds, st, (const float*)ws, 1.0f / (float)rows, (const bf16_t*)w_hi, (const bf16_t*)w_lo, ldb, K, N, bias,
+                           r_ref, fold_post, bias_in, bias_post, y_ref);
+    else
+        hipLaunchKernelGGL(lin_prep_bias_kernel<false>, grid, dim3(256), lds, st, (const float*)ws, 1.0f / (float)rows, (const bf16_t*)nullptr, (const bf16_t*)w_lo, ldb, K, N, bias,
+                           (const float*)nullptr, 0, bias_in, (float*)nullptr, (float*)nullptr);
     DIC_CHECK_LAUNCH();
     return 0;
 }

@@ -204,14 +204,59 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TY* y, const float* g
     }
 }
 
+// CENTRED RESIDUAL STREAM (round 5; replaces the fp32 copies of dic_ln_fwd_r32 in the parity mode): the pre-LayerNorm sum arrives as
+// y_c = bf16(y - y_ref) with ONE fp32 reference row y_ref per tensor (predicted by dic_lin_prep before the GEMM ran), the LayerNorm runs on
+// y_c + y_ref in fp32 and leaves two bf16 tensors: h, the next Linear's MFMA operand, and h_c = bf16(h - h_ref), the residual operand of
+// the next residual GEMM, centred on h_ref = LayerNorm(y_ref) (every wave computes it; block 0 publishes it).  While a denoiser's rows are
+// nearly equal (the first hundreds of training steps) the rounding error of a bf16 residual stream is the SAME vector for every token and
+// does not average out of a batch-mean loss; stored relative to a row all tokens are close to, it is 2^-9 of the rows' differences instead
+// of 2^-9 of the rows (profiles/r05_cen_probe.txt: the same loss distances as the fp32 residual stream, at bf16 bytes).
+__global__ __launch_bounds__(256) void ln_fwd_cen_kernel(const bf16_t* y_c, const float* y_ref, const float* gamma, const float* beta, bf16_t* h, bf16_t* h_c,
+                                                         float* h_ref, float* mean, float* rstd, int rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    f32x4 g[NCH], b[NCH], yr[NCH], hr[NCH];
+    load_row<float>(gamma, lane, g);
+    load_row<float>(beta, lane, b);
+    load_row<float>(y_ref, lane, yr);
+    {
+        float mu, rs;
+        row_stats(yr, eps, mu, rs);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hr[c][k] = (yr[c][k] - mu) * rs * g[c][k] + b[c][k];
+        if (h_ref && blockIdx.x == 0 && threadIdx.x < 64) store_row<float>(h_ref, lane, hr);
+    }
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        f32x4 v[NCH];
+        load_row<bf16_t>(y_c + (size_t)row * D, lane, v);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[c] = v[c] + yr[c];
+        float mu, rs;
+        row_stats(v, eps, mu, rs);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[c][k] = (v[c][k] - mu) * rs * g[c][k] + b[c][k];
+        store_row<bf16_t>(h + (size_t)row * D, lane, v);
+        if (h_c) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) v[c] = v[c] - hr[c];
+            store_row<bf16_t>(h_c + (size_t)row * D, lane, v);
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
 template <typename T, typename TY = T>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, const TY* y, const float* gamma, const float* mean, const float* rstd, T* dx, T* dx_drop,
-                                                      float p_drop, SeedArg seed_, float* partial, int rows) {
+                                                      float p_drop, SeedArg seed_, float* partial, int rows, const float* y_ref = nullptr) {
     const unsigned long long seed = seed_.resolve();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
-    f32x4 g[NCH];
+    f32x4 g[NCH], yr[NCH];
     load_row<float>(gamma, lane, g);
+    if (y_ref) load_row<float>(y_ref, lane, yr);         // centred residual stream: y holds bf16(y - y_ref) (ln_fwd_cen_kernel)
     f32x4 acc[3][NCH];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -226,6 +271,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* dh, con
         load_row<TY>(y + (size_t)row * D, lane, v);
         load_row<T>(dh + (size_t)row * D, lane, d);
         const float mu = mean[row], rs = rstd[row];
+        if (y_ref) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) v[c] = v[c] + yr[c];
+        }
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -468,6 +517,29 @@ extern "C" int dic_ln_fwd_r32(const float* y32, const float* gamma, const float*
     DIC_REQUIRE(Dd == D && T > 0 && h_bf16 != nullptr, "dic_ln_fwd_r32: D must be 768");
     dim3 grid(rows_grid(T, 2048)), block(256);
     hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float>), grid, block, 0, (hipStream_t)stream, y32, gamma, beta, (bf16_t*)h_bf16, h32, mean, rstd, T, eps);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_ln_fwd_cen(const void* y_c, const float* y_ref, const float* gamma, const float* beta, void* h, void* h_c, float* h_ref, float* mean,
+                              float* rstd, int T, int Dd, float eps, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0 && y_c && y_ref && h, "dic_ln_fwd_cen: D must be 768; y_c (bf16), y_ref (fp32 [768]) and h are required");
+    dim3 grid(rows_grid(T, 1024)), block(256);
+    hipLaunchKernelGGL(ln_fwd_cen_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)y_c, y_ref, gamma, beta, (bf16_t*)h, (bf16_t*)h_c, h_ref, mean, rstd, T, eps);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dic_ln_bwd_cen(const void* dh, const void* y_c, const float* y_ref, const float* gamma, const float* mean, const float* rstd, void* dx,
+                              void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks, int T, int Dd, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0 && n_partial_blocks > 0 && y_ref, "dic_ln_bwd_cen: D must be 768; y_ref is the reference row of dic_ln_fwd_cen's input");
+    dim3 grid(n_partial_blocks), block(64 * LNB_WAVES);
+    const size_t lds = LNB_WAVES * 3 * D * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, lds, (hipStream_t)stream, (const bf16_t*)dh, (const bf16_t*)y_c, gamma, mean, rstd, (bf16_t*)dx,
+                       (bf16_t*)dx_drop, p_drop, make_seed(seed, DIC_STRIDE_DROP), partial, T, y_ref);
     DIC_CHECK_LAUNCH();
     return 0;
 }

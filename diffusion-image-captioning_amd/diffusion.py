@@ -204,7 +204,7 @@ def set_rng_state(st: dict, model=None):
     shift = (r - sr) * parallel._RANK_MIX
     if st.get("t_seed") is not None:
         _state["t_seed"] = int(st["t_seed"])
-    _state["noise_seed"] = (int(st["noise_seed"]) + shift) & 0xFFFFFFFFFFFFFFFF
+    _state["noise_seed"] = (int(st["noise_seed"]) + shift) & 0x7FFFFFFFFFFFFFFF       # mod 2^63, exactly like parallel.rank_seed at start-up
     gstates = list(st.get("guidance", {}).values())
     if r == sr and gstates:
         g = _guidance_gen()
@@ -227,8 +227,10 @@ def _t_one(dev):
 
 
 def _next_seed():
-    _state["noise_seed"] += 0x9E3779B1
-    return _state["noise_seed"] & 0xFFFFFFFFFFFFFFFF
+    # the counter lives mod 2^63 like every per-rank seed (parallel.rank_seed): a stream restored from another rank's checkpoint
+    # (set_rng_state) then continues bit for bit where an uninterrupted run of this rank would be
+    _state["noise_seed"] = (_state["noise_seed"] + 0x9E3779B1) & 0x7FFFFFFFFFFFFFFF
+    return _state["noise_seed"]
 
 
 # ------------------------------------------------------------------ q_sample (ref :347-362)

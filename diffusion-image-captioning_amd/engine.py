@@ -47,7 +47,7 @@ class Ops:
 
     def gemm(self, A, B, Cc, M, N, K, lda, ldb, ldc, a_km=0, b_km=0, epi=EPI_AFFINE, bias=0, R=0, ldr=0, aux=0,
              ldaux=0, p_drop=0.0, seed=0, out_f32=0, accumulate=0, tgt=0, lse=0, partial=0, tgt_logit=0,
-             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0, B2=0, b2_col0=0):
+             ce_rows_a=0, ce_scale_a=0.0, ce_scale_b=0.0, dtype=None, split_k=1, split_ws=0, colsum_out=0, tile=None, cu_cap=0, B2=0, b2_col0=0, bias2=0):
         g = self._gp
         g.A, g.B, g.C = A, B, Cc
         g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -55,7 +55,7 @@ class Ops:
         g.p_drop, g.seed, g.out_f32, g.accumulate = p_drop, seed, out_f32, accumulate
         g.tgt, g.lse, g.partial, g.tgt_logit = tgt, lse, partial, tgt_logit
         g.ce_rows_a, g.ce_scale_a, g.ce_scale_b = ce_rows_a, ce_scale_a, ce_scale_b
-        g.split_k, g.split_ws, g.colsum_out, g.B2, g.b2_col0 = split_k, split_ws, colsum_out, B2, b2_col0
+        g.split_k, g.split_ws, g.colsum_out, g.B2, g.b2_col0, g.bias2 = split_k, split_ws, colsum_out, B2, b2_col0, bias2
         dt = self.dt if dtype is None else dtype
         if tile is None:
             tile = choose_tile(M, N, split_k, epi) if (dt == DIC_BF16 and epi != EPI_CE_PARTIAL and (not a_km or M % 256 == 0)) else 128
@@ -83,12 +83,13 @@ _PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"      # the two Layer
 # "only xr"); "0" switches it off, "w" keeps it to the split-weight mode as before (A/B switches)
 _HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "1")
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
-_SPLIT_SET = _os.environ.get("DIC_SPLIT_SET", "all")          # "vo2t" | "all": which forward Linears take the lo weight half in the split-weight mode
+_SPLIT_SET = _os.environ.get("DIC_SPLIT_SET", "auto")         # "vo2t" | "all" | "auto": which forward Linears take the lo weight half in the split-weight modes
 _BWD_PARITY = max(2, int(_os.environ.get("DIC_BWD_PARITY", "2")))   # gradient-buffer sets shared by the main and the weight-gradient stream (A/B switch)
 _UVT32 = _os.environ.get("DIC_UVT32", "1") != "0"
 # fp32 residual stream (include/dic_hip.h, DIC_RES_F32): "auto" = with the split weights (the parity mode dtype="bf16w"), "1" / "0" force it (A/B)
 _RES32 = _os.environ.get("DIC_RES32", "auto")
 DIC_U_F32, DIC_RES_F32, OUT_F32_RES_F32 = 0x100, 0x200, 3
+_CEN = _os.environ.get("DIC_CEN", "1") != "0"              # bf16m: centred bf16 residual stream + one-launch dic_lin_prep ("0": round 4's fp32 residual stream + dic_lo_mean_bias; A/B)
 _CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
 
@@ -163,7 +164,9 @@ class Denoiser:
         # transform -- at B = 512 FFN lin1 and the query / key projections make no measurable difference to any loss term at any state (54 % of the
         # second-pass flops), at small batches they do, hence not the default.
         # split_slots (slot -> bool) overrides the set, split_qk overrides the q / k choice (the probes use both).
-        self.split_set = _SPLIT_SET
+        # "auto" (round 5): the exact form bf16w corrects every Linear; the mean-row form bf16m leaves out FFN lin1 -- its correction never moved a
+        # loss term at any state (round 4, B = 512; 7e-5 at B = 16 with q / k left out as well), and it is one launch per layer on the critical path
+        self.split_set = _SPLIT_SET if _SPLIT_SET != "auto" else ("vo2t" if self.lo_mode == "mean" else "all")
         self.split_slots = None
         self.split_qk = None
         self.dt = DIC_BF16 if self.bf16 else DIC_F32
@@ -171,7 +174,11 @@ class Denoiser:
         self.uvt32 = self.bf16 and _UVT32
         self.dt_u = (self.dt | DIC_U_F32) if self.uvt32 else self.dt
         # fp32 residual stream: the pre-LayerNorm sums and the residual operands of the two residual GEMMs of a block in fp32, bf16 MFMA operands
-        self.res32 = self.bf16 and (_RES32 == "1" or (_RES32 == "auto" and self.split_w))
+        # CENTRED residual stream (round 5, the parity mode dtype="bf16m"): the same roundings removed at bf16 bytes -- the pre-LayerNorm sums and the
+        # residual operands are stored as bf16(value - reference row), one fp32 reference row per tensor predicted by dic_lin_prep
+        # (include/dic_hip.h; DIC_CEN=0: the round-4 form of bf16m, fp32 copies)
+        self.cen = self.split_w and self.lo_mode == "mean" and _CEN
+        self.res32 = self.bf16 and not self.cen and (_RES32 == "1" or (_RES32 == "auto" and self.split_w))
         self.dt_ln = (self.dt | DIC_RES_F32) if self.res32 else self.dt
         self.tdtype = torch.bfloat16 if self.bf16 else torch.float32
         self.es = 2 if self.bf16 else 4
@@ -358,6 +365,14 @@ class Denoiser:
         if self.lo_mode == "mean":
             ws["beff"] = f(self.n_layers * (6 * D + Hd) + D)       # effective biases of the forward Linears (bias + mean-row lo correction)
             ws["lomean_ws"] = f(64 * Hd)
+        if self.cen:
+            # centred residual stream: reference rows [layer][y1 | sa | y2 | h_next][768] (+ a zero row: the embedding LayerNorm's output is stored
+            # as it is), the bias rows that go behind FFN-2's dropout, the centred residual copies of sa / h
+            ws["refs"] = torch.zeros(self.n_layers + 1, 4, D, dtype=torch.float32, device=dev)
+            ws["bpost"] = f(self.n_layers, 2, D)
+            ws["hc"] = [None] + [e(T, D) for _ in range(self.n_layers - 1)]
+            for Lw in ws["layers"]:
+                Lw["sac"] = e(T, D)
         if self.res32:
             ws["h32"] = [f(T, D) for _ in range(self.n_layers)]          # residual operand of layer i's out-proj (the last LayerNorm's output has no reader)
             for Lw in ws["layers"]:
@@ -436,12 +451,19 @@ class Denoiser:
         while math.gcd(lo_stride, Tk) != 1:
             lo_stride += 1
 
-        def bias_of(wslot, bslot, a_ptr, K, Nn):
-            """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows), two small launches"""
-            if not lo_mean or (sel is not None and not sel(wslot)):
+        cen = self.cen
+        def bias_of(wslot, bslot, a_ptr, K, Nn, resid=None):
+            """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows).
+            resid = (r_ref, y_ref, bias_post, fold): the centred residual stream's reference rows for a residual Linear (dic_lin_prep)."""
+            if not lo_mean or (resid is None and sel is not None and not sel(wslot)):
                 return P.ptr(bslot)
             out = _p(ws["beff"]) + beff_off[0] * 4
             beff_off[0] += Nn
+            if cen:
+                r_ref, y_ref, b_post, fold = resid if resid is not None else (0, 0, 0, 0)
+                _lib.check(lib.dic_lin_prep(a_ptr, T, K, lo_stride, K, P.ptr(wslot, "Pb") if resid is not None else 0, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot),
+                                            r_ref, fold, out, b_post, y_ref, _p(ws["lomean_ws"]), st), "lin_prep")
+                return out
             _lib.check(lib.dic_lo_mean_bias(a_ptr, T, K, lo_stride, K, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot), out, _p(ws["lomean_ws"]), st),
                        "lo_mean_bias")
             return out
@@ -484,6 +506,11 @@ class Denoiser:
                                              P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
                                              _p(ws["h32"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
         of = OUT_F32_RES_F32 if r32 else 0
+        if cen:
+            refs = ws["refs"]
+            ref = lambda i, j: refs.data_ptr() + ((i * 4 + j) * D) * 4          # j: 0 y1_ref, 1 sa_ref, 2 y2_ref, 3 h_ref of layer i + 1
+            zero_ref = ref(self.n_layers, 0)                                      # (the last block of `refs` is never written: zeros)
+            bpost = lambda i, j: ws["bpost"].data_ptr() + ((i * 2 + j) * D) * 4
         for i in range(self.n_layers):
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
@@ -492,6 +519,23 @@ class Denoiser:
                    B2=lo(pre + "Wqkv"), b2_col0=v_col0)
             # K6: attention
             _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
+            if cen:
+                # K7 / K8 on the centred residual stream: y1, y2 hold bf16(sum - predicted mean row), the residual operands bf16(h - h_ref) / bf16(sa - sa_ref)
+                h_ref = zero_ref if i == 0 else ref(i - 1, 3)
+                o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D,
+                       bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D, resid=(h_ref, ref(i, 0), 0, 1)), R=_p(h) if i == 0 else _p(ws["hc"][i]), ldr=D)
+                _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y1"]), ref(i, 0), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["sac"]), ref(i, 1),
+                                              _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd_cen")
+                o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU,
+                       bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd), aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
+                drop2 = ph > 0.0
+                o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D,
+                       bias=bias_of(pre + "W2", pre + "b2", _p(Lw["g"]), Hd, D, resid=(ref(i, 1), ref(i, 2), bpost(i, 1) if drop2 else 0, 0 if drop2 else 1)),
+                       bias2=bpost(i, 1) if drop2 else 0, R=_p(Lw["sac"]), ldr=D, p_drop=ph, seed=seed + 4 * i + 2)
+                last = i + 1 == self.n_layers
+                _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y2"]), ref(i, 2), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]),
+                                              0 if last else _p(ws["hc"][i + 1]), 0 if last else ref(i, 3), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd_cen")
+                continue
             # K7: out-proj + bias + residual, then LayerNorm
             o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D), R=_p(ws["h32"][i]) if r32 else _p(h), ldr=D,
                    B2=lo(pre + "Wo"), out_f32=of)
@@ -667,8 +711,13 @@ class Denoiser:
                 main.wait_event(done[i + npar])       # the dW GEMMs of layer i + npar have finished with this set's buffers
             dy_, dyd_, dy1_, du_, dqkv_ = ws["dy"][sp], ws["dyd"][sp], ws["dy1"][sp], ws["du"][sp], ws["dqkv"][sp]
             # output_layer_norm backward; bias grad of lin2 folded in
-            _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
-                                      _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
+            if self.cen:
+                yref = lambda j: ws["refs"].data_ptr() + ((i * 4 + j) * D) * 4
+                _lib.check(lib.dic_ln_bwd_cen(_p(dH), _p(Lw["y2"]), yref(2), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
+                                              _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
+            else:
+                _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
+                                          _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
             if not _PAIR_FOLDS:
                 fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                          # [ln2g | ln2b | b2]
             dyd = dyd_ if use_drop else dy_
@@ -681,8 +730,12 @@ class Denoiser:
             flush_side()                              # one launch per layer starts the side stream too late to hide behind this layer's chain
             o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
-            _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
-                                      0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
+            if self.cen:
+                _lib.check(lib.dic_ln_bwd_cen(_p(ws["dsa"]), _p(Lw["y1"]), yref(0), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
+                                              0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
+            else:
+                _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
+                                          0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
             if _PAIR_FOLDS:                                                                   # [ln2g | ln2b | b2] and [ln1g | ln1b | bo] in one launch
                 fold2(parts[2 * sp], P.ptr(pre + "ln2g", "G"), parts[2 * sp + 1], P.ptr(pre + "ln1g", "G"), 3 * D)
             else:

@@ -39,6 +39,9 @@ extern "C" {
 #define DIC_OUT_F32 1
 #define DIC_RES_IS_F32 2
 
+/* ABI version: bumped whenever a struct layout or a signature in this header changes; a binding must refuse a library whose dic_version()
+ * differs from the DIC_HIP_VERSION it was written against (diffusion-image-captioning_amd/_lib.py does).                          */
+#define DIC_HIP_VERSION 15
 int dic_version(void);
 const char* dic_last_error(void);
 
@@ -103,6 +106,8 @@ typedef struct DicGemmParams {
     int64_t step_ctr0;          /* replayed inside a hipGraph shifts `seed` by 64 x (steps since capture), as the host does between eager steps */
     int b2_col0;                /* with B2: only output columns >= b2_col0 (a multiple of 256) take the second pass, the others use B alone -- the
                                    fused q|k|v projection with the low-order half on its value third only (b2_col0 = 2 D); 0: every column */
+    const float* bias2;         /* [N] or NULL (bf16 forward AFFINE with dropout and a bf16 residual): C = dropout(acc + bias) + bias2 + R -- the row the
+                                   centred residual stream adds BEHIND the dropout of hf:223 (dic_lin_prep's bias_post); without dropout it is part of `bias` */
 } DicGemmParams;
 
 int dic_gemm(int dtype, int a_km, int b_km, int epi, const DicGemmParams* p, void* stream);
@@ -340,6 +345,28 @@ int dic_colsum_pair(const float* in0, float* out0, const float* in1, float* out1
 size_t dic_lo_mean_bias_ws_bytes(int K);
 int dic_lo_mean_bias(const void* A, int T, int lda, int row_stride, int K, const void* lo, int ldb, int N, const float* bias, float* bias_eff,
                      float* ws, void* stream);
+
+/* ---------------------------------------------------------------- one-launch Linear preparation + centred residual stream (round 5)
+ * The parity mode of the bf16 engine (hf:183-185, 201, 221-223, 236, 253, 510 evaluated so that no rounding is COMMON to all token rows):
+ *   dic_lin_prep, in front of a forward Linear y = dropout(A W^T + b) + R (two small launches, like dic_lo_mean_bias, which it extends):
+ *     abar = column mean of every row_stride-th row of A (bf16 [T][lda]); s_lo = W_lo abar, s_hi = W_hi abar (W_hi / W_lo: the bf16 halves of the fp32
+ *     weight, [N][ldb]);
+ *     bias_in[n]   = bias[n] + s_lo[n]                 -> DicGemmParams.bias: dic_lo_mean_bias's correction
+ *     and, when y_ref is given (the residual Linears; needs w_hi):
+ *     y_ref[n]     = bias[n] + s_lo[n] + s_hi[n] + r_ref[n]    the predicted mean row of the sum; the GEMM stores bf16(y - y_ref)
+ *     bias_post[n] = r_ref[n] - y_ref[n]               -> DicGemmParams.bias2 (behind the dropout); fold_post = 1 (no dropout): added to bias_in instead
+ *     r_ref: the reference row of the centred residual operand R_c = bf16(R - r_ref) (NULL: R is stored as it is).
+ *     ws: dic_lin_prep_ws_bytes(K) bytes.  Deterministic (slabs of column sums added in a fixed order).
+ *   dic_ln_fwd_cen: LayerNorm of y = y_c + y_ref (y_c bf16 [T][768], y_ref fp32 [768]) -> h = bf16(LN(y)) (the next Linear's operand), h_c =
+ *     bf16(LN(y) - h_ref) (optional: the next residual operand), h_ref = LN(y_ref) (fp32 [768], optional output), mean / rstd as dic_ln_fwd.
+ *   dic_ln_bwd_cen: dic_ln_bwd (bf16) with y given as (y_c, y_ref).                                                                             */
+size_t dic_lin_prep_ws_bytes(int K);
+int dic_lin_prep(const void* A, int T, int lda, int row_stride, int K, const void* w_hi, const void* w_lo, int ldb, int N, const float* bias,
+                 const float* r_ref, int fold_post, float* bias_in, float* bias_post, float* y_ref, void* ws, void* stream);
+int dic_ln_fwd_cen(const void* y_c, const float* y_ref, const float* gamma, const float* beta, void* h, void* h_c, float* h_ref, float* mean,
+                   float* rstd, int T, int D, float eps, void* stream);
+int dic_ln_bwd_cen(const void* dh, const void* y_c, const float* y_ref, const float* gamma, const float* mean, const float* rstd, void* dx,
+                   void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks, int T, int D, void* stream);
 
 /* ---------------------------------------------------------------- AdamW (ref:335 -- torch defaults, decoupled wd on every tensor)
  * p,g,m,v flat f32 [n]; g is multiplied by grad_scale first (1/world_size after the RCCL sum);

@@ -40,15 +40,42 @@ VARIANTS = {
 }
 
 
+_SR_RUNS = 0
+
+
 def bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def bf_sr(x, gen):
+    """Stochastic rounding to bf16 (round 5): add 16 uniform random bits below the bf16 mantissa, truncate.  Unbiased, and -- unlike
+    round-to-nearest -- independent from row to row even when the rows are equal, which is what a batch-mean loss averages out."""
+    bits = x.contiguous().view(torch.int32)
+    rnd = torch.randint(0, 65536, bits.shape, dtype=torch.int32, device=x.device, generator=gen)
+    return ((bits + rnd) & -65536).view(torch.float32)
+
+
 def run(points, P, E, batch, t, nz, layers, L=16):
-    r = lambda name, x: bf(x) if name in points else x
+    # "sr" (round 5): every ACTIVATION rounding point that is on rounds stochastically (one draw per stored tensor: h / sa feed the GEMM and
+    # the residual add from the same bf16 copy); "p" (in-register attention probabilities) and the weights keep round-to-nearest
+    sr = "sr" in points
+    global _SR_RUNS
+    _SR_RUNS += 1                                    # every stochastic run is a fresh draw (listing a group twice shows the spread)
+    gen = torch.Generator(device=E.device).manual_seed(77 + _SR_RUNS) if sr else None
+    memo = {}
+
+    def r(name, x):
+        if name not in points:
+            return x
+        if sr and name not in ("w", "wlm", "p"):
+            k = id(x)
+            if k not in memo:
+                memo[k] = (x, bf_sr(x, gen))          # (keeps x alive so the id stays unique)
+            return memo[k][1]
+        return bf(x)
     W = lambda n: r("w", P[n])
 
-    def lin(x, wname, bname):
+    def lin(x, wname, bname, abar=None):
         """nn.Linear with the weight rounded to bf16 when "w" is on.  "wcm" / "wcmp" (round 4, collapse_probe.py): add back the part of the
         rounding's effect that is common to the rows -- mean row (of all rows / of the rows at each sequence position of each pass) times the
         lo half: one GEMV (or a [2T x K] GEMM) per Linear instead of a second pass over every row."""
@@ -59,8 +86,8 @@ def run(points, P, E, batch, t, nz, layers, L=16):
                 half = x.shape[0] // 2
                 xm = torch.cat([x[:half].mean(0, keepdim=True).expand(half, -1, -1), x[half:].mean(0, keepdim=True).expand(x.shape[0] - half, -1, -1)])
                 y = y + F.linear(xm, lo)
-            else:
-                y = y + F.linear(x.reshape(-1, x.shape[-1]).mean(0), lo)
+            else:             # abar (round 5, "wcmref"): a PREDICTED mean row (the centred stream's reference row) instead of the measured one
+                y = y + F.linear(x.reshape(-1, x.shape[-1]).mean(0) if abar is None else abar, lo)
         return y
     B = batch["input_ids"].shape[0]
     dev = E.device                                                          # (round 4: the same what-if on the GPU, collapse_probe.py)
@@ -82,21 +109,49 @@ def run(points, P, E, batch, t, nz, layers, L=16):
     ln = lambda v, a: F.layer_norm(v, (768,), P[a + ".weight"], P[a + ".bias"], 1e-12)
     h = ln(h, pre + "embeddings.LayerNorm")
     T = L + 1
+    # "cen" (round 5): the residual stream stored as bf16(value - reference row), the reference row (fp32, one per tensor) PREDICTED before the
+    # tensor exists: pre-LayerNorm sums y_ref = (mean input row) W^T + b + residual's reference, LayerNorm outputs o_ref = LN(y_ref), the
+    # embedding LayerNorm's output uncentred (its rows are noised embeddings, never equal).  "cenop": the GEMM operand copy of h / sa is
+    # that same centred tensor (its reference row enters through the bias: o_ref W^T in fp32).
+    cen, cenop = "cen" in points, "cenop" in points
+    cb = lambda v, ref: ref + bf(v - ref)
+    h_ref = torch.zeros(768, device=dev)
     for i in range(layers):
         lp = pre + f"transformer.layer.{i}."
-        ho = r("h_op", h)
-        q, k, v = (r("qkv", lin(ho, lp + f"attention.{s}_lin.weight", lp + f"attention.{s}_lin.bias")) for s in "qkv")
+        if cen:
+            h_st = cb(h, h_ref)
+            ho = h_st if cenop else r("h_op", h)
+        else:
+            ho = r("h_op", h)
+        pred = "wcmref" in points and cen                  # ("wcmref_qkv" / "_lin1" / "_vt": one family of LayerNorm-fed Linears at a time)
+        pq = (pred or "wcmref_qkv" in points) and cen and i > 0
+        q, k, v = (r("qkv", lin(ho, lp + f"attention.{s}_lin.weight", lp + f"attention.{s}_lin.bias", h_ref if pq else None)) for s in "qkv")
         sh = lambda z: z.view(n, T, 12, 64).transpose(1, 2)
         s_ = torch.matmul(sh(q), sh(k).transpose(2, 3)) * 0.125
         s_ = s_.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
         p_ = r("p", F.softmax(s_, -1))
         ctx = r("ctx", torch.matmul(p_, sh(v)).transpose(1, 2).reshape(n, T, 768))
+        if cen:
+            flat = lambda z: z.reshape(-1, z.shape[-1])[::16].mean(0)                # the engine's sampled mean row (every 16th token row)
+            y1_ref = F.linear(flat(ctx), P[lp + "attention.out_lin.weight"], P[lp + "attention.out_lin.bias"]) + h_ref
+            y1 = cb(lin(ctx, lp + "attention.out_lin.weight", lp + "attention.out_lin.bias") + h_st, y1_ref)
+            sa = ln(y1, lp + "sa_layer_norm")
+            sa_ref = ln(y1_ref, lp + "sa_layer_norm")
+            sa_st = cb(sa, sa_ref)
+            g = r("g", F.gelu(lin(sa_st if cenop else r("sa_op", sa), lp + "ffn.lin1.weight", lp + "ffn.lin1.bias", sa_ref if (pred or "wcmref_lin1" in points) else None)))
+            y2_ref = F.linear(flat(g), P[lp + "ffn.lin2.weight"], P[lp + "ffn.lin2.bias"]) + sa_ref
+            y2 = cb(lin(g, lp + "ffn.lin2.weight", lp + "ffn.lin2.bias") + sa_st, y2_ref)
+            h = ln(y2, lp + "output_layer_norm")
+            h_ref = ln(y2_ref, lp + "output_layer_norm")
+            continue
         y1 = r("y1", lin(ctx, lp + "attention.out_lin.weight", lp + "attention.out_lin.bias") + r("h_res", h))
         sa = ln(y1, lp + "sa_layer_norm")
         g = r("g", F.gelu(lin(r("sa_op", sa), lp + "ffn.lin1.weight", lp + "ffn.lin1.bias")))
         y2 = r("y2", lin(g, lp + "ffn.lin2.weight", lp + "ffn.lin2.bias") + r("sa_res", sa))
         h = ln(y2, lp + "output_layer_norm")
-    u = r("uvt", lin(r("h_op", h), "model.vocab_transform.weight", "model.vocab_transform.bias"))
+    if cen and cenop:
+        h = cb(h, h_ref)
+    u = r("uvt", lin(h if (cen and cenop) else r("h_op", h), "model.vocab_transform.weight", "model.vocab_transform.bias", h_ref if (cen and ("wcmref" in points or "wcmref_vt" in points)) else None))
     xo = ln(F.gelu(u), "model.vocab_layer_norm")[:, :L]
     tgt = x0.repeat(2, 1, 1)
     l1 = (xo - tgt).abs().sum(1)

@@ -55,6 +55,34 @@ if args.groups == "r32":                         # which half of the fp32 residu
     GROUPS = [("no fp32 residual stream", NOW), ("fp32 residual stream (both residual GEMMs)", NOW - {"h_res", "sa_res", "y1", "y2"}),
               ("FFN half only (y2, sa_res)", NOW - {"sa_res", "y2"}), ("attention half only (y1, h_res)", NOW - {"h_res", "y1"}),
               ("sums only (y1, y2)", NOW - {"y1", "y2"}), ("residual reads only (h_res, sa_res)", NOW - {"h_res", "sa_res"})]
+if args.groups == "sr":                          # round 5: stochastic rounding of every stored activation instead of fp32 copies of some of them
+    NOW = ACT - {"uvt", "xr"}
+    R32 = NOW - {"h_res", "sa_res", "y1", "y2"}
+    GROUPS = [("RTN: round-4 bf16 activations (fp32 uvt, centred head)", NOW), ("RTN: + fp32 residual stream (bf16m / bf16w)", R32),
+              ("RTN: every activation point in bf16", ACT), ("SR : every activation point in bf16", ACT | {"sr"}),
+              ("SR : every activation point (second draw)", ACT | {"sr"}), ("SR : all but uvt", (ACT - {"uvt"}) | {"sr"}),
+              ("SR : all but xr", (ACT - {"xr"}) | {"sr"}), ("SR : round-4 points (fp32 uvt, centred head)", NOW | {"sr"}),
+              ("only the weights", {"w", "wlm"}), ("SR every point + weights + mean-row correction", ACT | {"sr", "w", "wlm", "wcm"}),
+              ("SR every point + weights, no correction", ACT | {"sr", "w", "wlm"}),
+              ("RTN fp32 residual stream + weights + mean-row correction (= bf16m)", R32 | {"w", "wlm", "wcm"})]
+if args.groups == "pred":                        # round 5: the mean-row correction of the LayerNorm-fed Linears from the PREDICTED mean row (the reference row)
+    NOW = ACT - {"uvt", "xr"}
+    R32 = NOW - {"h_res", "sa_res", "y1", "y2"}
+    WC = {"w", "wlm", "wcm"}
+    GROUPS = [("only the weights", {"w", "wlm"}), ("weights + measured mean-row correction", WC), ("weights + correction, LN-fed Linears from the reference rows", WC | {"cen", "wcmref"}),
+              ("centred stream + weights + measured correction (= bf16m)", R32 | WC | {"cen"}),
+              ("centred stream + weights + correction from the reference rows", R32 | WC | {"cen", "wcmref"}),
+              ("   ... only q/k/v from the reference rows", R32 | WC | {"cen", "wcmref_qkv"}), ("   ... only FFN lin1", R32 | WC | {"cen", "wcmref_lin1"}),
+              ("   ... only the MLM-head transform", R32 | WC | {"cen", "wcmref_vt"}), ("   ... q/k/v + lin1", R32 | WC | {"cen", "wcmref_qkv", "wcmref_lin1"})]
+if args.groups == "cen":                         # round 5: centred bf16 residual stream (reference rows predicted from the mean input rows)
+    NOW = ACT - {"uvt", "xr"}
+    R32 = NOW - {"h_res", "sa_res", "y1", "y2"}
+    WC = {"w", "wlm", "wcm"}
+    GROUPS = [("RTN: round-4 bf16 activations (fp32 uvt, centred head)", NOW), ("fp32 residual stream (bf16m / bf16w)", R32),
+              ("centred bf16 residual stream", R32 | {"cen"}), ("centred bf16 residual stream, operands from it too", R32 | {"cen", "cenop"}),
+              ("fp32 residual stream + weights + mean-row correction (= bf16m)", R32 | WC),
+              ("centred residual stream + weights + mean-row correction", R32 | WC | {"cen"}),
+              ("centred residual stream incl. operands + weights + correction", R32 | WC | {"cen", "cenop"})]
 done = 0
 for upto in [int(v) for v in args.trajectory.split(",")]:
     bw.train()

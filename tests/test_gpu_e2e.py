@@ -422,7 +422,7 @@ def test_bf16_engines_stay_near_fp32_along_a_training_run():
     kw = dict(config=dict(n_layers=nl, dropout=0.0, attention_dropout=0.0))
     f32, bw, bm, b16 = (dic.DistilBertModel(E, E, dtype=d, **kw) for d in ("fp32", "bf16w", "bf16m", "bf16"))
     assert bw.uvt32 and bw.head_centered and bw.res32 and b16.uvt32 and b16.head_centered and not b16.res32 and not b16.split_w
-    assert bm.lo_mode == "mean" and bm.res32 and bw.lo_mode == "pass2"
+    assert bm.lo_mode == "mean" and bm.cen and not bm.res32 and bw.lo_mode == "pass2" and not bw.cen
     held = [{k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 1 + 7 * i).items()} for i in range(2)]
     train = [{k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, L, V, 100 + i).items()} for i in range(8)]
     draws = [(torch.from_numpy(synth.timesteps(S, 100, i)), [torch.from_numpy(synth.noise((B, L, 768), 3 + i, f"eps{j}")) for j in range(2)]) for i in range(3)]

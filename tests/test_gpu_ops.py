@@ -379,6 +379,107 @@ def test_lo_mean_bias_is_bias_plus_lo_times_the_mean_of_the_sampled_rows(L, T, K
     assert float((out0.cpu().double() - (ref - bias.double())).abs().max()) < 1e-4 * float(corr) + 1e-7
 
 
+@pytest.mark.parametrize("T,K,N,stride,resid", [(17408, 768, 2304, 17, False), (17408, 768, 768, 17, True), (17408, 3072, 768, 17, True), (300, 768, 772, 1, False),
+                                                (1000, 3072, 3072, 7, False), (333, 768, 768, 3, True)])
+def test_lin_prep_mean_row_correction_and_reference_rows(L, T, K, N, stride, resid):
+    """dic_lin_prep (round 5): bias_in = bias + W_lo . abar; for a residual Linear also y_ref = bias + (W_hi + W_lo) . abar + r_ref and
+    bias_post = r_ref - y_ref (folded into bias_in when no dropout sits between).  abar = mean of every stride-th row.  Against float64 on the
+    same bf16 operands; repeated launches on ONE workspace give the same bits, also right behind one another on the stream."""
+    g = torch.Generator().manual_seed(T + K + N)
+    A = torch.randn(T, K, generator=g) * 0.7 + torch.randn(1, K, generator=g) * 0.4
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias, r_ref = torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g)
+    Ad, Wd = dev(A, torch.bfloat16), dev(W)
+    hi, lo = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda"), torch.zeros(N, K, dtype=torch.bfloat16, device="cuda")
+    ok(L.dic_cast_bf16_hl(p(Wd), p(hi), p(lo), N * K, stream()), L)
+    ws = torch.zeros(L.dic_lin_prep_ws_bytes(K) // 4, device="cuda")
+    abar = Ad.float().cpu().double()[::stride].mean(0)
+    s_lo, s_hi = lo.float().cpu().double() @ abar, hi.float().cpu().double() @ abar
+    outs = []
+    for fold in ((0, 1) if resid else (0,)):
+        for rep in range(3):
+            b_in, b_post, y_ref = (torch.full((N + 4,), 7.0, device="cuda") for _ in range(3))
+            ok(L.dic_lin_prep(p(Ad), T, K, stride, K, p(hi) if resid else 0, p(lo), K, N, p(dev(bias)), p(dev(r_ref)) if resid else 0, fold,
+                              p(b_in), p(b_post) if resid else 0, p(y_ref) if resid else 0, p(ws), stream()), L)
+            if rep == 0:
+                torch.cuda.synchronize()
+            outs.append((fold, b_in.clone(), b_post.clone(), y_ref.clone()))
+    torch.cuda.synchronize()
+    scale = float(s_lo.abs().max()) + 1e-9
+    for fold, b_in, b_post, y_ref in outs:
+        assert bool((b_in[N:] == 7.0).all())
+        if resid:
+            yr = bias.double() + s_lo + s_hi + r_ref.double()
+            assert float((y_ref[:N].cpu().double() - yr).abs().max()) < 3e-6 * float(yr.abs().max())
+            assert float((b_post[:N].cpu().double() - (r_ref.double() - yr)).abs().max()) < 3e-6 * float(yr.abs().max())
+            want = bias.double() + s_lo + ((r_ref.double() - yr) if fold else 0)
+            assert float((b_in[:N].cpu().double() - want).abs().max()) < 3e-6 * float(yr.abs().max()) + 1e-4 * scale
+        else:
+            assert float((b_in[:N].cpu().double() - (bias.double() + s_lo)).abs().max()) < 1e-4 * scale + 1e-7
+    for a, b in zip(outs[:3], outs[1:3]):                                     # bit-identical reruns
+        assert all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+
+def test_gemm_second_bias_row_behind_the_dropout(L):
+    """DicGemmParams.bias2: C = dropout(acc + bias) + bias2 + R (bf16 forward AFFINE with dropout and residual) -- same mask as without it."""
+    M, N, K = 600, 768, 320
+    g = torch.Generator().manual_seed(11)
+    A, B = torch.randn(M, K, generator=g) * 0.3, torch.randn(N, K, generator=g) * 0.3
+    bias, b2, Rr = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd, Rd = dev(A, torch.bfloat16), dev(B, torch.bfloat16), dev(Rr, torch.bfloat16)
+    for tile in (128, 256):
+        C0 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        C1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        kw = dict(A=p(Ad), B=p(Bd), M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=p(dev(bias)), R=p(Rd), ldr=N, tile=tile, p_drop=0.2, seed=77)
+        gemm(L, BF16, 0, 0, 0, C=p(C0), **kw)
+        gemm(L, BF16, 0, 0, 0, C=p(C1), bias2=p(dev(b2)), **kw)
+        want = (C0.float().cpu().double() + b2.double())
+        assert float((C1.float().cpu().double() - want).abs().max()) < 2 ** -7 * float(want.abs().max())       # two bf16 roundings apart at most
+    g_ = dic._lib.GemmParams()
+    for k, v in dict(kw, C=p(C1), bias2=p(dev(b2)), p_drop=0.0).items():
+        setattr(g_, k, v)
+    assert L.dic_gemm(BF16, 0, 0, 0, C.byref(g_), stream()) != 0            # without dropout the row belongs into `bias`: refused loudly
+
+
+def test_centred_layernorm_forward_backward(L):
+    """dic_ln_fwd_cen / dic_ln_bwd_cen: LayerNorm of y = y_c + y_ref given as a bf16 remainder and one fp32 reference row; outputs the bf16 operand
+    copy, the remainder of the output against h_ref = LN(y_ref), and h_ref.  With nearly equal rows (a collapsed denoiser) the centred pair
+    carries the row differences that plain bf16 storage of y would round away."""
+    T = 333
+    g = torch.Generator().manual_seed(3)
+    y_ref = torch.randn(768, generator=g) * 1.5 + 0.2
+    gamma, beta = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    dh = torch.randn(T, 768, generator=g)
+    for spread in (1.0, 1e-3):
+        y = y_ref + spread * torch.randn(T, 768, generator=g)
+        y_c = dev(y - y_ref, torch.bfloat16)
+        y_used = (y_c.float().cpu() + y_ref).double().requires_grad_(True)
+        gg, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        ref = R.layer_norm(y_used, gg, bb)
+        href = R.layer_norm(y_ref.double()[None], gamma.double(), beta.double())[0]
+        h, h_c = (torch.zeros(T, 768, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+        h_ref, mean, rstd = torch.zeros(768, device="cuda"), torch.zeros(T, device="cuda"), torch.zeros(T, device="cuda")
+        ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), p(h), p(h_c), p(h_ref), p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+        torch.cuda.synchronize()
+        assert relerr(h_ref, href) < 2e-6
+        assert relerr(h.float(), ref.detach()) < 5e-3
+        rebuilt = h_c.float().cpu().double() + h_ref.cpu().double()
+        dev_scale = float((ref.detach() - href).abs().max())
+        assert float((rebuilt - ref.detach()).abs().max()) < 5e-3 * dev_scale + 1e-6          # error relative to the DISTANCE from the reference row
+        h2 = torch.zeros_like(h)
+        ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), p(h2), 0, 0, p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+        torch.cuda.synchronize()
+        assert torch.equal(h, h2)
+        dhd = dev(dh, torch.bfloat16)
+        ref.backward(dhd.float().cpu().double())
+        dx, dxd = (torch.zeros(T, 768, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+        part = torch.zeros(64, 3 * 768, device="cuda")
+        ok(L.dic_ln_bwd_cen(p(dhd), p(y_c), p(dev(y_ref)), p(dev(gamma)), p(mean), p(rstd), p(dx), 0, 0.0, 0, p(part), 64, T, 768, stream()), L)
+        s = _colsum(L, part, 3 * 768)
+        assert relerr(dx.float(), y_used.grad) < 1e-2
+        assert relerr(s[:768], gg.grad) < 2e-5 and relerr(s[768:1536], bb.grad) < 1e-5
+
+
 def test_ln_and_gelu_ln_with_fp32_inputs_in_the_bf16_engine(L):
     """dic_ln_fwd_r32 / dic_ln_bwd(DIC_BF16 | DIC_RES_F32) and dic_gelu_ln_fwd / _bwd(DIC_BF16 | DIC_U_F32): fp32 y / u in, bf16 operand copy
     (+ fp32 residual copy) out, bf16 gradients -- the statistics and the fp32 outputs to fp32 accuracy, the bf16 outputs to bf16 rounding."""
