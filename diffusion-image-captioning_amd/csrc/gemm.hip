@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         int pi = 0;
         while (pi + 1 < grp->n && tg >= grp->tile0[pi + 1]) ++pi;
         p.A = grp->A[pi]; p.B = grp->B[pi]; p.M = grp->M[pi]; p.N = grp->N[pi]; p.lda = grp->lda[pi]; p.ldb = grp->ldb[pi];
-        p.colsum_out = grp->cs[pi];
+        p.colsum_out = grp->cs[pi]; p.C = grp->Cout[pi];
         stepA = (unsigned)BK * (unsigned)p.lda * 2u; stepB = (unsigned)BK * (unsigned)p.ldb * 2u;
         const int lt = tg - grp->tile0[pi], nbn_ = grp->nbn[pi];
         TileId t_;
@@ -1423,10 +1423,18 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         DIC_STAMP();
         // `cur` is now the stage that holds (or will hold) the next unit's first K-step; the other stage is free.
         bool more = more_next;
+        // grouped launch with ONE K-slice per tile (round 5: the weight gradients of two layers, 216 tiles = one round of 256 workgroups): the
+        // tile is complete, so it goes straight to its dW (and its column sums to db) -- no slab, no fold launch
+        const bool grp_direct = GROUP && grp->split == 1;
         if constexpr (GROUP) {
-            // the unit's partial tile goes to its own slab, in tile-local coordinates (the fold kernel adds a tile's slices up)
-            pe.C = grp->ws + (size_t)slab_done * (G::BM * G::BN + G::BM);
-            pe.ldc = G::BN; pe.M = G::BM; pe.N = G::BN; pe.out_f32 = 1; pe.accumulate = 0; pe.bias = nullptr; pe.R = nullptr; pe.p_drop = 0.f;
+            pe.out_f32 = 1; pe.accumulate = 0; pe.bias = nullptr; pe.R = nullptr; pe.p_drop = 0.f;
+            if (grp_direct) {
+                pe.ldc = pe.N;
+            } else {
+                // the unit's partial tile goes to its own slab, in tile-local coordinates (the fold kernel adds a tile's slices up)
+                pe.C = grp->ws + (size_t)slab_done * (G::BM * G::BN + G::BM);
+                pe.ldc = G::BN; pe.M = G::BM; pe.N = G::BN;
+            }
         } else {
             if (p.split_k > 1) redirect_to_slab(pe, done.kz);
         }
@@ -1453,7 +1461,8 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #pragma unroll
                     for (int gq = 0; gq < CS_GROUPS; ++gq) v += red[gq * G::BM + tid];
                     const int m = done.bm * G::BM + tid;
-                    if constexpr (GROUP) ((float*)pe.C)[G::BM * G::BN + tid] = v;
+                    if (GROUP && !grp_direct) ((float*)pe.C)[G::BM * G::BN + tid] = v;
+                    else if (GROUP) { if (m < pe.M) pe.colsum_out[m] = v; }
                     else if (m < pe.M) {
                         if (pe.split_k > 1) ((float*)pe.C)[(size_t)pe.M * pe.ldc + m] = v;
                         else pe.colsum_out[m] = pe.accumulate ? pe.colsum_out[m] + v : v;
@@ -1462,7 +1471,7 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
                 barrier_lds_only();
             }
         }
-        const int m_first = (GROUP ? 0 : row_base + done.bm * tile_rows) + row0_w, n_first = (GROUP ? 0 : done.bn * G::BN) + wn * G::WCOLS;
+        const int m_first = ((GROUP && !grp_direct) ? 0 : row_base + done.bm * tile_rows) + row0_w, n_first = ((GROUP && !grp_direct) ? 0 : done.bn * G::BN) + wn * G::WCOLS;
         if constexpr (EPI == DIC_EPI_CE_PARTIAL) {
             epilogue_ce_partial<C, CNT>(acc, pe, m_first, n_first, wn, lane, done.bn, done.nbn, issue_next);
         } else {
@@ -1880,13 +1889,18 @@ int plan_wgrad_group(const DicWgradItem* items, int n, int T, int cu_cap, WgradP
     int cus = device_cus();
     if (cu_cap > 0 && cu_cap < cus) cus = cu_cap;
     // K-slices per tile: minimise rounds x (slice length + per-unit fixed cost ~ 8 K-steps: first DMA + a 256 KB partial tile written at ~16 B/clk)
-    double best = 1e30;
+    double best = 1e30, cost1 = 1e30;
     int best_s = 1;
     for (int S = 1; S <= 64 && (S == 1 || d.nk / S >= 8); ++S) {
         const long long units = (long long)tiles * S;
-        const double cost = (double)((units + cus - 1) / cus) * ((d.nk + S - 1) / S + 8.0);
+        // (S = 1 writes no slab and needs no fold: its fixed cost is the epilogue alone, and it wins ties)
+        const double cost = (double)((units + cus - 1) / cus) * ((d.nk + S - 1) / S + (S == 1 ? 2.0 : 8.0));
+        if (S == 1) cost1 = cost;
         if (cost < best - 1e-9) { best = cost; best_s = S; }
     }
+    // what the model does not see: S > 1 writes S x tiles partial tiles and reads them back in a second launch (0.8 GB for 216 tiles x 7 slices
+    // at 48 756 tokens) -- one slice per tile is taken whenever the model puts it within 12 % of the best cut
+    if (best_s > 1 && cost1 <= 1.12 * best) best_s = 1;
     d.split = best_s;
     d.per = (d.nk + best_s - 1) / best_s;
     const long long units = (long long)tiles * best_s;
@@ -1929,7 +1943,7 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
 #endif
     launch_timed(wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
     const int tiles = pl.dev.tiles;
-    launch_timed(wgrad_group_fold_kernel, dim3(tiles, G::BM / 16), dim3(256), 0u, st, pl.dev);
+    if (pl.dev.split > 1) launch_timed(wgrad_group_fold_kernel, dim3(tiles, G::BM / 16), dim3(256), 0u, st, pl.dev);      // (one slice per tile: written in place)
     tl_prof = nullptr;
     DIC_CHECK_LAUNCH();
     return 0;

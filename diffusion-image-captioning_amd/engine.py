@@ -84,7 +84,12 @@ _PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"      # the two Layer
 _HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "1")
 _MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
 _SPLIT_SET = _os.environ.get("DIC_SPLIT_SET", "auto")         # "vo2t" | "all" | "auto": which forward Linears take the lo weight half in the split-weight modes
-_BWD_PARITY = max(2, int(_os.environ.get("DIC_BWD_PARITY", "2")))   # gradient-buffer sets shared by the main and the weight-gradient stream (A/B switch)
+# weight-gradient grouping (Denoiser.backward): "pair" (round 5 default) = the four Linears of TWO layers as one persistent launch, one K-slice per
+# tile (216 tiles on 256 CUs: no split-K slabs, no fold); "1" = two launches + two folds per layer (round 4); "2" = out-proj + qkv only; "0" = none
+_WGRAD_GROUP = _os.environ.get("DIC_WGRAD_GROUP", "pair")
+# gradient-buffer sets shared by the main and the weight-gradient stream: a set is reused once the launch that reads it has finished -- the pair
+# launch goes out a layer later than its first layer's gradients exist, so it needs four sets where the per-layer launches need two
+_BWD_PARITY = max(2, int(_os.environ.get("DIC_BWD_PARITY", "4" if _WGRAD_GROUP == "pair" else "2")))
 _UVT32 = _os.environ.get("DIC_UVT32", "1") != "0"
 # fp32 residual stream (include/dic_hip.h, DIC_RES_F32): "auto" = with the split weights (the parity mode dtype="bf16w"), "1" / "0" force it (A/B)
 _RES32 = _os.environ.get("DIC_RES32", "auto")
@@ -627,25 +632,36 @@ class Denoiser:
         # out-proj + qkv, the two with too few tiles to split well on their own (9 + 27 tiles x 7 slices = one round): 0.5-0.8 % on the step.
         # Round 4 re-measured with the halves (DIC_WGRAD_GROUP_HALVES, below): "1" = [lin2, lin1] as one launch and [out-proj, qkv] as another
         # ties "2" on the two-stream step (13.93 vs 13.93 ms, profiles/r04_wgrad_group_ab.txt) with 24 launches fewer per step -> default "1".
-        gmode = _os.environ.get("DIC_WGRAD_GROUP", "1")       # "0": none; "1": every Linear of the layer (two halves); "2": out-proj + qkv only
-        group = self.bf16 and gmode in ("1", "2")
+        # Round 5, "pair": the split-K slabs (2.4 GB written + re-read per step) and the 25 fold launches go away when ONE launch carries two layers:
+        # 216 tiles of 272 K-steps = one round of the 256 CUs at 84 %, each tile written once, in place (dic_wgrad_group picks one slice per tile).
+        gmode = _WGRAD_GROUP
+        pair = gmode == "pair" and self.bf16 and len(ws["dy"]) >= 4
+        if gmode == "pair" and not pair:
+            gmode = "1"
+        group = self.bf16 and gmode in ("1", "2", "pair")
         items = []
+        open_layers = []                              # pair mode: layers whose weight-gradient items wait for the launch
 
         def flush_group():
             if not items:
                 return
-            arr = (_lib.WgradItem * len(items))(*items)
-            n_items = len(items)
+            cap_ = _WGRAD_CU_CAP if use_side else 0
+            batches = [list(items)]
             items.clear()
+            arr0 = (_lib.WgradItem * len(batches[0]))(*batches[0])
+            if len(batches[0]) > 4 and lib.dic_wgrad_group_ws_bytes(arr0, len(batches[0]), T, cap_) > skcap * 4:
+                batches = [batches[0][:4], batches[0][4:]]        # (a two-layer group whose K cut needs more slab space than the workspace has: one launch per layer)
+            for b_ in batches:
+                arr = (_lib.WgradItem * len(b_))(*b_)
 
-            def launch():
-                _lib.check(lib.dic_wgrad_group(arr, n_items, T, skw, skcap * 4, _WGRAD_CU_CAP if use_side else 0, o.stream), "wgrad_group")
-            on_side(launch)
+                def launch(arr=arr, n_items=len(b_)):
+                    _lib.check(lib.dic_wgrad_group(arr, n_items, T, skw, skcap * 4, cap_, o.stream), "wgrad_group")
+                on_side(launch)
 
         def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
             bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum)."""
-            if group and M % 256 == 0 and N % 8 == 0 and (gmode == "1" or slot.endswith(("Wo", "Wqkv"))):
+            if group and M % 256 == 0 and N % 8 == 0 and (gmode in ("1", "pair") or slot.endswith(("Wo", "Wqkv"))):
                 items.append(_lib.WgradItem(dY=dY, ldy=lda, X=X, ldx=ldb, dW=P.ptr(slot, "G"), db=P.ptr(bias_slot, "G") if bias_slot is not None else 0, M=M, N=N))
                 return
             sk, tile = pick_split_k(M, N, T, 64 if self.bf16 else 32)
@@ -675,21 +691,31 @@ class Denoiser:
             on_side(lambda: _lib.check(lib.dic_colsum_pair(pbuf0, dst0, pbuf1, dst1, NPART, cols, cols, o.stream), "colsum_pair"))
 
         def finish_layer(j):
-            """dW launches of layer j are queued: mark it, and hand the layer's gradient slice to the data-parallel reducer."""
+            """dW launches of layer j are queued: mark it, and hand the layer's gradient slice to the data-parallel reducer.
+            Pair mode: the launch goes out after every second encoder layer (and after the last one); both layers are marked then."""
+            open_layers.append(j)
+            if pair and j < self.n_layers and j > 0 and len(open_layers) < 2:
+                flush_side()                          # (this layer's LayerNorm folds go out now; its weight gradients wait for the next layer's)
+                return
             flush_group()
             flush_side()
+            ev_side = None
             if use_side:
-                done[j] = torch.cuda.Event()
-                done[j].record(side)
-            if layer_done is not None and j < self.n_layers:
+                ev_side = torch.cuda.Event()
+                ev_side.record(side)
+            for jj in open_layers:
                 if use_side:
-                    ev = torch.cuda.Event()
-                    ev.record(main)                   # the LayerNorm / bias gradients of this layer come from the main stream
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        layer_done(j)
-                else:
-                    layer_done(j)
+                    done[jj] = ev_side
+                if layer_done is not None and jj < self.n_layers:
+                    if use_side:
+                        ev = torch.cuda.Event()
+                        ev.record(main)                   # the LayerNorm / bias gradients of this layer come from the main stream
+                        side.wait_event(ev)
+                        with torch.cuda.stream(side):
+                            layer_done(jj)
+                    else:
+                        layer_done(jj)
+            open_layers.clear()
 
         # head: GELU+LN backward, vocab_transform
         nl = self.n_layers
@@ -725,7 +751,7 @@ class Denoiser:
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_MUL_AUX if ws["gelu_d"] else EPI_GELU_BWD,
                    aux=_p(Lw["u"]), ldaux=Hd)
             wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                                # dW1 (+ db1)
-            if _os.environ.get("DIC_WGRAD_GROUP_HALVES", "1") == "1":
+            if not pair and _os.environ.get("DIC_WGRAD_GROUP_HALVES", "1") == "1":
                 flush_group()                         # the two FFN gradients go out now (72 tiles), out-proj + qkv at the end of the layer (36):
             flush_side()                              # one launch per layer starts the side stream too late to hide behind this layer's chain
             o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual

@@ -1207,10 +1207,11 @@ def test_step_prep_randint_zero(L):
     assert bool((z[4:204] == 0).all()) and bool((z[:4] == 3).all()) and bool((z[204:] == 3).all())
 
 
-@pytest.mark.parametrize("T,cu_cap", [(64 * 11 + 5, 0), (64 * 40, 0), (64 * 3 + 7, 0), (64 * 70 + 1, 7)])
+@pytest.mark.parametrize("T,cu_cap", [(64 * 11 + 5, 0), (64 * 40, 0), (64 * 3 + 7, 0), (64 * 70 + 1, 7), (64 * 40, 10), (64 * 11 + 5, 5)])
 def test_wgrad_group_matches_separate_products(L, T, cu_cap):
     """dic_wgrad_group: several dW = dY^T X (+ db = colsum dY) in one split-K launch + fold, against fp64; bit-identical when repeated; a small
-    cu_cap makes every workgroup walk many (slice, tile) units."""
+    cu_cap makes every workgroup walk many (slice, tile) units.  The last two cases (as many CUs as tiles / half as many) take ONE K-slice per
+    tile: written in place, no slab and no fold (round 5: the two-layer weight-gradient launch of the training step)."""
     shapes = [(768, 256, True), (256, 768, False), (512, 264, True)]            # (M, N, with bias gradient)
     g = torch.Generator().manual_seed(T)
     items, keep, refs = [], [], []
