@@ -155,7 +155,8 @@ def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_
     # passes: the one-off CLIP projection and the exact-fp32 rounding head drop out), launch by launch (no graph replay: the per-launch events
     # need real launches)
     Lh = dic.lib()
-    os.environ["DIC_SAMPLE_GRAPH_OFF"] = "1"
+    opt = importlib.import_module("diffusion-image-captioning_amd.options").OPT
+    keep_graph, opt.sample_graph = opt.sample_graph, False
     acc = {}
     for npass in (8, 2):
         Lh.dic_prof_begin(npass * (layers * 6 + 16))
@@ -164,7 +165,7 @@ def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_
         ms, fl, n = C.c_double(), C.c_double(), C.c_int()
         Lh.dic_prof_end(C.byref(ms), C.byref(fl), C.byref(n))
         acc[npass] = (ms.value, fl.value, n.value)
-    os.environ.pop("DIC_SAMPLE_GRAPH_OFF", None)
+    opt.sample_graph = keep_graph
     dms, dfl, dn = (acc[8][k] - acc[2][k] for k in range(3))
     if dms > 0:
         peak = 2500.0 if dtype != "fp32" else 157.3
@@ -172,7 +173,7 @@ def sampling_leg(dic, torch, E, dev, batch, passes, layers, dtype, reps=2, bleu_
         out["roofline"] = {"bound": "mfma", "kernel": "forward GEMMs of one denoising pass (QKV, out-proj, FFN1+GELU, FFN2 per layer + the MLM-head transform)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "gemm_ms_per_pass": round(dms / 6, 3),
                            "launches_per_pass": dn // 6}
-    if dtype == "bf16" and bleu_batch > 0:
+    if dtype in ("bf16", "bf16r") and bleu_batch > 0:
         # BLEU-4 of the bf16 loop's ids against the fp32 loop's ids from the SAME start noise (the fp32 path is the one the -m gpu tests
         # pin bit-exactly to the reference's ids on the golden fixture): how far the bf16 passes drift in token space
         m32 = dic.DistilBertModel(E, E, config=dict(n_layers=layers), dtype="fp32", device=dev)
@@ -243,21 +244,25 @@ def main():
     ap.add_argument("--seq-len", type=int, default=16)
     ap.add_argument("--cfg-weight", type=float, default=0.0, help="classifier-free guidance weight (configs[4]: 0.3 with --seq-len 32)")
     ap.add_argument("--passes", type=int, default=100, help="denoising passes of --mode sample")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16w", "bf16m", "fp32"],
-                    help="bf16 (default): the throughput mode; bf16m: the fast mode inside the 1e-4 loss tolerance (mean-row lo-weight correction, fp32 "
-                         "residual stream) -- reported by the default line as parity_fast_mode, or benchmarked itself with --dtype bf16m (the default line "
-                         "then carries plain bf16 as throughput_mode); bf16w: bf16m's exact form, the lo weight halves as a second K-loop pass")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16r", "bf16w", "bf16m", "fp32"],
+                    help="bf16 (default; 'bf16m' is its older name): the engine inside north_star's 1e-4 loss tolerance -- mean-row lo-weight correction of "
+                         "every forward Linear + centred bf16 residual stream; bf16r: the raw bf16 engine without them (the default line carries it as "
+                         "throughput_mode); bf16w: the default's exact form, the lo weight halves as a second K-loop pass")
+    ap.add_argument("--no-oracle-leg", action="store_true", help="skip loss_rel_vs_cpu_oracle (one forward of the CPU oracle at the bench shape, ~1-2 min)")
     ap.add_argument("--sustained", type=int, default=500, help="steps of the extra sustained leg of the default line (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline + roofline only (no CPU legs, no sampling / seq32 / dtype-delta extras)")
     args = ap.parse_args()
+    if args.dtype == "bf16m":
+        args.dtype = "bf16"
 
     # --gpus N without a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI) exactly as the driver would
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch(args.gpus)
     import torch
     dic = importlib.import_module("diffusion-image-captioning_amd")
+    OPT = importlib.import_module("diffusion-image-captioning_amd.options").OPT
     rank, world, local = dic.parallel.init_from_env()
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}: refusing to report a line for a different GPU count")
@@ -274,7 +279,7 @@ def main():
     E = dic.synth.vocab_embedding(30522, 768, 0)
 
     if args.mode == "sample":
-        line = sampling_leg(dic, torch, E, dev, args.batch or 2048, args.passes, args.layers, "bf16" if args.dtype == "bf16m" else args.dtype, reps=3)
+        line = sampling_leg(dic, torch, E, dev, args.batch or 2048, args.passes, args.layers, args.dtype, reps=3)
         line.update({"n_gpus": world, "steps": args.passes, "warmup": 2, "ms_per_step": line["ms_per_pass"], "higher_is_better": True, "scaling": "weak",
                      "vs_baseline": None, "data": "synthetic",
                      "config": {"workload": f"sample(): {line['batch']} images, {args.passes} x0-prediction passes of the {args.layers}-layer denoiser, "
@@ -337,7 +342,7 @@ def main():
         mine = torch.tensor([B * args.steps / dt_local], device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
-        os.environ["DIC_DP_TIMING"] = "1"
+        OPT.dp_timing = True
         ar_ms, ncoll = [], 0
         for _ in range(3):
             dic.train_func(model, trainer, x)
@@ -347,7 +352,7 @@ def main():
                 if v is not None:
                     ar_ms.append(v)
                 ncoll = red.n_collectives
-        os.environ.pop("DIC_DP_TIMING", None)
+        OPT.dp_timing = False
         barrier()
         try:
             rccl_ver = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -357,8 +362,8 @@ def main():
         torch.distributed.all_gather_object(devs, f"{torch.cuda.current_device()}:{torch.cuda.get_device_properties(torch.cuda.current_device()).name}")
         dp_info = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(), "rccl_version": rccl_ver,
                    "devices_by_rank": devs, "collectives_per_step": ncoll,
-                   "mode": "single all-reduce after the backward (DIC_DP_SINGLE=1)" if os.environ.get("DIC_DP_SINGLE", "0") == "1" else
-                           f"slices of {os.environ.get('DIC_DP_GROUP', '3')} layers issued from the backward + tail",
+                   "mode": "single all-reduce after the backward (options.dp_single)" if OPT.dp_single else
+                           f"slices of {OPT.dp_group} layers issued from the backward + tail",
                    "allreduce_ms_per_step": round(sum(ar_ms) / len(ar_ms), 3) if ar_ms else None,
                    "allreduce_note": "sum over the step's collectives of issue -> completion on the compute stream, rank 0 (they overlap the backward)",
                    "gradient_bytes": int(model.params.numel) * 4, "per_rank_captions_per_s": [round(float(v), 1) for v in allr]}
@@ -375,8 +380,13 @@ def main():
                     step()
                 torch.cuda.synchronize()
                 ds = time.perf_counter() - c0
+            pw_ = ps.summary()
             sustained = {"steps": args.sustained, "value": round(B * args.sustained / ds, 1), "unit": "captions/s", "ms_per_step": round(ds / args.sustained * 1e3, 3),
-                         "seconds": round(ds, 2), "power": ps.summary()}
+                         "seconds": round(ds, 2), "power": pw_}
+            if pw_ and pw_.get("socket_power_w_mean"):
+                # energy of one step = mean socket power x step time (what a faster-but-denser kernel has to beat when the package is power-limited)
+                sustained["joules_per_step"] = round(pw_["socket_power_w_mean"] * ds / args.sustained, 2)
+                sustained["captions_per_joule"] = round(B / sustained["joules_per_step"], 1)
         except Exception as e:                    # an extra leg never takes the headline line down with it
             leg_errors['sustained'] = f"{type(e).__name__}: {e}"[:400]
 
@@ -413,7 +423,7 @@ def main():
                 roof["whole_step_traffic_gb"] = round(pj["step_fetch_gb_x2"] + pj["step_write_gb"], 2)
             if args.dtype == "bf16w":
                 roof["note"] = "executed flops: the forward Linears run their K loop twice (hi + lo weight halves); algorithmic flops per step are those of the bf16 line"
-            if args.dtype in ("bf16", "bf16m") and w == 0.0:
+            if args.dtype in ("bf16", "bf16r") and w == 0.0:
                 if model.ce_fused:
                     roof["logits_recompute"] = "none: the training forward of the rounding loss keeps exp(logit - c) (dic_gemm CE_EXP), every GEMM flop counted is algorithmic"
                 else:
@@ -430,8 +440,8 @@ def main():
     dtype_delta = sampling = seq32 = None
     parity_fast = None
     throughput_mode = None
-    if extras and args.dtype in ("bf16", "bf16m"):
-        alt = "bf16" if args.dtype == "bf16m" else "bf16m"        # the other of the two: plain bf16 (fastest, outside the tolerance) / bf16m (the parity mode)
+    if extras and args.dtype in ("bf16", "bf16r"):
+        alt = "bf16r" if args.dtype == "bf16" else "bf16"         # the other of the two: the raw bf16 engine (fastest, outside the tolerance) / the default (parity) engine
         try:
             # The same eval step (same t, same noise, dropout off) in the fp32 engine (the parity dtype: within 1e-4 of the CPU reference, tests/), the
             # benchmarked bf16 engine and the parity mode "bf16m" -- at the INITIAL weights (the comparison the -m gpu tests make against the oracle)
@@ -469,14 +479,15 @@ def main():
             dtype_delta["note"] = ("the benchmarked mode against the fp32 HIP engine (itself within 1e-4 of the CPU oracle at this shape, tests/); first four keys: at "
                                    "the initial weights.  What separates the PLAIN bf16 engine from fp32 there is the bf16 rounding of the WEIGHTS: one perturbation "
                                    "shared by every sample, whose first-order effect a batch-mean loss does not average out (profiles/r04_weight_rounding_probe.txt); "
-                                   + ("parity_fast_mode (bf16m) adds its row-common part back (dic_lo_mean_bias) and keeps the residual stream in fp32"
-                                      if args.dtype == "bf16" else "this mode adds its row-common part back (dic_lo_mean_bias); throughput_mode is the plain engine"))
+                                   + ("the benchmarked (default) engine adds its row-common part back (dic_lin_prep) and stores the residual stream centred on predicted "
+                                      "mean rows; throughput_mode is the raw engine without either" if args.dtype == "bf16" else
+                                      "this is the RAW engine; parity_fast_mode is the default engine, which adds the row-common part back (dic_lin_prep)"))
             # ALONG A TRAINING RUN (8 cycled synthetic batches, a fresh split-weight model trains; the three engines evaluate a held-out batch on its
             # weights at a few states): between the first and some hundreds of steps the denoiser's rows are nearly equal, and bf16 roundings of
             # row-common quantities no longer average out of a batch mean -- tests/test_gpu_e2e.py::test_bf16_engines_stay_near_fp32_along_a_training_run
             along, x_keep = None, x
             try:
-                mt = mk("bf16m")
+                mt = mk("bf16")
                 mt.load_state_dict(init)
                 trt = dic.AdamW(mt.parameters(), lr=1e-4)
                 tb = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=100 + i).items()} for i in range(8)]
@@ -515,13 +526,13 @@ def main():
                 ow = dic.train_func(mw, trw, x)
             torch.cuda.synchronize()
             dw = (time.perf_counter() - c0) / nw
-            desc = {"bf16m": "bf16m: bf16 MFMA operands / gradients; the lo halves of the fp32 master weights enter every forward Linear through their row-common "
-                             "part only (mean row of the Linear's input x lo half, added to the bias: dic_lo_mean_bias -- the part of the weights' rounding a "
-                             "batch-mean loss does not average out), fp32 residual stream (pre-LayerNorm sums + residual reads), fp32 MLM-head pre-activation, "
-                             "mean-centred rounding-head input, fp32 master weights and optimizer.  dtype='bf16w' (the lo halves as a second K-loop pass, "
-                             "8-9 % slower) gives the same distances",
-                    "bf16": "bf16: plain bf16 weights and activations (fp32 MLM-head pre-activation, mean-centred rounding-head input), fp32 master weights and "
-                            "optimizer: the fastest mode, outside north_star's 1e-4 at the initial weights"}
+            desc = {"bf16": "bf16 (the default engine): bf16 MFMA operands / gradients; the lo halves of the fp32 master weights enter the forward Linears through "
+                            "their row-common part only (mean row of the Linear's input x lo half, added to the bias: dic_lin_prep -- the part of the weights' "
+                            "rounding a batch-mean loss does not average out; FFN lin1 left out), residual stream stored as bf16(value - predicted mean row) "
+                            "(dic_ln_fwd_cen), fp32 MLM-head pre-activation, mean-centred rounding-head input, fp32 master weights and optimizer.  "
+                            "dtype='bf16w' (the lo halves as a second K-loop pass + fp32 residual stream, ~25 % slower) gives the same distances",
+                    "bf16r": "bf16r: raw bf16 weights and activations (fp32 MLM-head pre-activation, mean-centred rounding-head input), fp32 master weights and "
+                             "optimizer: the fastest mode, outside north_star's 1e-4 at the initial weights (what rounds 1-4 benchmarked)"}
 
             def block(name, value_, ms_, steps_, loss_):
                 b_ = {"dtype": desc[name], "value": round(value_, 1), "unit": "captions/s", "ms_per_step": round(ms_, 3), "steps": steps_, "loss": round(loss_, 4),
@@ -530,8 +541,8 @@ def main():
                     b_["loss_rel_vs_fp32_along_training_8_cycled_batches_held_out_eval"] = {k: v[name] for k, v in along.items()}
                 return b_
             alt_block = block(alt, B / dw, dw * 1e3, nw, float(ow[0]))
-            if args.dtype == "bf16m":             # the benchmarked mode IS the parity mode: its block repeats the headline's numbers next to its loss distances
-                parity_fast = block("bf16m", value, dt / args.steps * 1e3, args.steps, loss_val)
+            if args.dtype == "bf16":              # the benchmarked mode IS the parity mode: its block repeats the headline's numbers next to its loss distances
+                parity_fast = block("bf16", value, dt / args.steps * 1e3, args.steps, loss_val)
                 parity_fast["is_the_benchmarked_mode"] = True
                 throughput_mode = alt_block
             else:
@@ -541,7 +552,7 @@ def main():
         except Exception as e:                    # an extra leg never takes the headline line down with it
             leg_errors['dtype_deltas_parity_fast_mode'] = f"{type(e).__name__}: {e}"[:400]
     fp32_mode = None
-    if extras and args.dtype in ("bf16", "bf16m"):
+    if extras and args.dtype in ("bf16", "bf16r"):
         try:
             # the parity dtype's throughput on the same workload (fp32 MFMA peak is 1/16 of bf16's): a few steps are enough
             m32 = dic.DistilBertModel(E, E, config=dict(n_layers=args.layers, dropout=0.1, attention_dropout=0.1), dtype="fp32", device=dev, seed=0)
@@ -568,7 +579,7 @@ def main():
     if extras:
         try:
             # (sampling in the plain bf16 engine: its token ids already equal the oracle's, and the forward-only passes have nothing to average over)
-            sampling = sampling_leg(dic, torch, E, dev, 2048, 100, args.layers, "bf16" if args.dtype == "bf16m" else args.dtype)
+            sampling = sampling_leg(dic, torch, E, dev, 2048, 100, args.layers, args.dtype)
             if (L, w) == (16, 0.0):
                 # configs[4] on one GPU: seq_len 32 (+2 CLIP rows = 34 tokens: the 2x2-tile MFMA attention) with classifier-free guidance
                 configure(32, 0.3)
@@ -593,6 +604,62 @@ def main():
         except Exception as e:                    # an extra leg never takes the headline line down with it
             leg_errors['sampling_seq32'] = f"{type(e).__name__}: {e}"[:400]
 
+    # ---- the benchmarked dtype against the CPU ORACLE at the bench shape (forward only: one evaluation of oracle/ref_model.py on the host cores -- the
+    # checker, outside every timed region), and the reference's own default shape (SAMPLE_SIZE 100, batch 8, 6 layers) on the GPU
+    oracle_rel = ref_faithful = None
+    if extras and not args.no_oracle_leg and args.dtype != "fp32" and (L, w, S) == (16, 0.0, 1):
+        try:
+            from oracle import ref_model as R
+            st0 = dic.synth.denoiser_state(args.layers, 0)
+            xb0 = dic.synth.batch(B, L, 30522, 1)
+            t0_ = torch.from_numpy(dic.synth.timesteps(S, 100, 0))
+            nz0 = [torch.from_numpy(dic.synth.noise((B, L, 768), 3, f"eps{i}")) for i in range(2)]
+            c0 = time.perf_counter()
+            om = R.build(R.Config(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, n_layers=args.layers, vocab=30522), st0, E,
+                         requires_grad=False)
+            with torch.no_grad():
+                oref = [float(v) for v in R.train_func(om, None, {k: torch.from_numpy(v) for k, v in xb0.items()}, train=False, t=t0_, noises=nz0)]
+            osec = time.perf_counter() - c0
+            del om
+            mo = dic.DistilBertModel(E, E, config=dict(n_layers=args.layers, dropout=0.0, attention_dropout=0.0), dtype=args.dtype, device=dev, seed=0)
+            mo.load_state(st0)
+            mo.eval()
+            with torch.no_grad():
+                og = [float(v) for v in dic.train_func(mo, None, {k: torch.from_numpy(v).to(dev) for k, v in xb0.items()}, train=False, t=t0_, noises=nz0)]
+            oracle_rel = {k: round(abs(a_ - b_) / abs(b_), 8) for k, a_, b_ in zip(("total", "x_t", "x_1", "prob"), og, oref)}
+            oracle_rel.update({"mode": args.dtype, "tolerance": 1e-4, "oracle_losses": [round(v, 5) for v in oref], "oracle_seconds": round(osec, 1),
+                               "what": f"eval step (dropout off) of the benchmarked engine at the bench shape (B={B}, S={S}, {args.layers} layers, synthetic weights) against "
+                                       "oracle/ref_model.py on the host cores, same batch / timesteps / noise"})
+            del mo
+            torch.cuda.empty_cache()
+        except Exception as e:                    # an extra leg never takes the headline line down with it
+            leg_errors['loss_rel_vs_cpu_oracle'] = f"{type(e).__name__}: {e}"[:400]
+    if extras and (L, w, S, args.layers) == (16, 0.0, 1, 12):
+        try:
+            dic.cfg.update(BATCH_SIZE=8, SAMPLE_SIZE=100)
+            mr = dic.DistilBertModel(E, E, config=dict(n_layers=6, dropout=0.1, attention_dropout=0.1), dtype=args.dtype, device=dev, seed=0)
+            trr = dic.AdamW(mr.parameters(), lr=1e-4)
+            xr = {k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(8, L, 30522, seed=1).items()}
+            for _ in range(3):
+                dic.train_func(mr, trr, xr)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            nr = 10
+            for _ in range(nr):
+                orr = dic.train_func(mr, trr, xr)
+            torch.cuda.synchronize()
+            dr = (time.perf_counter() - c0) / nr
+            ref_faithful = {"value": round(8 / dr, 1), "unit": "captions/s", "ms_per_step": round(dr * 1e3, 3), "steps": nr, "loss": round(float(orr[0]), 4),
+                            "sequences_per_step": "100 x 8 x_t + 8 x_1", "dtype": args.dtype,
+                            "what": "the reference's own defaults (CLIP-DDPM.py:55-119: SAMPLE_SIZE 100, batch 8, DistilBertConfig() = 6 layers); cpu_baseline_config1 "
+                                    "is the CPU port at this shape"}
+            del mr, trr
+            torch.cuda.empty_cache()
+        except Exception as e:
+            leg_errors['reference_faithful'] = f"{type(e).__name__}: {e}"[:400]
+        finally:
+            configure(L, w)
+
     # ---- CPU baseline: the oracle (a port of the reference step) on this host's cores, bounded sample, rank 0 at N=1 only
     cpu = cpu1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.quick:
@@ -609,7 +676,7 @@ def main():
             "metric": "training captions/sec (seq16, bert-base)" if L == 16 else f"training captions/sec (seq{L}, bert-base)", "value": round(value, 2),
             "unit": "captions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype in ("bf16m", "bf16w") else args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype in ("bf16r", "bf16w") else args.dtype, "data": "synthetic",
             "config": {"workload": f"train_func: B={B}/GPU x S={S} (+x_1 pass) = {(S + 1) * B} sequences x {L}+2 tokens (an unguided text row is "
                                    f"skipped), {args.layers}-layer DistilBERT-width denoiser, concat fusion, linear beta T=100, dropout 0.1, AdamW{guided}",
                        "precision_mode": args.dtype, "global_batch": world * B, "seq_len": L, "sample_size": S, "n_layers": args.layers,
@@ -619,6 +686,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, "sustained": sustained, "bf16_vs_fp32_loss_rel": dtype_delta,
             "parity_fast_mode": parity_fast, "throughput_mode": throughput_mode, "fp32_mode": fp32_mode,
             "sampling": sampling, "seq32_cfg": seq32, "data_parallel": dp_info,
+            "loss_rel_vs_cpu_oracle": oracle_rel, "reference_faithful_S100_B8_6layer": ref_faithful,
+            # every switch that differs from the shipped configuration (diffusion-image-captioning_amd/options.py); {} = the configuration the tests assert
+            "options_non_default": OPT.non_default(),
         }
         if leg_errors:
             line["leg_errors"] = leg_errors      # an extra leg that raised: its object above is null, the headline value is unaffected

@@ -27,7 +27,7 @@ EXPORTS = [
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
     "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep", "dic_step_ctx_set", "dic_step_advance",
-    "dic_lin_prep", "dic_lin_prep_ws_bytes", "dic_ln_fwd_cen", "dic_ln_bwd_cen",
+    "dic_lin_prep", "dic_lin_prep_ws_bytes", "dic_ln_fwd_cen", "dic_ln_bwd_cen", "dic_set_option",
 ]
 
 
@@ -176,12 +176,15 @@ def lib():
         L.dic_cast_bf16_hl.argtypes = [P, P, P, I64, P]
         L.dic_probe_tr16.argtypes = [P, P, P]
         L.dic_gemm_set_variant.argtypes = [I]
+        L.dic_set_option.argtypes = [C.c_char_p, I]
         L.dic_gemm_set_w4a.argtypes = [I]
         L.dic_prof_begin.argtypes = [I]
         L.dic_prof_algorithmic_bytes.restype = C.c_double
         L.dic_prof_algorithmic_bytes.argtypes = []
         L.dic_prof_get.argtypes = [I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.dic_prof_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        from . import options
+        options.push_to_library(L)          # the library reads no environment: its process-global switches come from the one record
         _lib = L
     return _lib
 

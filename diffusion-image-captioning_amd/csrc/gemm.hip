@@ -20,6 +20,7 @@
 //         fmaf chain), which is what lets the rounding head reproduce the oracle's token ids bit-for-bit.
 // The MFMA is issued with operands swapped (D = Bfrag x Afrag) so that each lane ends up holding 4
 // CONSECUTIVE n for one m: epilogue loads/stores are 8-byte (bf16) or 16-byte (f32) vectors.
+#include <cstring>
 #include "common.h"
 #include "../../include/dic_hip.h"
 #include <stdlib.h>
@@ -1515,11 +1516,8 @@ __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmP
 // compiled only into measurement builds (-DDIC_GEMM_VARIANTS, scripts/gemm_pp_check.py): the shipped library carries ONE K loop.
 #ifdef DIC_GEMM_VARIANTS
 #include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (variant 1)
-int g_pp = -1;
-int gemm_variant() {
-    if (g_pp < 0) { const char* e = getenv("DIC_GEMM_PP"); g_pp = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
-    return g_pp;
-}
+int g_pp = 0;
+int gemm_variant() { return g_pp; }
 #include "gemm_w4.h"          // gemm_w4_kernel: 256 x 256 tiles on four waves (variant 2, k-contiguous operands only)
 #else
 int g_pp = 0;
@@ -1596,12 +1594,11 @@ void launch_timed(F kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t st,
     }
 }
 
-// DIC_GEMM=1 runs bf16 on the register-staged v1 kernel (kept for within-run A/B measurements); default = LDS-DMA kernel.
-bool bf16_on_v1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DIC_GEMM"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+// Process-global measurement switches (dic_set_option; the library reads NO environment variable -- the one record of every switch is
+// diffusion-image-captioning_amd/options.py, which pushes its values through dic_set_option when the library is loaded).
+// gemm_v1 = 1 runs bf16 on the register-staged v1 kernel (kept for within-run A/B measurements); default = LDS-DMA kernel.
+int g_gemm_v1 = 0, g_persist = 1, g_rows = 1;
+bool bf16_on_v1() { return g_gemm_v1 == 1; }
 
 int device_cus() {
     static int cus = -1;
@@ -1612,17 +1609,8 @@ int device_cus() {
     }
     return cus;
 }
-bool persist_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DIC_GEMM_PERSIST"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
-
-bool rows_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DIC_GEMM_ROWS"); v = (e && e[0] == '0') ? 0 : 1; }       // 0: always full-height tiles (A/B measurements)
-    return v == 1;
-}
+bool persist_enabled() { return g_persist == 1; }
+bool rows_enabled() { return g_rows == 1; }          // 0: always full-height tiles (A/B measurements)
 
 #include "gemm_w4a.h"         // gemm_w4a_kernel: the hand-scheduled four-wave kernel (round 4; DIC_GEMM_W4A)
 
@@ -1696,11 +1684,8 @@ void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
 // unchanged, a sampling pass 7.56 -> 7.47 ms -- but the TRAINING step gets 0.8 % slower (13.78 -> 13.91 ms): there the CUs a partial round leaves
 // idle are not idle, they run the weight-gradient stream's kernels.
 struct TwoHeights { int cA = 0, cB = 0, row_split = 0; };
-int g_two_heights = -1;
-bool two_heights_enabled() {
-    if (g_two_heights < 0) { const char* e = getenv("DIC_GEMM_TWO_HEIGHTS"); g_two_heights = (e && e[0] == '1') ? 1 : 0; }
-    return g_two_heights == 1;
-}
+int g_two_heights = 0;
+bool two_heights_enabled() { return g_two_heights == 1; }
 TwoHeights plan_two_heights(int M, int nbn, int slots, int K, int rows_single, bool ignore_switch = false) {
     TwoHeights best;
     if ((!ignore_switch && !two_heights_enabled()) || !rows_enabled() || nbn > slots) return best;
@@ -1959,6 +1944,18 @@ extern "C" int dic_gemm_set_variant(int v) {
     dic_set_error("dic_gemm_set_variant: this library was built without -DDIC_GEMM_VARIANTS (the alternative K loops are measurement-build only)");
     return 1006;
 #endif
+}
+// One setter for every process-global switch of the library (include/dic_hip.h lists the names); returns 0, or 1007 for an unknown name.
+extern "C" int dic_set_option(const char* name, int value) {
+    if (!name) { dic_set_error("dic_set_option: name is NULL"); return 1007; }
+    if (!strcmp(name, "gemm_v1")) g_gemm_v1 = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_persist")) g_persist = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_rows")) g_rows = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_two_heights")) g_two_heights = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_w4a")) g_w4a = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_variant")) return dic_gemm_set_variant(value);
+    else { dic_set_error("dic_set_option: unknown option"); return 1007; }
+    return 0;
 }
 // process-global measurement / test switch: 1 = eligible forward GEMMs run on the hand-scheduled four-wave kernel (gemm_w4a.h).  Returns the previous value.
 extern "C" int dic_gemm_set_w4a(int on) {

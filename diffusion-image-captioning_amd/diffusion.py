@@ -449,9 +449,7 @@ def loss(model: Denoiser, x_t, x_1, x_tgt, x_0, image_clip, text_clip, mask, idx
     return out[0], out[1], prob
 
 
-import os as _os
-
-_STREAMED_ADAMW = _os.environ.get("DIC_STREAMED_ADAMW", "1") == "1"      # A/B switch for measurements
+from .options import OPT
 
 
 # ------------------------------------------------------------------ AdamW (ref :335)
@@ -583,7 +581,7 @@ def train_func(model: Denoiser, trainer, x, train=True, *, t=None, noises=None, 
             raise RuntimeError("train_func(train=True) called under torch.no_grad()")
         reducer = parallel.GradReducer(model)
         layer_done = reducer.layer_done if reducer.active else None
-        if layer_done is None and isinstance(trainer, AdamW) and _STREAMED_ADAMW:
+        if layer_done is None and isinstance(trainer, AdamW) and OPT.streamed_adamw:
             store = model.params
             trainer.begin_step()
 
@@ -628,7 +626,6 @@ def validate(model: Denoiser, val_loader=None):
 
 
 # ------------------------------------------------------------------ sampling loop (ref :611-621, COCO_BLEU.py:249-256)
-_SAMPLE_GRAPH = _os.environ.get("DIC_SAMPLE_GRAPH", "1") == "1"      # replay passes 3..K of a sampling loop as one hipGraph (A/B switch)
 
 
 @torch.no_grad()
@@ -676,12 +673,12 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
     # a forward-only pass is one stream of kernels: its GEMMs may finish their last round with shorter tiles (include/dic_hip.h,
     # dic_gemm_set_two_heights; 7.56 -> 7.47 ms per pass at B = 2048 -- the training step keeps the switch off)
     lib = _lib.lib()
-    prev_two = lib.dic_gemm_set_two_heights(0 if _os.environ.get("DIC_GEMM_TWO_HEIGHTS") == "0" else 1)
+    prev_two = lib.dic_gemm_set_two_heights(1 if (OPT.sample_two_heights or OPT.gemm_two_heights) else 0)
     # ... and its k-contiguous GEMMs without dropout (QKV, out-proj + residual, FFN-2 + residual, the MLM-head transform) run on the hand-scheduled
     # four-wave kernel where their shape allows (include/dic_hip.h, dic_gemm_set_w4a: token count a multiple of 256): 8.06 -> 7.90 ms per pass at
     # B = 2048 (profiles/r04_sampling_w4a_ab.txt).  The training step keeps it off: at the 1400 W package limit its denser MFMA stream is paid back
     # in clock (profiles/r04_power_probe.txt)
-    prev_w4a = lib.dic_gemm_set_w4a(0 if _os.environ.get("DIC_GEMM_W4A") == "0" else 1)
+    prev_w4a = lib.dic_gemm_set_w4a(1 if (OPT.sample_w4a or OPT.gemm_w4a) else 0)
     try:
         for k in range(steps):
             if graph is not None:
@@ -689,8 +686,11 @@ def sample(model: Denoiser, image_clip, steps=5, *, start=None, return_hidden=Fa
                 continue
             if k >= 1:
                 x_view = (x_out.data_ptr(), Tk * 768, B, L)
-            run = lambda: model.encode(None, None, None, None, drop_txt=drop_txt, x_view=x_view, inputs_ready=k > 0, tidx=t_first if k == 0 else t_later)
-            if _SAMPLE_GRAPH and no_dropout and k == 2 and steps >= 8 and not _os.environ.get("DIC_SAMPLE_GRAPH_OFF"):
+            # (raw: the passes run without the parity mode's mean-row corrections -- a sampling pass feeds a per-row argmax, there is no batch mean
+            # whose row-common roundings would need protecting, and the 37 small launches per pass would cost 5 %; options.sample_raw)
+            run = lambda: model.encode(None, None, None, None, drop_txt=drop_txt, x_view=x_view, inputs_ready=k > 0, tidx=t_first if k == 0 else t_later,
+                                       raw=OPT.sample_raw)
+            if OPT.sample_graph and no_dropout and k == 2 and steps >= 8:
                 seed_before = model._seed
                 try:
                     graph = torch.cuda.CUDAGraph()

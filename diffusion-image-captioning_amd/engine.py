@@ -22,9 +22,10 @@ from ._lib import (DIC_BF16, DIC_F32, EPI_AFFINE, EPI_BIAS_GELU, EPI_BIAS_GELU_D
 from .config import LOSS_KINDS, cfg
 from .params import ParamStore
 
+from .options import OPT
+
 LN_EPS = 1e-12
-import os as _os0
-NPART = int(_os0.environ.get("DIC_LN_NPART", "512"))          # persistent blocks (= partial rows) of the LayerNorm backward kernels (2 per CU; A/B switch)
+NPART = OPT.ln_npart          # persistent blocks (= partial rows) of the LayerNorm backward kernels (2 per CU)
 
 
 def _p(t):
@@ -65,49 +66,20 @@ class Ops:
 
 
 import math
-import os as _os
 
-_TILE_MODE = _os.environ.get("DIC_GEMM_TILE", "auto")      # "128" | "256" | "auto" (A/B switch for measurements)
-_WGRAD_CU_CAP = int(_os.environ.get("DIC_WGRAD_CU_CAP", "0"))   # >0: weight-gradient GEMMs keep to this many CUs (A/B switch)
-_WGRAD_TILE = _os.environ.get("DIC_WGRAD_TILE", "auto")    # tile of the weight-gradient GEMMs (A/B switch)
-_V1_BF16 = _os.environ.get("DIC_GEMM", "") == "1"           # bf16 on the register-staged v1 kernel (128-tiles only)
-_WGRAD_MAX_SPLIT = int(_os.environ.get("DIC_WGRAD_MAX_SPLIT", "32"))     # cap of the weight-gradient GEMMs' split-K factor (A/B switch)
-_GELU_FWD_TILE = _os.environ.get("DIC_GELU_FWD_TILE", "256")   # tile of the bias+GELU forward GEMM (A/B switch)
-_GELU_BWD_TILE = _os.environ.get("DIC_GELU_BWD_TILE", "128")   # tile of the GELU' input-gradient GEMM (A/B switch; 128 measured faster in rounds 2 and 3)
-# bf16 engine: FFN-1's forward epilogue leaves gelu'(u) behind instead of u (same bytes), so the backward's epilogue is one multiply (MUL_AUX)
-# instead of erf + exp per element (round-3 review item 3; "0": the round-3 form, kept as the A/B partner and for the fp32 engine)
-_GELU_D = _os.environ.get("DIC_GELU_D", "1") != "0"
-_PAIR_FOLDS = _os.environ.get("DIC_PAIR_FOLDS", "1") != "0"      # the two LayerNorm-gradient folds of a layer in one launch (A/B switch)
-# mean-centred rounding-head input (Denoiser.center_head_input): on in both bf16 engines (4 small launches, ~0.1 ms of a 14 ms step: without it
-# the rounding loss of a collapsed denoiser -- the first hundreds of training steps -- is 1.5-2.5e-4 off, profiles/r04_collapse_probe.txt
-# "only xr"); "0" switches it off, "w" keeps it to the split-weight mode as before (A/B switches)
-_HEAD_CENTER = _os.environ.get("DIC_HEAD_CENTER", "1")
-_MUL_AUX_TILE = _os.environ.get("DIC_MUL_AUX_TILE", "256")     # tile of that multiply-epilogue GEMM (A/B switch)
-_SPLIT_SET = _os.environ.get("DIC_SPLIT_SET", "auto")         # "vo2t" | "all" | "auto": which forward Linears take the lo weight half in the split-weight modes
-# weight-gradient grouping (Denoiser.backward): "pair" (round 5 default) = the four Linears of TWO layers as one persistent launch, one K-slice per
-# tile (216 tiles on 256 CUs: no split-K slabs, no fold); "1" = two launches + two folds per layer (round 4); "2" = out-proj + qkv only; "0" = none
-_WGRAD_GROUP = _os.environ.get("DIC_WGRAD_GROUP", "pair")
-# gradient-buffer sets shared by the main and the weight-gradient stream: a set is reused once the launch that reads it has finished -- the pair
-# launch goes out a layer later than its first layer's gradients exist, so it needs four sets where the per-layer launches need two
-_BWD_PARITY = max(2, int(_os.environ.get("DIC_BWD_PARITY", "4" if _WGRAD_GROUP == "pair" else "2")))
-_UVT32 = _os.environ.get("DIC_UVT32", "1") != "0"
-# fp32 residual stream (include/dic_hip.h, DIC_RES_F32): "auto" = with the split weights (the parity mode dtype="bf16w"), "1" / "0" force it (A/B)
-_RES32 = _os.environ.get("DIC_RES32", "auto")
+# Every switch lives in options.py (one record, shipped values = its defaults); what remains here are names for the hot ones.
 DIC_U_F32, DIC_RES_F32, OUT_F32_RES_F32 = 0x100, 0x200, 3
-_CEN = _os.environ.get("DIC_CEN", "1") != "0"              # bf16m: centred bf16 residual stream + one-launch dic_lin_prep ("0": round 4's fp32 residual stream + dic_lo_mean_bias; A/B)
-_CE_FUSED = _os.environ.get("DIC_CE_FUSED", "1") != "0"     # rounding loss: training forward keeps exp(logit - c), no logits recompute (A/B switch)
 N_CU = 256
 
 
 def choose_tile(M, N, split_k=1, epi=EPI_AFFINE):
     """256x256 workgroup tiles (8 waves, one workgroup per CU) pull half the bytes per flop through L2 of the 128x128 ones
     (measured: 1.16-1.26 vs 0.83-0.95 PFLOP/s on large squares), but there are 4x fewer of them and their epilogue is not hidden
-    behind a second resident workgroup: use them when they still give every CU work.  The GELU' epilogue (one extra 113 MB
-    input) measured faster on 128-tiles (145 vs 154 us); bias+GELU (two 113 MB outputs) on 256-tiles (136 vs 162 us)."""
-    if _TILE_MODE in ("128", "256"):
-        return int(_TILE_MODE) if (M >= 256 and N >= 256) else 128
-    if (M < 256 or N < 256 or (epi == EPI_GELU_BWD and _GELU_BWD_TILE != "256") or (epi == EPI_MUL_AUX and _MUL_AUX_TILE != "256") or
-            (epi in (EPI_BIAS_GELU, EPI_BIAS_GELU_D) and _GELU_FWD_TILE == "128")):
+    behind a second resident workgroup: use them when they still give every CU work.  The GELU' epilogue of the fp32 engine (one extra
+    113 MB input) measured faster on 128-tiles (145 vs 154 us); bias+GELU (two 113 MB outputs) and the multiply epilogue on 256-tiles."""
+    if OPT.gemm_tile in ("128", "256"):
+        return int(OPT.gemm_tile) if (M >= 256 and N >= 256) else 128
+    if M < 256 or N < 256 or epi == EPI_GELU_BWD:
         return 128
     units = ((M + 255) // 256) * ((N + 255) // 256) * max(split_k, 1)
     return 256 if units >= int(0.75 * N_CU) else 128
@@ -119,14 +91,12 @@ def pick_split_k(M, N, K, bk=64, max_split=32):
     Measured at K = 18432: 768x768 -> 128-tiles x14 (468 TF) beats 256-tiles x28 (404); 3072x768 -> 256-tiles x7 (836 TF)
     beats 128-tiles x3 (781); 2304x768 -> 256-tiles x9 (736) ~ 128-tiles x4 (731).  Returns (split_k, tile)."""
     nk = (K + bk - 1) // bk
-    big = _TILE_MODE != "128" and M % 256 == 0 and N >= 256 and M * N >= 2304 * 768
-    if _TILE_MODE == "256" and M % 256 == 0 and N >= 256:
+    big = OPT.gemm_tile != "128" and M % 256 == 0 and N >= 256 and M * N >= 2304 * 768
+    if OPT.gemm_tile == "256" and M % 256 == 0 and N >= 256:
         big = True
-    if _WGRAD_TILE in ("128", "256"):
-        big = _WGRAD_TILE == "256" and M % 256 == 0 and N >= 256
     tile, resident = (256, N_CU) if big else (128, 2 * N_CU)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
-    return max(1, min(max_split, _WGRAD_MAX_SPLIT, resident // max(tiles, 1), nk // 8)), tile
+    return max(1, min(max_split, resident // max(tiles, 1), nk // 8)), tile
 
 
 class Denoiser:
@@ -135,15 +105,22 @@ class Denoiser:
     embedding / projection: objects with `.weight` ([V,768]; nn.Embedding / nn.Linear work) or raw arrays/tensors.
     The projection bias is zeroed as ref :247 does.  `config` may be a HF DistilBertConfig-like object or a dict with
     `n_layers`, `dropout`, `attention_dropout`.
-    dtype (keyword-only; the reference is fp32): "fp32" exact-fp32 MFMA GEMMs (token ids identical to the CPU reference's); "bf16" bf16 MFMA
-    operands, the fastest; "bf16m" the same arithmetic minus the roundings a batch-mean loss does not average out (mean-row lo-weight
-    correction per Linear, fp32 residual stream): every loss term within 1e-4 of fp32 along a whole run; "bf16w" its exact form (lo weight
-    halves as a second GEMM pass).  An unknown value raises ValueError.
+    dtype (keyword-only; the reference is fp32):
+      "fp32"  exact-fp32 MFMA GEMMs: token ids identical to the CPU reference's, losses to 1e-6;
+      "bf16"  (default; torch.bfloat16 and the older name "bf16m" mean the same) bf16 MFMA operands and activations, fp32 master weights --
+              evaluated so that no bf16 rounding is COMMON to all token rows: every forward Linear adds back the row-common part of the
+              weights' rounding (mean input row x lo weight half, dic_lin_prep), the residual stream is stored centred on predicted mean rows
+              (dic_ln_fwd_cen), the MLM-head pre-activation stays fp32, the rounding head sees mean-centred rows.  Every loss term within
+              1e-4 of fp32 at the initial weights, at trained weights and along a run (DESIGN.md section 4), ~4 % slower than "bf16r";
+      "bf16r" the raw bf16 engine without those corrections: the fastest, 1-3e-4 from fp32 (the A/B partner; what rounds 1-4 benchmarked);
+      "bf16w" the exact form of "bf16": the lo weight halves as a second pass of every forward GEMM's K loop + an fp32 residual stream (the
+              reference the mean-row form is checked against; ~25 % slower).
+    An unknown value raises ValueError.
     """
 
     def __init__(self, embedding=None, projection=None, config=None, *, dtype="bf16", device="cuda:0", seed=0, split_weights=None):
-        if dtype not in ("fp32", "bf16", "bf16w", "bf16m", torch.float32, torch.bfloat16):
-            raise ValueError(f"dtype must be 'fp32', 'bf16', 'bf16m' or 'bf16w', not {dtype!r}")
+        if dtype not in ("fp32", "bf16", "bf16r", "bf16w", "bf16m", torch.float32, torch.bfloat16):
+            raise ValueError(f"dtype must be 'fp32', 'bf16' (= 'bf16m'), 'bf16r' or 'bf16w', not {dtype!r}")
         _lib.require_gpu()
         get = (lambda k, d: config.get(k, d)) if isinstance(config, dict) else (lambda k, d: getattr(config, k, d))
         self.n_layers = int(get("n_layers", 6)) if config is not None else 6
@@ -151,19 +128,19 @@ class Denoiser:
         self.p_attn = float(get("attention_dropout", 0.1)) if config is not None else 0.1
         self.n_heads, self.dim, self.hidden = 12, 768, 3072
         self.device = torch.device(device)
-        self.bf16 = dtype in ("bf16", "bf16w", "bf16m", torch.bfloat16)
+        self.bf16 = dtype in ("bf16", "bf16r", "bf16w", "bf16m", torch.bfloat16)
         # SPLIT WEIGHTS (dtype="bf16w" / split_weights=True / DIC_SPLIT_W=1; bf16 engine only): the forward Linears multiply by hi + lo bf16 halves
         # of the fp32 master weights (two passes of the GEMM's K loop, include/dic_hip.h DicGemmParams.B2) instead of by their bf16 rounding.
         # This is the fast mode that meets north_star's 1e-4 loss tolerance: the weights' rounding error is the same for every sample and does
         # not average out of a batch-mean loss, the activations' does (profiles/r04_weight_rounding_probe.txt).  The backward is unchanged.
         if split_weights is None:
-            split_weights = dtype in ("bf16w", "bf16m") or _os0.environ.get("DIC_SPLIT_W", "0") == "1"
+            split_weights = dtype in ("bf16", "bf16m", "bf16w", torch.bfloat16)
         self.split_w = bool(split_weights) and self.bf16
         # HOW the lo halves enter (DIC_LO_MODE): "pass2" = a second pass of the K loop (DicGemmParams.B2, dtype="bf16w"); "mean" = only their
         # row-common part, mean row of the Linear's input times the lo half, added to the bias (dic_lo_mean_bias, dtype="bf16m"): two small
         # launches per Linear instead of doubling its flops
-        self.lo_mode = _os0.environ.get("DIC_LO_MODE", "mean" if dtype == "bf16m" else "pass2") if self.split_w else None
-        self.lo_row_stride = int(_os0.environ.get("DIC_LO_ROW_STRIDE", "16"))      # rows sampled for the mean row: every 16th
+        self.lo_mode = ("pass2" if dtype == "bf16w" else "mean") if self.split_w else None
+        self.lo_row_stride = OPT.lo_row_stride      # rows sampled for the mean row: every 16th
         # WHICH forward Linears take the lo half (DIC_SPLIT_SET; profiles/r04_split_alloc_trajectory_dense.txt: 19 states along a training run):
         # "all" (default): every Linear; "vo2t" = only the value third of q|k|v, the attention output projection, FFN lin2 and the MLM-head
         # transform -- at B = 512 FFN lin1 and the query / key projections make no measurable difference to any loss term at any state (54 % of the
@@ -171,19 +148,19 @@ class Denoiser:
         # split_slots (slot -> bool) overrides the set, split_qk overrides the q / k choice (the probes use both).
         # "auto" (round 5): the exact form bf16w corrects every Linear; the mean-row form bf16m leaves out FFN lin1 -- its correction never moved a
         # loss term at any state (round 4, B = 512; 7e-5 at B = 16 with q / k left out as well), and it is one launch per layer on the critical path
-        self.split_set = _SPLIT_SET if _SPLIT_SET != "auto" else ("vo2t" if self.lo_mode == "mean" else "all")
+        self.split_set = OPT.split_set if OPT.split_set != "auto" else ("vo2t" if self.lo_mode == "mean" else "all")
         self.split_slots = None
         self.split_qk = None
         self.dt = DIC_BF16 if self.bf16 else DIC_F32
         # bf16 engines keep the MLM-head pre-activation (vocab_transform's output) in fp32: include/dic_hip.h, DIC_U_F32 (DIC_UVT32=0: A/B)
-        self.uvt32 = self.bf16 and _UVT32
+        self.uvt32 = self.bf16 and OPT.uvt32
         self.dt_u = (self.dt | DIC_U_F32) if self.uvt32 else self.dt
         # fp32 residual stream: the pre-LayerNorm sums and the residual operands of the two residual GEMMs of a block in fp32, bf16 MFMA operands
         # CENTRED residual stream (round 5, the parity mode dtype="bf16m"): the same roundings removed at bf16 bytes -- the pre-LayerNorm sums and the
         # residual operands are stored as bf16(value - reference row), one fp32 reference row per tensor predicted by dic_lin_prep
         # (include/dic_hip.h; DIC_CEN=0: the round-4 form of bf16m, fp32 copies)
-        self.cen = self.split_w and self.lo_mode == "mean" and _CEN
-        self.res32 = self.bf16 and not self.cen and (_RES32 == "1" or (_RES32 == "auto" and self.split_w))
+        self.cen = self.split_w and self.lo_mode == "mean" and OPT.cen
+        self.res32 = self.bf16 and not self.cen and (OPT.res32 == "1" or (OPT.res32 == "auto" and self.split_w))
         self.dt_ln = (self.dt | DIC_RES_F32) if self.res32 else self.dt
         self.tdtype = torch.bfloat16 if self.bf16 else torch.float32
         self.es = 2 if self.bf16 else 4
@@ -245,7 +222,7 @@ class Denoiser:
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("DIC_SIDE_PRIO", "0")))
+            self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     def set_dropout_seed(self, seed: int):
@@ -389,7 +366,7 @@ class Denoiser:
         ws["dHa"], ws["dHb"] = e(T, D), e(T, D)
         # gradients that a weight-gradient GEMM consumes exist twice (layer parity): those GEMMs run on a second stream and may
         # still be reading layer i+1's copy while the main stream produces layer i's
-        npar = _BWD_PARITY              # sets of the gradient buffers the weight-gradient stream reads: layer i reuses the set of layer i + npar
+        npar = OPT.n_bwd_sets           # sets of the gradient buffers the weight-gradient stream reads: layer i reuses the set of layer i + npar
         ws["dy"], ws["dyd"], ws["dy1"] = [e(T, D) for _ in range(npar)], [e(T, D) for _ in range(npar)], [e(T, D) for _ in range(npar)]
         ws["du"], ws["dqkv"] = [e(T, Hd) for _ in range(npar)], [e(T, 3 * D) for _ in range(npar)]
         ws["dsa"], ws["dctx"] = e(T, D), e(T, D)
@@ -423,13 +400,15 @@ class Denoiser:
         return ws
 
     # ------------------------------------------------------------------ encoder forward (hf:92-118, 150-259, 501-513)
-    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None, tidx=None, x_view=None, inputs_ready=False):
+    def encode(self, x, image_clip, text_clip, key_mask, add_txt=None, drop_txt=False, cap=None, tidx=None, x_view=None, inputs_ready=False, raw=False):
         """x [N,L,768] fp32; image_clip/text_clip [N,512]; key_mask [N,Tk] uint8 -> x_out [N,Tk,768] fp32.
         Saves what backward() needs.  Dropout (hidden p, attention p) is active iff self.training.
         drop_txt (concat fusion, no guided row in the batch): run with Tk = L+1, leaving the never-read text row out.
         x_view = (data_ptr, elements between sequences, N, L): read the L input rows of every sequence in place from a larger fp32 tensor
         (the sampling loop's feedback of x_out[:, :L], ref :613-620) instead of from `x`; inputs_ready: the workspace's CLIP rows, key mask
-        and CLIP projections are those of the previous call (constant over a sampling loop) -- neither copied nor recomputed."""
+        and CLIP projections are those of the previous call (constant over a sampling loop) -- neither copied nor recomputed.
+        raw: run this pass as the "bf16r" engine would (no mean-row corrections, plain bf16 residual stream) whatever the engine's dtype --
+        forward-only use (sample(): per-row argmax, no batch mean whose common-mode rounding would need protecting)."""
         if x_view is not None:
             x_ptr, x_stride, N, L = x_view
         else:
@@ -449,14 +428,16 @@ class Denoiser:
         sel = self.split_slots
         if sel is None and self.split_set != "all":
             sel = lambda slot: not slot.endswith("W1")
-        lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if (self.split_w and self.lo_mode == "pass2") else (lambda slot: 0)   # low-order weight halves
-        lo_mean = self.split_w and self.lo_mode == "mean"
+        lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if (self.split_w and self.lo_mode == "pass2" and not raw) else (lambda slot: 0)   # low-order weight halves
+        lo_mean = self.split_w and self.lo_mode == "mean" and not raw
         beff_off = [0]
         lo_stride = self.lo_row_stride          # rows are [sequence][token]: a stride that shares a factor with Tk would visit only some token positions
         while math.gcd(lo_stride, Tk) != 1:
             lo_stride += 1
 
-        cen = self.cen
+        cen = self.cen and not raw
+        assert not (raw and torch.is_grad_enabled() and self.training and self.cen), "encode(raw=True) is forward-only: backward() would read reference rows this pass did not write"
+
         def bias_of(wslot, bslot, a_ptr, K, Nn, resid=None):
             """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows).
             resid = (r_ref, y_ref, bias_post, fold): the centred residual stream's reference rows for a residual Linear (dic_lin_prep)."""
@@ -476,7 +457,7 @@ class Denoiser:
         v_col0 = 0 if qk_lo else 2 * D                     # q|k|v GEMM: first output column whose weight rows take the second pass
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
         ws["has_u"] = keep_u
-        gelu_d = ws["gelu_d"] = self.bf16 and _GELU_D and not _V1_BF16          # Lw["u"] then holds gelu'(u), not u
+        gelu_d = ws["gelu_d"] = self.bf16 and OPT.gelu_d and not OPT.gemm_v1          # Lw["u"] then holds gelu'(u), not u
         if x_ptr is None:
             if x.data_ptr() != ws["xin"].data_ptr():
                 ws["xin"][:N].copy_(x)
@@ -505,7 +486,8 @@ class Denoiser:
         _lib.check(lib.dic_fuse_ln_fwd_x(self.dt, mode, x_ptr, x_stride, _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                          P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
                                          _p(ws["h"][0]), _p(ws["mean0"]), _p(ws["rstd0"]), N, L, D, LN_EPS, ph, seed, st), "fuse_ln_fwd")
-        r32 = self.res32
+        r32 = self.res32 and not raw
+        ws["cen_fwd"] = cen
         if r32:          # the embedding LayerNorm once more in fp32 (same dropout mask: it is a function of seed and position): layer 0's residual
             _lib.check(lib.dic_fuse_ln_fwd_x(DIC_F32, mode, x_ptr, x_stride, _p(ws["img_p"]), _p(ws["txt_p"]), _p(ws["addtxt"]),
                                              P.ptr("seg") if self.concat else 0, P.ptr("pos"), temb_p, tidx_p, P.ptr("eln_g"), P.ptr("eln_b"),
@@ -596,14 +578,13 @@ class Denoiser:
                 _lib.check(lib.dic_zero(P.ptr("Wtxt", "G"), D * 512 * 4, st), "zero")
                 _lib.check(lib.dic_zero(P.ptr("btxt", "G"), D * 4, st), "zero")
         main = torch.cuda.current_stream()
-        use_side = self.bf16 and _os.environ.get("DIC_WGRAD_STREAM", "1") == "1" and self.wgrad_stream_enabled
+        use_side = self.bf16 and OPT.wgrad_stream and self.wgrad_stream_enabled
         side = self._side_stream() if use_side else None
         done = {}                                     # layer -> event on the side stream after that layer's dW launches
 
-        # Each side launch is handed over as soon as its inputs exist (one event on the main stream per hand-over).  Batching the
-        # hand-overs to two per layer (DIC_SIDE_BATCH=1) saves events but starts the side work later: measured 1.5 % slower.
+        # Each side launch is handed over as soon as its inputs exist (one event on the main stream per hand-over; batching the hand-overs
+        # to two per layer saved events but started the side work later: 1.5 % slower, round 2).
         pending = []
-        batch_side = _os.environ.get("DIC_SIDE_BATCH", "0") == "1"
 
         def flush_side():
             if not pending:
@@ -622,8 +603,7 @@ class Denoiser:
 
         def on_side(fn):
             pending.append(fn)
-            if not (use_side and batch_side):
-                flush_side()
+            flush_side()
 
         # Grouped weight gradients (dic_wgrad_group: one K-slice count for all the tiles of several Linears, one launch + one fold).
         # DIC_WGRAD_GROUP=1 groups all four Linears of a layer: 2.4 % faster with everything on one stream (15.79 vs 16.16 ms) but 1-2 %
@@ -634,7 +614,7 @@ class Denoiser:
         # ties "2" on the two-stream step (13.93 vs 13.93 ms, profiles/r04_wgrad_group_ab.txt) with 24 launches fewer per step -> default "1".
         # Round 5, "pair": the split-K slabs (2.4 GB written + re-read per step) and the 25 fold launches go away when ONE launch carries two layers:
         # 216 tiles of 272 K-steps = one round of the 256 CUs at 84 %, each tile written once, in place (dic_wgrad_group picks one slice per tile).
-        gmode = _WGRAD_GROUP
+        gmode = OPT.wgrad_group
         pair = gmode == "pair" and self.bf16 and len(ws["dy"]) >= 4
         if gmode == "pair" and not pair:
             gmode = "1"
@@ -645,7 +625,7 @@ class Denoiser:
         def flush_group():
             if not items:
                 return
-            cap_ = _WGRAD_CU_CAP if use_side else 0
+            cap_ = OPT.wgrad_cu_cap if use_side else 0
             batches = [list(items)]
             items.clear()
             arr0 = (_lib.WgradItem * len(batches[0]))(*batches[0])
@@ -673,7 +653,7 @@ class Denoiser:
 
             def launch():
                 o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0,
-                       colsum_out=cs, tile=tile, cu_cap=_WGRAD_CU_CAP if use_side else 0)
+                       colsum_out=cs, tile=tile, cu_cap=OPT.wgrad_cu_cap if use_side else 0)
             on_side(launch)
             if bias_slot is not None and not self.bf16:
                 colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
@@ -737,35 +717,31 @@ class Denoiser:
                 main.wait_event(done[i + npar])       # the dW GEMMs of layer i + npar have finished with this set's buffers
             dy_, dyd_, dy1_, du_, dqkv_ = ws["dy"][sp], ws["dyd"][sp], ws["dy1"][sp], ws["du"][sp], ws["dqkv"][sp]
             # output_layer_norm backward; bias grad of lin2 folded in
-            if self.cen:
+            if ws["cen_fwd"]:
                 yref = lambda j: ws["refs"].data_ptr() + ((i * 4 + j) * D) * 4
                 _lib.check(lib.dic_ln_bwd_cen(_p(dH), _p(Lw["y2"]), yref(2), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
                                               _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
             else:
                 _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(dH), _p(Lw["y2"]), P.ptr(pre + "ln2g"), _p(Lw["m2"]), _p(Lw["r2"]), _p(dy_),
                                           _p(dyd_) if use_drop else 0, ph, seed + 4 * i + 2, parts[2 * sp], NPART, T, D, st), "ln_bwd")
-            if not _PAIR_FOLDS:
-                fold(parts[2 * sp], 3 * D, P.ptr(pre + "ln2g", "G"))                          # [ln2g | ln2b | b2]
             dyd = dyd_ if use_drop else dy_
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_MUL_AUX if ws["gelu_d"] else EPI_GELU_BWD,
                    aux=_p(Lw["u"]), ldaux=Hd)
             wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                                # dW1 (+ db1)
-            if not pair and _os.environ.get("DIC_WGRAD_GROUP_HALVES", "1") == "1":
+            if not pair:
                 flush_group()                         # the two FFN gradients go out now (72 tiles), out-proj + qkv at the end of the layer (36):
             flush_side()                              # one launch per layer starts the side stream too late to hide behind this layer's chain
             o.gemm(_p(du_), P.ptr(pre + "W1", wsrc), _p(ws["dsa"]), T, D, Hd, Hd, D, D, b_km=1, R=_p(dy_), ldr=D)       # + residual
             # sa_layer_norm backward; bias grad of out_lin folded in
-            if self.cen:
+            if ws["cen_fwd"]:
                 _lib.check(lib.dic_ln_bwd_cen(_p(ws["dsa"]), _p(Lw["y1"]), yref(0), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
                                               0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
             else:
                 _lib.check(lib.dic_ln_bwd(self.dt_ln, _p(ws["dsa"]), _p(Lw["y1"]), P.ptr(pre + "ln1g"), _p(Lw["m1"]), _p(Lw["r1"]), _p(dy1_),
                                           0, 0.0, 0, parts[2 * sp + 1], NPART, T, D, st), "ln_bwd")
-            if _PAIR_FOLDS:                                                                   # [ln2g | ln2b | b2] and [ln1g | ln1b | bo] in one launch
-                fold2(parts[2 * sp], P.ptr(pre + "ln2g", "G"), parts[2 * sp + 1], P.ptr(pre + "ln1g", "G"), 3 * D)
-            else:
-                fold(parts[2 * sp + 1], 3 * D, P.ptr(pre + "ln1g", "G"))                      # [ln1g | ln1b | bo]
+            # [ln2g | ln2b | b2] and [ln1g | ln1b | bo] in one launch
+            fold2(parts[2 * sp], P.ptr(pre + "ln2g", "G"), parts[2 * sp + 1], P.ptr(pre + "ln1g", "G"), 3 * D)
             wgrad(_p(dy1_), _p(Lw["ctx"]), pre + "Wo", D, D, D, D)
             o.gemm(_p(dy1_), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
             _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(dqkv_), N, Tk, self.n_heads, 64, pa,
@@ -817,7 +793,7 @@ class Denoiser:
     # ------------------------------------------------------------------ rounding head: streaming CE / argmax (ref :323, 436-437, 620)
     @property
     def head_centered(self):
-        return self.bf16 and not self.te and (_HEAD_CENTER == "1" or (_HEAD_CENTER in ("w", "auto") and self.split_w))
+        return self.bf16 and not self.te and (OPT.head_center == "1" or (OPT.head_center in ("w", "auto") and self.split_w))
 
     def center_head_input(self, cw, x_a, n_a, x_b, n_b, L, Tk):
         """bf16 engines: rewrite cw["xr"] as bf16(x - xbar) over the head rows (rows t < L of the n_a sequences at x_a and the n_b at x_b, fp32
@@ -841,7 +817,7 @@ class Denoiser:
         cbias = _p(cw["cvec"]) if (cw.get("centered") and ce_ws is not None and dtype is None) else 0
         W = self.W_lm_c if dtype is None else (self.W_lm if dtype == DIC_F32 else self.W_lm_c)
         f32 = dtype == DIC_F32 or (dtype is None and not self.bf16)
-        tile = 128 if (f32 or _V1_BF16) else choose_tile(M, self.vocab, 1, EPI_CE_PARTIAL)
+        tile = 128 if (f32 or OPT.gemm_v1) else choose_tile(M, self.vocab, 1, EPI_CE_PARTIAL)
         np_ = o.L.dic_ce_n_partials(self.vocab, tile)
         o.gemm(_p(xr), _p(W), 0, M, self.vocab, 768, 768, 768, 0, epi=EPI_CE_PARTIAL, tgt=_p(tgt) if tgt is not None else 0,
                partial=_p(cw["partial"]), tgt_logit=_p(cw["tgt_logit"]), dtype=dtype, tile=tile, bias=cbias)
@@ -856,7 +832,7 @@ class Denoiser:
     def ce_fused(self):
         """bf16 engine: the training forward of the rounding loss leaves exp(logit - c) behind, so the backward needs no second logits GEMM
         (DIC_CE_FUSED=0: the recompute path, kept as the A/B partner and for the fp32 engine)."""
-        return self.bf16 and not _V1_BF16 and _CE_FUSED
+        return self.bf16 and not OPT.gemm_v1 and OPT.ce_fused
 
     def rounding_train(self, xr, M, tgt, ce_ws=None):
         """Training form of `rounding` (ref :323, 436-437 with their backward in mind): one GEMM over the vocabulary writes

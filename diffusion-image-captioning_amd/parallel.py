@@ -92,17 +92,18 @@ class GradReducer:
         self.store = model.params
         self.handles = []            # (work handle, lo, hi) in issue order
         # DIC_FORCE_REDUCER=1: run the exchange path at world size 1 too (single-GPU test of the data-parallel code path)
-        self.active = is_initialized() and (world_size() > 1 or os.environ.get("DIC_FORCE_REDUCER", "0") == "1")
-        self.group = max(1, int(os.environ.get("DIC_DP_GROUP", "3")))
+        from .options import OPT
+        self.active = is_initialized() and (world_size() > 1 or OPT.force_reducer)
+        self.group = max(1, int(OPT.dp_group))
         # DIC_DP_SINGLE=1: north_star's literal design -- exactly ONE all-reduce of the whole flat buffer, after the backward (nothing
         # overlaps it; A/B partner of the sliced default on the first multi-GPU run)
-        self.single = os.environ.get("DIC_DP_SINGLE", "0") == "1"
+        self.single = bool(OPT.dp_single)
         # DIC_DP_CU_CAP=n: while a slice is on the wire, the backward's persistent GEMMs keep to n CUs' worth of workgroups so that RCCL's
         # kernels find free CUs (the 256-column GEMM holds 128 KB of LDS on every CU it runs on); 0 = no cap
-        self.cu_cap = int(os.environ.get("DIC_DP_CU_CAP", "0"))
+        self.cu_cap = int(OPT.dp_cu_cap)
         self.model = model
         self.n_collectives = 0
-        self.timing = os.environ.get("DIC_DP_TIMING", "0") == "1" and torch.cuda.is_available()
+        self.timing = bool(OPT.dp_timing) and torch.cuda.is_available()
         self._ev = []
 
     def layer_done(self, i):

@@ -143,6 +143,10 @@ size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
  * 256-column geometry runs.  0 (default) = the lock-step loop, 1 (env DIC_GEMM_PP=1) = the ping-pong loop of csrc/gemm_pp.h.  Results are
  * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
 int dic_gemm_set_variant(int pp);
+/* Every process-global switch of the library by name (the library reads no environment variable): "gemm_w4a" (0 / 1, default 0: the four-wave asm
+ * GEMM where eligible), "gemm_two_heights" (default 0), "gemm_rows" (default 1: per-launch tile heights), "gemm_persist" (default 1: persistent grids),
+ * "gemm_v1" (default 0: bf16 on the register-staged fp32-style kernel), "gemm_variant" (= dic_gemm_set_variant).  Unknown name: 1007.                */
+int dic_set_option(const char* name, int value);
 /* Measurement / test switch (PROCESS-GLOBAL): 1 (default 0; env DIC_GEMM_TWO_HEIGHTS=1 turns it on everywhere) lets a forward GEMM of the 256-column
  * geometry run whole rounds of tall tiles followed by ONE round of shorter tiles over the remaining rows, when its units would otherwise end
  * in a partly filled round of the persistent grid; 0 = one tile height per launch.  Results are identical (a tile's arithmetic does not

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Loss distance from the fp32 engine of every bf16 mode ALONG one training run at the bench shape (the run of split_alloc_probe.py: the split-weight
 engine trains on 8 cycled batches; evaluation on two held-out batches x three noise / timestep draws, dropout off):
-  bf16   plain (fp32 MLM-head pre-activation, centred head)                      bf16m-r4 round 4's parity mode: mean-row lo correction (dic_lo_mean_bias, two launches) + fp32 residual stream
-  bf16m  the parity mode: one-launch dic_lin_prep + CENTRED bf16 residual stream  bf16w    second K-loop pass against the lo halves + fp32 residual stream
+  bf16r  raw (fp32 MLM-head pre-activation, centred head, nothing else)          bf16-r4  round 4's parity mode ("bf16m" then): mean-row lo correction (dic_lo_mean_bias) + fp32 residual stream
+  bf16   the default = the parity mode: dic_lin_prep + CENTRED bf16 residual stream  bf16w  second K-loop pass against the lo halves + fp32 residual stream
     python scripts/experiments/mode_trajectory_probe.py [--trajectory 0,1,2,...] [--time]
 """
 import argparse, importlib, os, sys, time
@@ -27,19 +27,19 @@ E = torch.from_numpy(dic.synth.vocab_embedding(30522, 768, 0))
 
 
 def make(dtype, res32=None, drop=0.0, cen=None):
-    keep = eng._RES32, eng._CEN
+    keep = eng.OPT.res32, eng.OPT.cen
     if res32 is not None:
-        eng._RES32 = res32
+        eng.OPT.res32 = res32
     if cen is not None:
-        eng._CEN = cen
+        eng.OPT.cen = cen
     try:
         return dic.DistilBertModel(E, E, dtype=dtype, config=dict(n_layers=NL, dropout=drop, attention_dropout=drop), device=dev, seed=0)
     finally:
-        eng._RES32, eng._CEN = keep
+        eng.OPT.res32, eng.OPT.cen = keep
 
 
 # bf16m: round 5's parity mode (centred bf16 residual stream, dic_lin_prep); bf16m-r4: round 4's (fp32 residual stream, dic_lo_mean_bias)
-MODES = {"bf16": make("bf16"), "bf16m-r4": make("bf16m", cen=False), "bf16m": make("bf16m"), "bf16w": make("bf16w", drop=args.train_dropout)}
+MODES = {"bf16r": make("bf16r"), "bf16-r4": make("bf16", cen=False), "bf16": make("bf16"), "bf16w": make("bf16w", drop=args.train_dropout)}
 SO = args.seed_offset
 f32 = make("fp32")
 held = [{k: torch.from_numpy(v).to(dev) for k, v in dic.synth.batch(B, L, 30522, seed=1 + 7 * i + SO).items()} for i in range(2)]
@@ -88,8 +88,8 @@ print("# worst term over the run / states with every term <= 1e-4:  " + "   ".jo
 if args.time:
     del f32
     x = train[0]
-    for name in ("bf16", "bf16m-r4", "bf16m", "bf16w", "bf16", "bf16m"):
-        m = make({"bf16m-r4": "bf16m"}.get(name, name), cen=False if name == "bf16m-r4" else None, drop=0.1)
+    for name in ("bf16r", "bf16-r4", "bf16", "bf16w", "bf16r", "bf16"):
+        m = make({"bf16-r4": "bf16"}.get(name, name), cen=False if name == "bf16-r4" else None, drop=0.1)
         tr = dic.AdamW(m.parameters(), lr=1e-4)
         for _ in range(5):
             dic.train_func(m, tr, x)

@@ -26,3 +26,17 @@ def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))
     return z, meta
+
+
+@pytest.fixture(autouse=True)
+def _shipped_options():
+    """Every test starts on the shipped configuration (options.py: nothing differs from the defaults unless DIC_OPTIONS / a legacy variable was set for
+    the whole run) and whatever a test switches is switched back -- a benchmark line and an assertion can then only differ in configuration visibly."""
+    import copy
+    import importlib
+    opts = importlib.import_module("diffusion-image-captioning_amd.options")
+    if not os.environ.get("DIC_OPTIONS") and not any(v in os.environ for v in opts.LEGACY_ENV):
+        assert opts.OPT.non_default() == {}, opts.OPT.non_default()
+    keep = copy.copy(opts.OPT.__dict__)
+    yield
+    opts.OPT.__dict__.update(keep)

@@ -445,7 +445,39 @@ def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_pat
         assert text.count("s_barrier") >= 2 * 6, name
 
 
+def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configuration():
+    """Round-4 review: engine behaviour hung on ~40 DIC_* environment reads.  One record now (options.py): its defaults ARE the shipped
+    configuration (pinned here -- a changed default must change this test), the package's hot-path modules and the C sources read no
+    environment variable, DIC_OPTIONS / the legacy names parse into it, unknown names are refused, and the library takes its four
+    process-global switches through dic_set_option."""
+    import dataclasses
+    opts = importlib.import_module("diffusion-image-captioning_amd.options")
+    shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
+                   head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, cen=True, res32="auto", sample_raw=True, streamed_adamw=True,
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=False, gemm_two_heights=False, gemm_variant=0, dp_group=3,
+                   dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False)
+    assert dataclasses.asdict(opts.Options()) == shipped
+    assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
+    o = opts.from_env({"DIC_OPTIONS": "cen=0, wgrad_group=1,dp_group=4", "DIC_WGRAD_STREAM": "0", "DIC_GEMM_W4A": "0"})
+    assert o.non_default() == {"cen": False, "wgrad_group": "1", "dp_group": 4, "wgrad_stream": False, "sample_w4a": False}
+    with pytest.raises(ValueError):
+        opts.from_env({"DIC_OPTIONS": "no_such_switch=1"})
+    with pytest.raises(ValueError):
+        opts.from_env({"DIC_OPTIONS": "cen=maybe"})
+    assert set(opts.LEGACY_ENV.values()) <= set(shipped)
+    pkg = os.path.join(ROOT, "diffusion-image-captioning_amd")
+    for mod in ("engine.py", "diffusion.py", "graph.py", "harness.py", "params.py", "train_embedding.py"):
+        assert "environ" not in open(os.path.join(pkg, mod)).read(), mod
+    par = open(os.path.join(pkg, "parallel.py")).read()
+    assert set(re.findall(r'environ(?:\.get|\.setdefault)?\(?\[?"(\w+)"', par)) <= {"WORLD_SIZE", "LOCAL_RANK", "RANK", "MASTER_ADDR", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                                                                   "DIC_DIST_SHARE_GPU", "DIC_DIST_BACKEND"}
+    for src in ("gemm.hip", "gemm_w4a.h", "attn.hip", "misc.hip", "common.h"):
+        assert "getenv" not in open(os.path.join(pkg, "csrc", src)).read(), src
+    L = dic.lib()
+    assert L.dic_set_option(b"gemm_w4a", 0) == 0 and L.dic_set_option(b"no_such_option", 1) != 0
+
+
 def test_unknown_precision_mode_is_refused_before_anything_else():
-    """dtype is one of fp32 / bf16 / bf16m / bf16w; a typo used to fall through to the fp32 engine silently."""
+    """dtype is one of fp32 / bf16 (= bf16m) / bf16r / bf16w; a typo used to fall through to the fp32 engine silently."""
     with pytest.raises(ValueError):
         dic.DistilBertModel(None, None, dtype="bf16x")
