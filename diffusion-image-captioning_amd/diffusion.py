@@ -139,18 +139,25 @@ def _guidance_draw(model, Nt, cfg_uniform=None):
 T_SEED_BASE = 0x7157E9        # timestep draws: the SAME stream on every rank (one t-vector per step for the whole global batch, ref :461)
 
 
+def _default_t_seed() -> int:
+    return (T_SEED_BASE + (torch.initial_seed() & 0x3FFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+
+
 def _next_t_seed() -> int:
     """Seed of the next timestep draw: a per-process counter.  Its start follows torch's global seed (`torch.manual_seed(s)` changes the
-    t-vectors, as it does for the reference's `torch.randint`, ref :460-461) unless `seed_timesteps` / `seed_all` set it; under data
-    parallelism `parallel.configure_model_for_rank` makes every rank start from rank 0's value, so the ranks agree on t without a
-    per-step collective (`parallel.assert_shared_timestep_seed` checks it)."""
-    if "t_seed" not in _state:
-        _state["t_seed"] = (T_SEED_BASE + (torch.initial_seed() & 0x3FFFFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+    t-vectors, as it does for the reference's `torch.randint`, ref :460-461) unless `seed_timesteps` / `seed_all` set it.  Under data parallelism
+    every rank must continue rank 0's counter (ref :461 shares one t-vector over the whole batch): that is ONE broadcast at an explicit
+    synchronisation point -- `parallel.configure_model_for_rank` or the start of `harness.fit` (`parallel.share_timestep_seed`) -- never a lazy
+    collective here: ranks that reach their first draw at different times (a rank-0-only sanity step, a restored checkpoint on some ranks)
+    would hang in it without a hint (round-4 advisor).  A multi-rank draw from a counter that was never shared therefore raises."""
+    if not _state.get("t_seed_shared", False):
         from . import parallel
         if parallel.world_size() > 1:
-            # torch.initial_seed() differs per process: a data-parallel run that never called parallel.configure_model_for_rank would draw a
-            # different t on every rank (ref :461 shares one t-vector over the whole batch) -- take rank 0's start, once
-            parallel.share_timestep_seed()
+            raise RuntimeError("data-parallel run: the timestep stream was never shared between the ranks -- call parallel.configure_model_for_rank(model) "
+                               "(or parallel.share_timestep_seed()) on EVERY rank before the first train_func / validate; torch.initial_seed() differs per "
+                               "process, so the ranks would noise their shards at different timesteps (ref :461 draws one t-vector for the whole batch)")
+    if "t_seed" not in _state:
+        _state["t_seed"] = _default_t_seed()
     _state["t_seed"] += 1
     return _state["t_seed"]
 
@@ -164,7 +171,10 @@ def _draw_t(S, dev):
 
 
 def seed_timesteps(seed: int):
+    """Start the timestep stream at `seed`.  Data parallel: call it with the SAME value on every rank (that is what makes the stream shared;
+    `parallel.assert_shared_timestep_seed` verifies it once per epoch) or let `parallel.share_timestep_seed` copy rank 0's."""
     _state["t_seed"] = int(seed) & 0x7FFFFFFFFFFFFFFF
+    _state["t_seed_shared"] = True
 
 
 def seed_all(seed: int, device=None):
@@ -204,6 +214,7 @@ def set_rng_state(st: dict, model=None):
     shift = (r - sr) * parallel._RANK_MIX
     if st.get("t_seed") is not None:
         _state["t_seed"] = int(st["t_seed"])
+        _state["t_seed_shared"] = True             # (every rank restores the same checkpoint's counter)
     _state["noise_seed"] = (int(st["noise_seed"]) + shift) & 0x7FFFFFFFFFFFFFFF       # mod 2^63, exactly like parallel.rank_seed at start-up
     gstates = list(st.get("guidance", {}).values())
     if r == sr and gstates:

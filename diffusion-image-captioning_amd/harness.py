@@ -85,6 +85,8 @@ def fit(model, trainer, train_loader, val_loader, epochs=None, scheduler="linspa
     early_stopped = False
     history = []
     model.train()
+    if parallel.world_size() > 1 and not diffusion._state.get("t_seed_shared", False):
+        parallel.share_timestep_seed()           # the explicit synchronisation point of the shared timestep stream (every rank is here)
     for epoch in range(epochs):
         acc = [0, 0, 0, 0]
         if cfg.END_LEARNING_RATE != cfg.LEARNING_RATE:

@@ -226,14 +226,16 @@ def configure_model_for_rank(model, rank_: int | None = None):
 
 
 def share_timestep_seed():
-    """Every rank continues the timestep stream from rank 0's counter (one small broadcast at configuration time, none per step)."""
+    """Every rank continues the timestep stream from rank 0's counter: one small broadcast at an explicit synchronisation point (model
+    configuration, the start of harness.fit, after a checkpoint restore) -- every rank must call it; none per step."""
     from . import diffusion
     if "t_seed" not in diffusion._state:
-        diffusion._next_t_seed()                          # materialise the default (torch.initial_seed()-derived) start
+        diffusion._state["t_seed"] = diffusion._default_t_seed()     # materialise the default (torch.initial_seed()-derived) start; no collective in there
     if is_initialized() and world_size() > 1:
         box = [diffusion._state["t_seed"]]
         dist.broadcast_object_list(box, src=0)
         diffusion._state["t_seed"] = int(box[0])
+    diffusion._state["t_seed_shared"] = True
     return diffusion._state["t_seed"]
 
 
