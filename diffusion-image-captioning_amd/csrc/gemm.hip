@@ -1491,10 +1491,51 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
 #endif
 }
 
+// CLOCK PROBE (measurement build only, -DDIC_CLOCK_PROBE; scripts/power_ab.py): workgroup 0 of every GEMM launch stamps the shader-clock counter
+// (s_memtime) and the 100 MHz wall clock (s_memrealtime) at its start and at its end into the next record of a caller-provided buffer
+// (dic_clock_probe_set) -- their ratio is the shader clock this launch actually ran at, measured inside the launch and per launch, which
+// rocm-smi's 1 Hz samples cannot give.  Record: {memtime0, realtime0, memtime1, realtime1, M, N, K, tag} (tag: 1000 a_km + 100 b_km + epi; 5000+ = asm).
+#ifdef DIC_CLOCK_PROBE
+__device__ unsigned long long* g_clk_buf = nullptr;
+__device__ unsigned g_clk_cap = 0, g_clk_n = 0;
+struct ClkProbe {
+    unsigned long long* rec = nullptr;
+    __device__ __forceinline__ void begin(int M, int N, int K, int tag) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g_clk_buf) {
+            const unsigned slot = atomicAdd(&g_clk_n, 1u);
+            if (slot < g_clk_cap) {
+                rec = g_clk_buf + (size_t)slot * 8;
+                rec[4] = (unsigned long long)M; rec[5] = (unsigned long long)N; rec[6] = (unsigned long long)K; rec[7] = (unsigned long long)tag;
+                rec[0] = __builtin_amdgcn_s_memtime(); rec[1] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+    }
+    __device__ __forceinline__ void end() {
+        if (rec) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); rec[2] = __builtin_amdgcn_s_memtime(); rec[3] = __builtin_amdgcn_s_memrealtime(); }
+    }
+};
+extern "C" int dic_clock_probe_set(void* buf, int capacity) {
+    unsigned long long* b = (unsigned long long*)buf;
+    unsigned cap = (unsigned)capacity, zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_clk_buf), &b, sizeof(b)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_clk_cap), &cap, sizeof(cap)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_clk_n), &zero, sizeof(zero)) != hipSuccess) { dic_set_error("dic_clock_probe_set: hipMemcpyToSymbol failed"); return 1008; }
+    return 0;
+}
+extern "C" int dic_clock_probe_count(void) {
+    unsigned n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_clk_n), sizeof(n));
+    return (int)n;
+}
+#else
+struct ClkProbe { __device__ __forceinline__ void begin(int, int, int, int) {} __device__ __forceinline__ void end() {} };
+#endif
+
 template <class C, bool AKM, bool BKM, int EPI, int CNT>
 __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams p) {
     if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
+    ClkProbe cp; cp.begin(p.M, p.N, p.K, 1000 * AKM + 100 * BKM + EPI);
     gemm_bf16_body<C, AKM, BKM, EPI, CNT, false>(p, nullptr);
+    cp.end();
 }
 // TWO TILE HEIGHTS IN ONE LAUNCH.  A persistent grid runs its units in rounds of `slots` workgroups; with one tile height the last round is
 // usually partial (17 408 x 2304: 702 units of 224 rows = 2.74 rounds; 34 816 x 768: 1.83).  Here the first `row_split` rows -- whole rounds of
@@ -1504,12 +1545,16 @@ __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel(DicGemmParams
 template <class C, bool BKM, int EPI, int CA, int CB>
 __global__ __launch_bounds__(Geo<C>::NTH, 2) void gemm_bf16_kernel2(DicGemmParams p, int row_split) {
     if (p.step_ctr) p.seed += (uint64_t)(p.step_ctr[0] - p.step_ctr0) * DIC_STRIDE_DROP;
+    ClkProbe cp; cp.begin(p.M, p.N, p.K, 100 * BKM + EPI);
     gemm_bf16_body<C, false, BKM, EPI, CA, false>(p, nullptr, 0, row_split);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     gemm_bf16_body<C, false, BKM, EPI, CB, false>(p, nullptr, row_split, p.M - row_split);
+    cp.end();
 }
 __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmParams p, WgradGroupDev grp) {
+    ClkProbe cp; cp.begin(grp.tiles, grp.split, p.K, 9000);
     gemm_bf16_body<T256, true, true, DIC_EPI_AFFINE, Geo<T256>::FM, true>(p, &grp);
+    cp.end();
 }
 
 // The two K-loop alternatives measured in round 3 (ping-pong loop, four-wave 256 x 256 kernel: equal or slower) are
@@ -1953,6 +1998,7 @@ extern "C" int dic_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_rows")) g_rows = value ? 1 : 0;
     else if (!strcmp(name, "gemm_two_heights")) g_two_heights = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4a")) g_w4a = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0xFF;
     else if (!strcmp(name, "gemm_variant")) return dic_gemm_set_variant(value);
     else { dic_set_error("dic_set_option: unknown option"); return 1007; }
     return 0;

@@ -43,6 +43,7 @@ class GraphedTrainStep:
         self.n = 0                         # host mirror of the device counter
         self.replays = 0
         self.captures = 0
+        self._pinned, self._pin_box, self._finalizer = (), [], None      # workspaces this object keeps out of the engine's eviction (see _capture)
         for _ in range(warmup):            # allocates workspaces / the side stream, loads every kernel: nothing may allocate while capturing
             diffusion.train_func(model, trainer, self.x)
         torch.cuda.synchronize()
@@ -73,11 +74,17 @@ class GraphedTrainStep:
         if sc["slot"] + self.HORIZON + 3 >= diffusion.LOSS_RING:
             sc["slot"] = 0                  # replays write slots slot0 .. slot0 + HORIZON without wrapping: restart at the ring's (oldest) head
         self.sc = sc
-        # the graph bakes in the addresses of these workspaces: keep them out of Denoiser._evict's reach
-        ws["pinned"] = True
+        # the graph bakes in the addresses of these workspaces: keep them out of Denoiser._evict's reach -- until this object goes away or
+        # re-captures onto another pair (pins are counted: several graphed steps may share a workspace)
         cw = model._ce_workspace((cfg.SAMPLE_SIZE + 1) * B * L_)
-        cw["pinned"] = True
+        self._unpin()
+        for w_ in (ws, cw):
+            w_["pinned"] = w_.get("pinned", 0) + 1
         self._pinned = (ws, cw)
+        if self._finalizer is None:
+            import weakref
+            self._finalizer = weakref.finalize(self, GraphedTrainStep._unpin_list, self._pin_box)
+        self._pin_box[:] = [ws, cw]
         self.stride_noise = (2 if cfg.X_0_PREDICTION else 3) * 0x9E3779B1          # diffusion._next_seed per q_sample call
         torch.cuda.synchronize()
         _lib.check(L.dic_step_ctx_set(self.ctr.data_ptr(), self.n + 1, self.stride_noise, self.table.data_ptr()), "step_ctx_set")
@@ -98,10 +105,23 @@ class GraphedTrainStep:
         return (int(self.model._seed), int(diffusion._state["noise_seed"]), int(diffusion._state.get("t_seed", 0)), int(self.trainer.t),
                 int(self.sc["slot"]), bool(self.model.training))
 
+    @staticmethod
+    def _unpin_list(box):
+        for w in box:
+            n = int(w.get("pinned", 0)) - 1
+            if n > 0:
+                w["pinned"] = n
+            else:
+                w.pop("pinned", None)
+        box[:] = []
+
+    def _unpin(self):
+        GraphedTrainStep._unpin_list(self._pin_box)
+        self._pinned = ()
+
     def release(self):
-        """Unpin the workspaces (the graph must not be replayed afterwards)."""
-        for w in getattr(self, "_pinned", ()):
-            w.pop("pinned", None)
+        """Unpin the workspaces (the graph must not be replayed afterwards).  Dropping the object does the same (weakref finaliser)."""
+        self._unpin()
         self.graph = None
 
     def _advance_host(self):

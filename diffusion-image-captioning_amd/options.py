@@ -48,7 +48,10 @@ class Options:
     sample_w4a: bool = True          # the four-wave asm GEMM inside sample()
     sample_two_heights: bool = True  # two tile heights per launch inside sample()
     # ---- C library (pushed through dic_set_option when the library is loaded)
-    gemm_w4a: bool = False           # the four-wave asm GEMM for every eligible launch (training too)
+    gemm_w4a: bool = True            # the four-wave asm GEMM for every eligible launch, training included (round 5: 14.76 -> 14.35 ms per step once the
+                                     # weight gradients run as one launch per two layers; 18.5 -> 17.1 J per step -- profiles/r05_power_ab.txt)
+    gemm_w4a_mask: int = 0x73        # which (layout, epilogue) forms may take it: bit 4 * b_km + {0 plain, 1 + residual, 2 x aux, 3 dropout + residual};
+                                     # 0x73 = all but the forward dropout + residual form (FFN lin2 in training: 84 vs 81 us, profiles/r05_w4a_mask_ab.txt)
     gemm_two_heights: bool = False   # two tile heights per launch everywhere
     gemm_variant: int = 0            # measurement builds (-DDIC_GEMM_VARIANTS): 1 ping-pong K loop, 2 four-wave C++ kernel
     # ---- data parallel (parallel.py)
@@ -76,7 +79,7 @@ LEGACY_ENV = {
     "DIC_GEMM_TWO_HEIGHTS": "gemm_two_heights", "DIC_GEMM_PP": "gemm_variant", "DIC_DP_GROUP": "dp_group", "DIC_DP_SINGLE": "dp_single",
     "DIC_DP_CU_CAP": "dp_cu_cap", "DIC_DP_TIMING": "dp_timing", "DIC_FORCE_REDUCER": "force_reducer", "DIC_SAMPLE_RAW": "sample_raw",
 }
-_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_two_heights", "gemm_variant")
+_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_two_heights", "gemm_variant")
 
 
 def _coerce(name: str, text: str):
@@ -90,7 +93,7 @@ def _coerce(name: str, text: str):
         if text.strip().lower() in ("0", "false", "off", "no", ""):
             return False
         raise ValueError(f"option {name}: {text!r} is not a boolean")
-    return kind(text.strip())
+    return int(text.strip(), 0) if kind is int else kind(text.strip())
 
 
 def from_env(env=None) -> Options:

@@ -155,7 +155,16 @@ class WordPiece:
         return [e["input_ids"] for e in enc], [e["attention_mask"] for e in enc]
 
     # ---- ids -> text
-    def decode(self, ids: Sequence, skip_special_tokens=False):
+    def decode(self, ids: Sequence, skip_special_tokens=False, cleanup="token"):
+        """cleanup="token" (default): the clean-up table is applied to every token on its own, which is what the tokenizers-backed
+        `DistilBertTokenizer` of transformers 5.x does (the installed 5.15: identical strings on a synthetic vocabulary, tests/test_next_rows.py) --
+        with a leading space in front of each token " ' " and " do not" can never match.  cleanup="string": the table runs over the JOINED text, the
+        behaviour of the slow `DistilBertTokenizer` of the reference's era (transformers 4.2x, `clean_up_tokenization` on the whole string):
+        "man ' s" -> "man's", "do not" -> "don't".  The reference's BLEU targets are raw `[CLS] caption [SEP]` strings (ref :625-627) split on
+        spaces, so candidates with apostrophes tokenise differently under the two: use "string" to reproduce the reference stack's BLEU, "token"
+        to match the installed transformers.  cleanup=None: no clean-up."""
+        if cleanup not in ("token", "string", None):
+            raise ValueError(f"cleanup must be 'token', 'string' or None, not {cleanup!r}")
         ids = ids.tolist() if hasattr(ids, "tolist") else list(ids)
         toks = [self.inv.get(int(i), self.unk) for i in ids]
         if skip_special_tokens:
@@ -164,10 +173,15 @@ class WordPiece:
         for k, t in enumerate(toks):
             if k:
                 t = t[2:] if t.startswith("##") else " " + t
-            for a, b in _CLEANUP:
-                t = t.replace(a, b)
+            if cleanup == "token":
+                for a, b in _CLEANUP:
+                    t = t.replace(a, b)
             out.append(t)
-        return "".join(out)
+        text = "".join(out)
+        if cleanup == "string":
+            for a, b in _CLEANUP:
+                text = text.replace(a, b)
+        return text
 
 
 class DictTokenizer:

@@ -881,6 +881,24 @@ def test_graphed_training_step_is_bit_identical_to_eager(dtype):
     assert ref[2:] == got, "graphed losses differ from the eager ones"
     assert torch.equal(model.params.P, P_graph)
     assert len({tuple(r) for r in ref}) == 14                      # (every step drew fresh noise / masks / timesteps)
+    # the workspaces a captured graph points into are pinned against the engine's eviction only while a GraphedTrainStep needs them (round-4
+    # advisor: dropping the object used to leave multi-GB workspaces pinned for good)
+    import gc
+    model, trainer = fresh()
+    s1 = dic.GraphedTrainStep(model, trainer, x, warmup=1)
+    pinned = lambda: sum(1 for c_ in (model._ws, model._ce_ws) for w_ in c_.values() if w_.get("pinned"))
+    assert pinned() == 2
+    s2 = dic.GraphedTrainStep(model, trainer, x, warmup=0)         # a second graphed step on the same workspaces: pins are counted
+    del s1
+    gc.collect()
+    assert pinned() == 2
+    s2.release()
+    assert pinned() == 0
+    s3 = dic.GraphedTrainStep(model, trainer, x, warmup=0)
+    assert pinned() == 2
+    del s3
+    gc.collect()
+    assert pinned() == 0
 
 
 def test_config5_seq32_guidance_bf16_matches_fp32():

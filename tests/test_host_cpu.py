@@ -455,12 +455,12 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, cen=True, res32="auto", sample_raw=True, streamed_adamw=True,
-                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=False, gemm_two_heights=False, gemm_variant=0, dp_group=3,
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x73, gemm_two_heights=False, gemm_variant=0, dp_group=3,
                    dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
-    o = opts.from_env({"DIC_OPTIONS": "cen=0, wgrad_group=1,dp_group=4", "DIC_WGRAD_STREAM": "0", "DIC_GEMM_W4A": "0"})
-    assert o.non_default() == {"cen": False, "wgrad_group": "1", "dp_group": 4, "wgrad_stream": False, "sample_w4a": False}
+    o = opts.from_env({"DIC_OPTIONS": "cen=0, wgrad_group=1,dp_group=4,gemm_w4a_mask=0xff", "DIC_WGRAD_STREAM": "0", "DIC_GEMM_W4A": "0"})
+    assert o.non_default() == {"cen": False, "wgrad_group": "1", "dp_group": 4, "wgrad_stream": False, "sample_w4a": False, "gemm_w4a": False, "gemm_w4a_mask": 255}
     with pytest.raises(ValueError):
         opts.from_env({"DIC_OPTIONS": "no_such_switch=1"})
     with pytest.raises(ValueError):

@@ -315,6 +315,16 @@ def test_wordpiece_decode_matches_tokenizer_decode():
     # round trip through the reference's BLEU target format (ref :626-627 wraps captions in "[CLS] .. [SEP]")
     s = "two dogs running on the grass ."
     assert mine.decode(mine(s, max_length=16)["input_ids"]).startswith("[CLS] two dogs running on the grass. [SEP]")
+    # WHICH transformers behaviour is pinned (round-4 advisor): the default, cleanup="token", is the installed 5.x tokenizers-backed decode
+    # checked above -- per token, so " ' " and " do not" never match.  The reference-era slow tokenizer cleaned the JOINED string:
+    # cleanup="string" reproduces that ("man ' s" -> "man's", "do not" -> "don't"), which changes how apostrophe candidates split for BLEU.
+    apo = [vocab["man"], vocab["'"], vocab["s"], vocab["ball"]]
+    assert mine.decode(apo) == "man ' s ball" and mine.decode(apo, cleanup="string") == "man's ball"
+    dn = [vocab["a"], vocab["do"], vocab["not"]]                  # (the table's entry is " do not": it needs a word in front, in both stacks)
+    assert mine.decode(dn) == "a do not" and mine.decode(dn, cleanup="string") == "a don't"
+    assert mine.decode(apo, cleanup=None) == "man ' s ball"
+    with pytest.raises(ValueError):
+        mine.decode(apo, cleanup="words")
 
 
 def test_dict_tokenizer_follows_the_reference_ablation():
