@@ -52,7 +52,7 @@ def relaunch(n):
         have = torch.cuda.device_count()
     except Exception:
         have = 0
-    if have < n and os.environ.get("DIC_DIST_SHARE_GPU", "0") != "1":          # (the shared-GPU gloo rig of the tests puts every rank on GPU 0)
+    if have < n and os.environ.get("DIC_DIST_SHARE_GPU", "0") != "1" and "--dry-run" not in sys.argv:   # (the shared-GPU gloo rig of the tests puts every rank on GPU 0)
         sys.exit(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -232,6 +232,77 @@ def cpu_leg(dic, torch, E, cb, S, L, layers, steps=3):
                       f"after 1 warm-up ({med:.2f} s/step)"}
 
 
+def dry_run(args):
+    """`--dry-run`: the plumbing of an N-rank run end to end WITHOUT a GPU and without a kernel -- what has to work the first time the driver starts
+    `bench.py --gpus 8` on a real node, rehearsed where it can be: the relauncher, torchrun's environment, `parallel.init_from_env` (gloo over CPU
+    tensors here, RCCL there), per-rank seeds with a shared timestep stream, the real `GradReducer` over a flat 12-layer gradient buffer (sliced
+    schedule or options.dp_single), barrier + max-over-ranks timing, the `data_parallel` block and the JSON schema.  The "step" only fills the
+    gradient buffer with a rank-dependent pattern and checks the reduced values; the line says so (`dry_run`, `data`) and its value is meaningless."""
+    import torch
+    dic = importlib.import_module("diffusion-image-captioning_amd")
+    OPT = importlib.import_module("diffusion-image-captioning_amd.options").OPT
+    ParamStore = importlib.import_module("diffusion-image-captioning_amd.params").ParamStore
+    diffusion = importlib.import_module("diffusion-image-captioning_amd.diffusion")
+    rank, world, local = dic.parallel.init_from_env()
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}")
+    store = ParamStore(args.layers, "cpu", bf16_shadow=False)
+
+    class Model:                                   # what configure_model_for_rank and GradReducer touch on a Denoiser
+        params, ops, device, dropout_seed_base, rank_rows_forced = store, None, torch.device("cpu"), 0x5EED0000, True
+
+        def set_dropout_seed(self, s_):
+            self.seed = s_
+    model = Model()
+    dic.parallel.configure_model_for_rank(model)
+    dic.seed_noise(dic.parallel.rank_seed(1234))
+    t_seeds = [diffusion._next_t_seed() for _ in range(3)]
+    dic.parallel.assert_shared_timestep_seed()
+    seeds = [None] * world
+    torch.distributed.all_gather_object(seeds, (model.seed, diffusion._state["noise_seed"], t_seeds))
+    assert len({s_[0] for s_ in seeds}) == world and len({s_[1] for s_ in seeds}) == world and len({tuple(s_[2]) for s_ in seeds}) == 1, seeds
+    B = args.batch or 512
+
+    class Trainer:
+        grad_scale = 1.0
+
+    def step():
+        store.G.fill_(float(rank + 1))
+        red = dic.parallel.GradReducer(model)
+        for i in reversed(range(args.layers)):
+            red.layer_done(i)
+        tr = Trainer()
+        red.finish(tr)
+        want = world * (world + 1) / 2
+        assert tr.grad_scale == 1.0 / world and float(store.G.min()) == want == float(store.G.max()), (float(store.G.min()), want)
+        return red
+    for _ in range(args.warmup):
+        step()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        red = step()
+    torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt])
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    mine = torch.tensor([B * args.steps / dt])
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(allr, mine)
+    dp_info = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(), "rccl_version": None,
+               "devices_by_rank": ["cpu"] * world, "collectives_per_step": red.n_collectives,
+               "mode": "single all-reduce after the backward (options.dp_single)" if OPT.dp_single else f"slices of {OPT.dp_group} layers issued from the backward + tail",
+               "allreduce_ms_per_step": None, "gradient_bytes": int(store.numel) * 4, "per_rank_captions_per_s": [round(float(v), 1) for v in allr]}
+    if rank == 0:
+        print(json.dumps({"metric": "training captions/sec (seq16, bert-base)", "value": round(world * B * args.steps / float(tmax), 2), "unit": "captions/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "DRY RUN: no kernel ran; CPU tensors over gloo, the step only fills and exchanges the gradient buffer",
+                          "dry_run": True, "config": {"workload": "plumbing rehearsal of bench.py --gpus N (relaunch, rendezvous, rank seeds, gradient exchange schedule, "
+                                                                  "timing, schema)", "global_batch": world * B, "n_layers": args.layers, "parallelism": f"dp{world}"},
+                          "roofline": None, "cpu_baseline": None, "data_parallel": dp_info, "options_non_default": OPT.non_default()}), flush=True)
+    torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +319,7 @@ def main():
                     help="bf16 (default; 'bf16m' is its older name): the engine inside north_star's 1e-4 loss tolerance -- mean-row lo-weight correction of "
                          "every forward Linear + centred bf16 residual stream; bf16r: the raw bf16 engine without them (the default line carries it as "
                          "throughput_mode); bf16w: the default's exact form, the lo weight halves as a second K-loop pass")
+    ap.add_argument("--dry-run", action="store_true", help="rehearse the multi-rank plumbing without a GPU (gloo, CPU tensors, no kernels): see dry_run()")
     ap.add_argument("--no-oracle-leg", action="store_true", help="skip loss_rel_vs_cpu_oracle (one forward of the CPU oracle at the bench shape, ~1-2 min)")
     ap.add_argument("--sustained", type=int, default=500, help="steps of the extra sustained leg of the default line (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,6 +332,8 @@ def main():
     # --gpus N without a launcher: start the N ranks ourselves (one process per GPU, RCCL over xGMI) exactly as the driver would
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch(args.gpus)
+    if args.dry_run:
+        return dry_run(args)
     import torch
     dic = importlib.import_module("diffusion-image-captioning_amd")
     OPT = importlib.import_module("diffusion-image-captioning_amd.options").OPT

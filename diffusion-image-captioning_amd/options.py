@@ -60,6 +60,7 @@ class Options:
     dp_cu_cap: int = 0               # > 0: the backward's persistent GEMMs keep to this many CUs while a slice is on the wire
     dp_timing: bool = False          # bracket every collective with events
     force_reducer: bool = False      # run the exchange path at world size 1 (single-GPU test of the data-parallel code path)
+    dp_timeout_s: int = 300          # rendezvous / collective timeout of the process group: a missing or dead peer ends the job with a message
 
     def non_default(self) -> dict:
         ref = Options()

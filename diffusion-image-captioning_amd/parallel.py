@@ -49,7 +49,17 @@ def init_from_env(backend: str | None = None):
         backend = os.environ.get("DIC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
-    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
+    from datetime import timedelta
+    from .options import OPT
+    r_ = int(os.environ["RANK"])
+    try:
+        # a finite timeout for the rendezvous AND for every later collective: a peer that never arrives / dies mid-step must end the job with a
+        # message, not leave the survivors in a collective forever (options.dp_timeout_s)
+        dist.init_process_group(backend=backend, rank=r_, world_size=ws, timeout=timedelta(seconds=int(OPT.dp_timeout_s)))
+    except Exception as e:
+        raise RuntimeError(f"data-parallel start-up failed on rank {r_} of {ws} (backend {backend}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}, "
+                           f"MASTER_PORT={os.environ.get('MASTER_PORT')}, timeout {OPT.dp_timeout_s} s): {type(e).__name__}: {e} -- every rank must be "
+                           "started with the same WORLD_SIZE / MASTER_* and reach init_from_env; on ROCm keep HSA_ENABLE_IPC_MODE_LEGACY=0") from e
     return dist.get_rank(), ws, local
 
 
@@ -128,7 +138,13 @@ class GradReducer:
         if self.timing:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        self.handles.append((dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True), lo, hi, ev0))
+        try:
+            work = dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        except Exception as e:
+            self.handles = []
+            raise RuntimeError(f"data-parallel gradient exchange could not be issued on rank {rank()} of {world_size()}: {type(e).__name__}: {str(e)[:300]} "
+                               "-- a peer rank has exited or the communicator is broken") from e
+        self.handles.append((work, lo, hi, ev0))
         self.n_collectives += 1
 
     def finish(self, trainer=None):
@@ -151,7 +167,12 @@ class GradReducer:
             trainer.grad_scale = 1.0 / w
             trainer.begin_step()
         for h, lo, hi, ev0 in self.handles:
-            h.wait()                                   # the current stream waits for this slice only
+            try:
+                h.wait()                               # the current stream waits for this slice only
+            except Exception as e:                     # a peer died / the collective timed out: one clear error instead of a stack of backend noise
+                self.handles = []
+                raise RuntimeError(f"data-parallel gradient exchange failed on rank {rank()} of {w} (elements [{lo}, {hi}) of the flat gradient buffer): "
+                                   f"{type(e).__name__}: {str(e)[:300]} -- a peer rank has exited or stalled; the step was NOT applied on this rank") from e
             if ev0 is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()

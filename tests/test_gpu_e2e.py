@@ -1117,7 +1117,7 @@ def test_optional_timestep_embedding_end_to_end_fp32():
 
 @pytest.mark.parametrize("world,dtype,layers,single,cfg_w", [(2, "fp32", 4, "0", "0"), (2, "bf16", 4, "1", "0"), (4, "bf16", 12, "0", "0"),
                                                              (4, "bf16", 4, "0", "0.3"), (2, "fp32", 4, "0", "0.3"), (8, "bf16", 12, "0", "0"),
-                                                             (8, "bf16w", 12, "1", "0"), (2, "bf16r", 4, "0", "0")])
+                                                             (8, "bf16w", 12, "1", "0"), (2, "bf16r", 4, "0", "0"), (8, "bf16", 12, "1", "0")])
 def test_data_parallel_step_of_the_real_engine_on_ranks_sharing_one_gpu(world, dtype, layers, single, cfg_w):
     """SURVEY section 8e with the HIP engine instead of the oracle: `world` processes (gloo; RCCL refuses two ranks on one device) take
     the step on their shards through parallel.GradReducer -- slices issued from the backward + streamed AdamW, or the one-collective exchange --

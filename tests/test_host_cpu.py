@@ -446,6 +446,84 @@ def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_pat
         assert text.count("s_barrier") >= 2 * 6, name
 
 
+def _run_bench(argv, env_extra=None, timeout=600):
+    import subprocess
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world,opts,n_coll", [(8, "", 7), (2, "dp_single=1", 1)])
+def test_bench_dry_run_rehearses_the_multi_gpu_plumbing(world, opts, n_coll):
+    """Round-4 review item 6: no multi-GPU node has ever run this code, so the first real `bench.py --gpus 8` must not be able to fail on
+    plumbing.  `--dry-run` goes through everything but the kernels on CPU tensors over gloo: the self-relaunch under torch.distributed.run,
+    the rendezvous, per-rank seeds + shared timestep stream, the real GradReducer over the 12-layer flat gradient buffer in both schedules
+    (7 sliced collectives / options.dp_single: exactly one), max-over-ranks timing and the JSON line with its `data_parallel` block."""
+    import json
+    r = _run_bench(["--gpus", str(world), "--dry-run", "--steps", "2", "--warmup", "1"], {"DIC_OPTIONS": opts})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["dry_run"] is True and d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["parallelism"] == f"dp{world}"
+    dp = d["data_parallel"]
+    assert dp["rccl_ranks"] == world and dp["collectives_per_step"] == n_coll and len(dp["per_rank_captions_per_s"]) == world
+    assert dp["gradient_bytes"] == 86830848 * 4
+    assert d["options_non_default"] == ({"dp_single": True} if opts else {})
+
+
+def _dp_dying_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), DIC_OPTIONS="dp_timeout_s=30")
+    sys.path.insert(0, ROOT)
+    d = importlib.import_module("diffusion-image-captioning_amd")
+    ParamStore = importlib.import_module("diffusion-image-captioning_amd.params").ParamStore
+    d.parallel.init_from_env(backend="gloo")
+    store = ParamStore(1, "cpu", bf16_shadow=False)
+
+    class M:
+        params = store
+    red = d.parallel.GradReducer(M)
+    red.layer_done(0)
+    red.finish(type("T", (), {"grad_scale": 1.0})())              # one healthy step
+    torch.distributed.barrier()
+    if rank == 1:
+        os._exit(0)                                               # dies between two steps, without a goodbye
+    msg = "no error"
+    try:
+        red = d.parallel.GradReducer(M)
+        red.layer_done(0)
+        red.finish(type("T", (), {"grad_scale": 1.0})())
+    except RuntimeError as e:
+        msg = str(e)
+    open(out, "w").write(msg)
+    os._exit(0)
+
+
+def test_data_parallel_failures_surface_as_one_clear_error_not_a_hang(tmp_path):
+    """A peer that dies mid-run and a peer that never shows up both end in ONE RuntimeError that names the rank, the world size and what to check
+    (parallel.init_from_env / GradReducer), within the process group's timeout (options.dp_timeout_s) -- not in a hang."""
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "rank0.txt")
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_dying_rank_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    msg = open(out).read()
+    assert "data-parallel gradient exchange" in msg and "rank 0 of 2" in msg and "peer rank" in msg, msg
+    # a rank that waits for a peer which never starts
+    import subprocess
+    code = ("import importlib, os, sys; sys.path.insert(0, %r); os.environ.update(RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', "
+            "DIC_OPTIONS='dp_timeout_s=5'); d = importlib.import_module('diffusion-image-captioning_amd'); d.parallel.init_from_env(backend='gloo')" % (ROOT, _free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "data-parallel start-up failed on rank 0 of 2" in r.stderr, r.stderr[-1500:]
+
+
 def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configuration():
     """Round-4 review: engine behaviour hung on ~40 DIC_* environment reads.  One record now (options.py): its defaults ARE the shipped
     configuration (pinned here -- a changed default must change this test), the package's hot-path modules and the C sources read no
@@ -456,7 +534,7 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, cen=True, res32="auto", sample_raw=True, streamed_adamw=True,
                    sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x73, gemm_two_heights=False, gemm_variant=0, dp_group=3,
-                   dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False)
+                   dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=300)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
     o = opts.from_env({"DIC_OPTIONS": "cen=0, wgrad_group=1,dp_group=4,gemm_w4a_mask=0xff", "DIC_WGRAD_STREAM": "0", "DIC_GEMM_W4A": "0"})
