@@ -16,7 +16,7 @@ _AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another bui
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
-ABI_VERSION = 15          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
+ABI_VERSION = 17          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
 EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [
@@ -27,7 +27,7 @@ EXPORTS = [
     "dic_gemm_split_ws_bytes", "dic_ce_n_partials", "dic_ce_partial_bytes", "dic_colsum_ws_bytes", "dic_ln_partial_bytes",
     "dic_te_dx0", "dic_embed_scatter", "dic_temb_grad", "dic_step_prep", "dic_randint", "dic_zero", "dic_wgrad_group", "dic_wgrad_group_ws_bytes",
     "dic_gemm_set_variant", "dic_fuse_ln_fwd_x", "dic_cfg_prep", "dic_step_ctx_set", "dic_step_advance",
-    "dic_lin_prep", "dic_lin_prep_ws_bytes", "dic_ln_fwd_cen", "dic_ln_bwd_cen", "dic_set_option",
+    "dic_lin_prep", "dic_lin_prep_ws_bytes", "dic_ln_fwd_cen", "dic_ln_bwd_cen", "dic_set_option", "dic_rank1_add",
 ]
 
 
@@ -141,7 +141,8 @@ def lib():
         L.dic_lin_prep.argtypes = [P, I, I, I, I, P, P, I, I, P, P, I, P, P, P, P, P]
         L.dic_lin_prep_ws_bytes.argtypes = [I]
         L.dic_lin_prep_ws_bytes.restype = C.c_size_t
-        L.dic_ln_fwd_cen.argtypes = [P, P, P, P, P, P, P, P, P, I, I, F, P]
+        L.dic_ln_fwd_cen.argtypes = [P, P, P, P, P, P, P, P, P, I, I, F, P, P, I, I, P, P, P]
+        L.dic_rank1_add.argtypes = [P, P, P, I, I, P]
         L.dic_ln_bwd_cen.argtypes = [P, P, P, P, P, P, P, P, F, U64, P, I, I, I, P]
         L.dic_gelu_ln_fwd.argtypes = [I, P, P, P, P, P, P, I, I, F, P]
         L.dic_gelu_ln_bwd.argtypes = [I, P, P, P, P, P, P, P, I, I, I, P]

@@ -963,6 +963,32 @@ extern "C" int dic_lin_prep(const void* A, int T, int lda, int row_stride, int K
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ rank-one completion of a weight gradient
+// dW[m][n] += db[m] * x_ref[n]: the Linear's input is stored centred, X = X_c + 1 x_ref^T (dic_ln_fwd_cen), the weight-gradient GEMM contracts
+// dY with X_c, and dY^T (1 x_ref^T) = colsum(dY) x_ref^T = db x_ref^T is what it leaves out (hf:183-185, 221, 510 backward; exact algebra, no
+// approximation).  Streaming: 8 B per element of dW.
+__global__ __launch_bounds__(256) void rank1_add_kernel(float* dW, const float* db, const float* x_ref, int M, int N) {
+    const int n4 = N >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)M * n4; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), c = (int)(i - (long long)m * n4) * 4;
+        const float s = db[m];
+        const f32x4 r = *(const f32x4*)(x_ref + c);
+        f32x4* p = (f32x4*)(dW + (size_t)m * N + c);
+        f32x4 v = *p;
+        v[0] += s * r[0]; v[1] += s * r[1]; v[2] += s * r[2]; v[3] += s * r[3];
+        *p = v;
+    }
+}
+extern "C" int dic_rank1_add(float* dW, const float* db, const float* x_ref, int M, int N, void* stream) {
+    DIC_REQUIRE(dW && db && x_ref && M > 0 && N > 0 && N % 4 == 0, "dic_rank1_add: dW [M][N] fp32 with N a multiple of 4, db [M], x_ref [N]");
+    long long n = (long long)M * (N / 4);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(rank1_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dW, db, x_ref, M, N);
+    DIC_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ K15 AdamW
 // torch.optim.AdamW semantics (ref :335): p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  One pass over the flat buffers: 16 B/param read, 12(+2) B written.

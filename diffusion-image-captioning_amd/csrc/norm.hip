@@ -211,21 +211,81 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TY* y, const float* g
 // nearly equal (the first hundreds of training steps) the rounding error of a bf16 residual stream is the SAME vector for every token and
 // does not average out of a batch-mean loss; stored relative to a row all tokens are close to, it is 2^-9 of the rows' differences instead
 // of 2^-9 of the rows (profiles/r05_cen_probe.txt: the same loss distances as the fp32 residual stream, at bf16 bytes).
+// nx_*: optional "next Linear" tail: nx_out[n] = nx_bias[n] + sum_k ([nx_hi] + [nx_lo])[n][k] h_ref[k], one output per wave, no cross-workgroup
+// step -- every wave already holds h_ref.  nx_hi: the next Linear multiplies the CENTRED tensor h_c by bf16(W) = W_hi, so the reference row's
+// share of that product belongs in its bias -- (h_c + 1 h_ref^T) W_hi^T = h_c W_hi^T + 1 (W_hi h_ref)^T, exact algebra.  nx_lo: the lo half's
+// share W_lo h_ref of the mean-row correction W_lo abar, abar = h_ref + mean(h_c): the Linear's dic_lin_prep adds the measured rest W_lo
+// mean(h_c), or -- q|k|v of layers >= 1, options.qkv_pred -- it is left at the prediction mean(h_c) = 0.  (FFN lin1 takes nx_hi only: it gets no
+// lo correction at all, and a PREDICTED one would hurt it at the synthetic initial weights: profiles/r05_pred_probe.txt.)  Used for the q|k|v projection of layers >= 1 (options.qkv_pred): two launches fewer per layer on the
+// critical path; what the prediction costs in accuracy is measured in profiles/r05_pred_probe.txt (nothing once the rows have begun to
+// collapse, 1e-5 of the L1 terms at the synthetic initial weights -- FFN lin1, by contrast, must NOT be fed this way: 1.2e-4).
 __global__ __launch_bounds__(256) void ln_fwd_cen_kernel(const bf16_t* y_c, const float* y_ref, const float* gamma, const float* beta, bf16_t* h, bf16_t* h_c,
-                                                         float* h_ref, float* mean, float* rstd, int rows, float eps) {
+                                                         float* h_ref, float* mean, float* rstd, int rows, float eps,
+                                                         const bf16_t* nx_hi, const bf16_t* nx_lo, int nx_ldb, int nx_n, const float* nx_bias, float* nx_out) {
     const int lane = threadIdx.x & 63;
     f32x4 g[NCH], b[NCH], yr[NCH], hr[NCH];
     load_row<float>(gamma, lane, g);
     load_row<float>(beta, lane, b);
     load_row<float>(y_ref, lane, yr);
     {
+        // h_ref: the LayerNorm of the reference row -- with the scale of a TYPICAL row, not its own.  While the rows are nearly equal the two are
+        // the same; while they differ (initial weights: rms distance from the mean row ~ the rows' own spread) the mean row has a much smaller
+        // variance than any row, LN(y_ref) would blow it up to unit scale, and a reference row that is far from every row doubles what the
+        // centred tensor's bf16 rounding costs (measured at B = 16: 1.2e-4 of the loss).  mean over rows of (y_r - mu_r) rstd_r ~ (ybar - mu(ybar))
+        // rstd* when rstd_r ~ rstd*: rstd* comes from four fixed sample rows (the same in every workgroup: deterministic), read by wave 0.
+        __shared__ float s_var;
+        if (threadIdx.x < 64) {
+            float vs = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = (int)(((long long)rows * q) / 4);
+                f32x4 t[NCH];
+                load_row<bf16_t>(y_c + (size_t)r * D, lane, t);
+                float sm = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { t[c] = t[c] + yr[c]; sm += t[c][0] + t[c][1] + t[c][2] + t[c][3]; }
+                const float m = wave_sum(sm) * (1.0f / D);
+                float qv = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float d = t[c][k] - m; qv += d * d; }
+                vs += wave_sum(qv) * (1.0f / D);
+            }
+            if (lane == 0) s_var = vs * 0.25f;
+        }
+        __syncthreads();
         float mu, rs;
         row_stats(yr, eps, mu, rs);
+        const float rs_typ = rsqrtf(s_var + eps);
+        rs = rs_typ < rs ? rs_typ : rs;                    // (never sharper than the reference row's own normalisation)
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int k = 0; k < 4; ++k) hr[c][k] = (yr[c][k] - mu) * rs * g[c][k] + b[c][k];
         if (h_ref && blockIdx.x == 0 && threadIdx.x < 64) store_row<float>(h_ref, lane, hr);
+    }
+    if (nx_out) {
+        const int nw = gridDim.x * 4;
+        for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < nx_n; n += nw) {
+            float a = 0.f;
+            if (nx_lo) {
+                f32x4 wv[NCH];
+                load_row<bf16_t>(nx_lo + (size_t)n * nx_ldb, lane, wv);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) a += (wv[c][0] * hr[c][0] + wv[c][1] * hr[c][1]) + (wv[c][2] * hr[c][2] + wv[c][3] * hr[c][3]);
+            }
+            if (nx_hi) {
+                f32x4 wv[NCH];
+                load_row<bf16_t>(nx_hi + (size_t)n * nx_ldb, lane, wv);
+                float a2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) a2 += (wv[c][0] * hr[c][0] + wv[c][1] * hr[c][1]) + (wv[c][2] * hr[c][2] + wv[c][3] * hr[c][3]);
+                a += a2;
+            }
+            a = wave_sum(a);
+            if (lane == 0) nx_out[n] = (nx_bias ? nx_bias[n] : 0.f) + a;
+        }
     }
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         f32x4 v[NCH];
@@ -238,7 +298,7 @@ __global__ __launch_bounds__(256) void ln_fwd_cen_kernel(const bf16_t* y_c, cons
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[c][k] = (v[c][k] - mu) * rs * g[c][k] + b[c][k];
-        store_row<bf16_t>(h + (size_t)row * D, lane, v);
+        if (h) store_row<bf16_t>(h + (size_t)row * D, lane, v);
         if (h_c) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) v[c] = v[c] - hr[c];
@@ -521,10 +581,15 @@ extern "C" int dic_ln_fwd_r32(const float* y32, const float* gamma, const float*
     return 0;
 }
 extern "C" int dic_ln_fwd_cen(const void* y_c, const float* y_ref, const float* gamma, const float* beta, void* h, void* h_c, float* h_ref, float* mean,
-                              float* rstd, int T, int Dd, float eps, void* stream) {
-    DIC_REQUIRE(Dd == D && T > 0 && y_c && y_ref && h, "dic_ln_fwd_cen: D must be 768; y_c (bf16), y_ref (fp32 [768]) and h are required");
+                              float* rstd, int T, int Dd, float eps, const void* next_hi, const void* next_lo, int next_ldb, int next_n, const float* next_bias,
+                              float* next_bias_out, void* stream) {
+    DIC_REQUIRE(Dd == D && T > 0 && y_c && y_ref && (h || h_c), "dic_ln_fwd_cen: D must be 768; y_c (bf16), y_ref (fp32 [768]) and one of h / h_c are required");
+    DIC_REQUIRE((next_lo == nullptr && next_hi == nullptr) || (next_bias_out != nullptr && next_n > 0 && next_ldb >= D && next_ldb % 4 == 0),
+                "dic_ln_fwd_cen: the next-Linear tail needs next_bias_out, next_n > 0 and next_ldb >= 768 (a multiple of 4)");
+    if (next_lo == nullptr && next_hi == nullptr) next_bias_out = nullptr;
     dim3 grid(rows_grid(T, 1024)), block(256);
-    hipLaunchKernelGGL(ln_fwd_cen_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)y_c, y_ref, gamma, beta, (bf16_t*)h, (bf16_t*)h_c, h_ref, mean, rstd, T, eps);
+    hipLaunchKernelGGL(ln_fwd_cen_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)y_c, y_ref, gamma, beta, (bf16_t*)h, (bf16_t*)h_c, h_ref, mean, rstd, T, eps,
+                       (const bf16_t*)next_hi, (const bf16_t*)next_lo, next_ldb, next_n, next_bias, next_bias_out);
     DIC_CHECK_LAUNCH();
     return 0;
 }

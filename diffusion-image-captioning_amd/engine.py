@@ -345,16 +345,17 @@ class Denoiser:
         ws["layers"] = [dict(qkv=e(T, 3 * D), ctx=e(T, D), y1=ey(T, D), m1=f(T), r1=f(T), sa=e(T, D), u=e(T, Hd), g=e(T, Hd),
                              y2=ey(T, D), m2=f(T), r2=f(T)) for _ in range(self.n_layers)]
         if self.lo_mode == "mean":
-            ws["beff"] = f(self.n_layers * (6 * D + Hd) + D)       # effective biases of the forward Linears (bias + mean-row lo correction)
+            ws["beff"] = f(self.n_layers * (10 * D + 2 * Hd) + 4 * D)       # effective biases of the forward Linears (bias + mean-row lo correction, LayerNorm tails)
             ws["lomean_ws"] = f(64 * Hd)
         if self.cen:
             # centred residual stream: reference rows [layer][y1 | sa | y2 | h_next][768] (+ a zero row: the embedding LayerNorm's output is stored
             # as it is), the bias rows that go behind FFN-2's dropout, the centred residual copies of sa / h
             ws["refs"] = torch.zeros(self.n_layers + 1, 4, D, dtype=torch.float32, device=dev)
             ws["bpost"] = f(self.n_layers, 2, D)
-            ws["hc"] = [None] + [e(T, D) for _ in range(self.n_layers - 1)]
-            for Lw in ws["layers"]:
-                Lw["sac"] = e(T, D)
+            if not OPT.cen_operand:                   # A/B form: an uncentred operand copy next to the centred residual copy (one more 27 MB write per LayerNorm)
+                ws["hc"] = [None] + [e(T, D) for _ in range(self.n_layers - 1)]
+                for Lw in ws["layers"]:
+                    Lw["sac"] = e(T, D)
         if self.res32:
             ws["h32"] = [f(T, D) for _ in range(self.n_layers)]          # residual operand of layer i's out-proj (the last LayerNorm's output has no reader)
             for Lw in ws["layers"]:
@@ -431,23 +432,31 @@ class Denoiser:
         lo = (lambda slot: P.ptr(slot, "Pl") if (sel is None or sel(slot)) else 0) if (self.split_w and self.lo_mode == "pass2" and not raw) else (lambda slot: 0)   # low-order weight halves
         lo_mean = self.split_w and self.lo_mode == "mean" and not raw
         beff_off = [0]
-        lo_stride = self.lo_row_stride          # rows are [sequence][token]: a stride that shares a factor with Tk would visit only some token positions
+        # every lo_row_stride-th row feeds the mean row -- but never fewer than ~1000 rows (a 16-caption batch has 544 token rows: all of them)
+        lo_stride = max(1, min(self.lo_row_stride, T // 1024))          # rows are [sequence][token]: a stride that shares a factor with Tk would visit only some token positions
         while math.gcd(lo_stride, Tk) != 1:
             lo_stride += 1
 
         cen = self.cen and not raw
+        tails = {}                                     # Linear -> bias row (b + W h_ref) that the LayerNorm launch writing its CENTRED input has left for it
         assert not (raw and torch.is_grad_enabled() and self.training and self.cen), "encode(raw=True) is forward-only: backward() would read reference rows this pass did not write"
 
-        def bias_of(wslot, bslot, a_ptr, K, Nn, resid=None):
-            """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows).
-            resid = (r_ref, y_ref, bias_post, fold): the centred residual stream's reference rows for a residual Linear (dic_lin_prep)."""
-            if not lo_mean or (resid is None and sel is not None and not sel(wslot)):
-                return P.ptr(bslot)
+        def slot(n):
             out = _p(ws["beff"]) + beff_off[0] * 4
-            beff_off[0] += Nn
+            beff_off[0] += n
+            return out
+
+        def bias_of(wslot, bslot, a_ptr, K, Nn, resid=None, bias_ptr=None):
+            """bias pointer of a forward Linear; in the mean-row mode: bias + lo . mean row of the input (sampled rows).
+            resid = (r_ref, y_ref, bias_post, fold): the centred residual stream's reference rows for a residual Linear (dic_lin_prep).
+            bias_ptr: the bias row to start from when it is not the parameter itself (a LayerNorm tail has already added W h_ref to it)."""
+            b0 = P.ptr(bslot) if bias_ptr is None else bias_ptr
+            if not lo_mean or (resid is None and sel is not None and not sel(wslot)):
+                return b0
+            out = slot(Nn)
             if cen:
                 r_ref, y_ref, b_post, fold = resid if resid is not None else (0, 0, 0, 0)
-                _lib.check(lib.dic_lin_prep(a_ptr, T, K, lo_stride, K, P.ptr(wslot, "Pb") if resid is not None else 0, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot),
+                _lib.check(lib.dic_lin_prep(a_ptr, T, K, lo_stride, K, P.ptr(wslot, "Pb") if resid is not None else 0, P.ptr(wslot, "Pl"), K, Nn, b0,
                                             r_ref, fold, out, b_post, y_ref, _p(ws["lomean_ws"]), st), "lin_prep")
                 return out
             _lib.check(lib.dic_lo_mean_bias(a_ptr, T, K, lo_stride, K, P.ptr(wslot, "Pl"), K, Nn, P.ptr(bslot), out, _p(ws["lomean_ws"]), st),
@@ -501,28 +510,67 @@ class Denoiser:
         for i in range(self.n_layers):
             Lw, h = ws["layers"][i], ws["h"][i]
             pre = f"L{i}."
+            if cen:
+                # The CENTRED stream: h (layers >= 1) and sa hold bf16(value - reference row); that ONE tensor is the MFMA operand of the next Linear
+                # (whose bias carries W h_ref, written by the LayerNorm launch that produced the tensor: `tails`) and the residual operand of the next
+                # residual GEMM; y1, y2 hold bf16(sum - predicted mean row).  Layer 0's h is the embedding LayerNorm's output as it is (reference 0).
+                h_ref = zero_ref if i == 0 else ref(i - 1, 3)
+                if not OPT.cen_operand:
+                    # A/B form (options.cen_operand = False): LayerNorm writes the uncentred bf16 operand copy AND the centred residual copy
+                    tb = tails.pop(pre + "Wqkv", None)
+                    o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D,
+                           bias=tb if (tb is not None and OPT.qkv_pred) else bias_of(pre + "Wqkv", pre + "bqkv", _p(h), D, 3 * D))
+                    _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
+                    o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D,
+                           bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D, resid=(h_ref, ref(i, 0), 0, 1)), R=_p(h) if i == 0 else _p(ws["hc"][i]), ldr=D)
+                    _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y1"]), ref(i, 0), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["sac"]), ref(i, 1),
+                                                  _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, 0, 0, 0, 0, 0, 0, st), "ln_fwd_cen")
+                    o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU,
+                           bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd), aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
+                    drop2 = ph > 0.0
+                    o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D,
+                           bias=bias_of(pre + "W2", pre + "b2", _p(Lw["g"]), Hd, D, resid=(ref(i, 1), ref(i, 2), bpost(i, 1) if drop2 else 0, 0 if drop2 else 1)),
+                           bias2=bpost(i, 1) if drop2 else 0, R=_p(Lw["sac"]), ldr=D, p_drop=ph, seed=seed + 4 * i + 2)
+                    last = i + 1 == self.n_layers
+                    nx = (0, 0, 0, 0, 0, 0)
+                    if not last and OPT.qkv_pred:
+                        t2 = slot(3 * D)
+                        tails[f"L{i + 1}.Wqkv"] = t2
+                        nx = (0, P.ptr(f"L{i + 1}.Wqkv", "Pl"), D, 3 * D, P.ptr(f"L{i + 1}.bqkv"), t2)
+                    _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y2"]), ref(i, 2), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]),
+                                                  0 if last else _p(ws["hc"][i + 1]), ref(i, 3), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, *nx, st), "ln_fwd_cen")
+                    continue
+                tb = tails.pop(pre + "Wqkv", None)
+                if tb is None:
+                    qkv_bias = bias_of(pre + "Wqkv", pre + "bqkv", _p(h), D, 3 * D)
+                else:              # (options.qkv_pred: the lo half's share of the mean-row correction stays at the tail's prediction W_lo h_ref)
+                    qkv_bias = tb if OPT.qkv_pred else bias_of(pre + "Wqkv", pre + "bqkv", _p(h), D, 3 * D, bias_ptr=tb)
+                o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=qkv_bias)
+                _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
+                o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D,
+                       bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D, resid=(h_ref, ref(i, 0), 0, 1)), R=_p(h), ldr=D)
+                t1 = slot(Hd)              # FFN lin1: b1 + W_hi sa_ref (it takes no lo correction, measured or predicted: options.split_set)
+                lo1 = P.ptr(pre + "W1", "Pl") if (sel is None or sel(pre + "W1")) else 0
+                _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y1"]), ref(i, 0), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), 0, _p(Lw["sa"]), ref(i, 1),
+                                              _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, P.ptr(pre + "W1", "Pb"), lo1, D, Hd, P.ptr(pre + "b1"), t1, st), "ln_fwd_cen")
+                o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU,
+                       bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd, bias_ptr=t1) if lo1 else t1, aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
+                drop2 = ph > 0.0
+                o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D,
+                       bias=bias_of(pre + "W2", pre + "b2", _p(Lw["g"]), Hd, D, resid=(ref(i, 1), ref(i, 2), bpost(i, 1) if drop2 else 0, 0 if drop2 else 1)),
+                       bias2=bpost(i, 1) if drop2 else 0, R=_p(Lw["sa"]), ldr=D, p_drop=ph, seed=seed + 4 * i + 2)
+                nxt = ("Wvt", "bvt", D) if i + 1 == self.n_layers else (f"L{i + 1}.Wqkv", f"L{i + 1}.bqkv", 3 * D)
+                t2 = slot(nxt[2])
+                tails[nxt[0]] = t2
+                lo2 = P.ptr(nxt[0], "Pl") if (sel is None or sel(nxt[0])) else 0
+                _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y2"]), ref(i, 2), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), 0, _p(ws["h"][i + 1]), ref(i, 3),
+                                              _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, P.ptr(nxt[0], "Pb"), lo2, D, nxt[2], P.ptr(nxt[1]), t2, st), "ln_fwd_cen")
+                continue
             # K5: q|k|v projections as one GEMM
             o.gemm(_p(h), P.ptr(pre + "Wqkv", wsrc), _p(Lw["qkv"]), T, 3 * D, D, D, D, 3 * D, bias=bias_of(pre + "Wqkv", pre + "bqkv", _p(h), D, 3 * D),
                    B2=lo(pre + "Wqkv"), b2_col0=v_col0)
             # K6: attention
             _lib.check(lib.dic_attn_fwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(Lw["ctx"]), N, Tk, self.n_heads, 64, pa, seed + 4 * i + 1, st), "attn_fwd")
-            if cen:
-                # K7 / K8 on the centred residual stream: y1, y2 hold bf16(sum - predicted mean row), the residual operands bf16(h - h_ref) / bf16(sa - sa_ref)
-                h_ref = zero_ref if i == 0 else ref(i - 1, 3)
-                o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D,
-                       bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D, resid=(h_ref, ref(i, 0), 0, 1)), R=_p(h) if i == 0 else _p(ws["hc"][i]), ldr=D)
-                _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y1"]), ref(i, 0), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["sac"]), ref(i, 1),
-                                              _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd_cen")
-                o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU,
-                       bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd), aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
-                drop2 = ph > 0.0
-                o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D,
-                       bias=bias_of(pre + "W2", pre + "b2", _p(Lw["g"]), Hd, D, resid=(ref(i, 1), ref(i, 2), bpost(i, 1) if drop2 else 0, 0 if drop2 else 1)),
-                       bias2=bpost(i, 1) if drop2 else 0, R=_p(Lw["sac"]), ldr=D, p_drop=ph, seed=seed + 4 * i + 2)
-                last = i + 1 == self.n_layers
-                _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y2"]), ref(i, 2), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]),
-                                              0 if last else _p(ws["hc"][i + 1]), 0 if last else ref(i, 3), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd_cen")
-                continue
             # K7: out-proj + bias + residual, then LayerNorm
             o.gemm(_p(Lw["ctx"]), P.ptr(pre + "Wo", wsrc), _p(Lw["y1"]), T, D, D, D, D, D, bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D), R=_p(ws["h32"][i]) if r32 else _p(h), ldr=D,
                    B2=lo(pre + "Wo"), out_f32=of)
@@ -541,7 +589,8 @@ class Denoiser:
             else:
                 _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y2"]), P.ptr(pre + "ln2g"), P.ptr(pre + "ln2b"), _p(ws["h"][i + 1]), _p(Lw["m2"]), _p(Lw["r2"]), T, D, LN_EPS, st), "ln_fwd")
         # K9: MLM-head transform: Linear -> GELU -> LayerNorm
-        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=bias_of("Wvt", "bvt", _p(ws["h"][-1]), D, D), B2=lo("Wvt"), out_f32=int(self.uvt32))
+        o.gemm(_p(ws["h"][-1]), P.ptr("Wvt", wsrc), _p(ws["uvt"]), T, D, D, D, D, D, bias=bias_of("Wvt", "bvt", _p(ws["h"][-1]), D, D, bias_ptr=tails.pop("Wvt", None)),
+               B2=lo("Wvt"), out_f32=int(self.uvt32))
         _lib.check(lib.dic_gelu_ln_fwd(self.dt_u, _p(ws["uvt"]), P.ptr("vln_g"), P.ptr("vln_b"), _p(ws["x_out"]), _p(ws["mv"]), _p(ws["rv"]), T, D, LN_EPS, st), "gelu_ln_fwd")
         self._saved = ws
         return ws["x_out"][:N]
@@ -585,12 +634,16 @@ class Denoiser:
         # Each side launch is handed over as soon as its inputs exist (one event on the main stream per hand-over; batching the hand-overs
         # to two per layer saved events but started the side work later: 1.5 % slower, round 2).
         pending = []
+        # (the hand-over events stay alive until the backward returns: under hipGraph capture a destroyed event's handle is reused by the next one,
+        # and a step with ~40 more hand-overs than before replayed with the embedding gradients computed too early -- round 5)
+        evs = []
 
         def flush_side():
             if not pending:
                 return
             if use_side:
                 ev = torch.cuda.Event()
+                evs.append(ev)
                 ev.record(main)
                 side.wait_event(ev)
                 o.stream = side.cuda_stream
@@ -631,16 +684,36 @@ class Denoiser:
             arr0 = (_lib.WgradItem * len(batches[0]))(*batches[0])
             if len(batches[0]) > 4 and lib.dic_wgrad_group_ws_bytes(arr0, len(batches[0]), T, cap_) > skcap * 4:
                 batches = [batches[0][:4], batches[0][4:]]        # (a two-layer group whose K cut needs more slab space than the workspace has: one launch per layer)
-            for b_ in batches:
-                arr = (_lib.WgradItem * len(b_))(*b_)
+            arrs = [(_lib.WgradItem * len(b_))(*b_) for b_ in batches]
+            todo = list(rank1)
+            rank1.clear()
 
-                def launch(arr=arr, n_items=len(b_)):
-                    _lib.check(lib.dic_wgrad_group(arr, n_items, T, skw, skcap * 4, cap_, o.stream), "wgrad_group")
+            def launch():          # ONE hand-over to the weight-gradient stream: the group launch(es), then the rank-one completions they feed
+                for arr in arrs:
+                    _lib.check(lib.dic_wgrad_group(arr, len(arr), T, skw, skcap * 4, cap_, o.stream), "wgrad_group")
+                for dW_, db_, xr_, M_, N_ in todo:
+                    _lib.check(lib.dic_rank1_add(dW_, db_, xr_, M_, N_, o.stream), "rank1_add")
+            on_side(launch)
+
+        rank1 = []                                    # (dW, db, x_ref, M, N): weight gradients whose X was stored centred
+
+        def flush_rank1():
+            """dW += db x_ref^T for the Linears that read a CENTRED tensor (X = X_c + 1 x_ref^T; the GEMM contracted dY with X_c): behind
+            the launch that wrote dW and db, on the same stream."""
+            todo = list(rank1)
+            rank1.clear()
+            if todo:
+                def launch():
+                    for dW_, db_, xr_, M_, N_ in todo:
+                        _lib.check(lib.dic_rank1_add(dW_, db_, xr_, M_, N_, o.stream), "rank1_add")
                 on_side(launch)
 
-        def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None):
+        def wgrad(dY, X, slot, M, N, lda, ldb, bias_slot=None, x_ref=0, db_slot=None):
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
-            bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum)."""
+            bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum).
+            x_ref: X holds bf16(input - x_ref) (centred stream): dW is completed by db x_ref^T (db: the gradient of bias_slot / db_slot)."""
+            if x_ref:
+                rank1.append((P.ptr(slot, "G"), P.ptr(bias_slot if bias_slot is not None else db_slot, "G"), x_ref, M, N))
             if group and M % 256 == 0 and N % 8 == 0 and (gmode in ("1", "pair") or slot.endswith(("Wo", "Wqkv"))):
                 items.append(_lib.WgradItem(dY=dY, ldy=lda, X=X, ldx=ldb, dW=P.ptr(slot, "G"), db=P.ptr(bias_slot, "G") if bias_slot is not None else 0, M=M, N=N))
                 return
@@ -655,6 +728,7 @@ class Denoiser:
                 o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0,
                        colsum_out=cs, tile=tile, cu_cap=OPT.wgrad_cu_cap if use_side else 0)
             on_side(launch)
+            flush_rank1()
             if bias_slot is not None and not self.bf16:
                 colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
 
@@ -689,6 +763,7 @@ class Denoiser:
                 if layer_done is not None and jj < self.n_layers:
                     if use_side:
                         ev = torch.cuda.Event()
+                        evs.append(ev)
                         ev.record(main)                   # the LayerNorm / bias gradients of this layer come from the main stream
                         side.wait_event(ev)
                         with torch.cuda.stream(side):
@@ -704,7 +779,9 @@ class Denoiser:
         dyb = ws["dy"][sp]
         _lib.check(lib.dic_gelu_ln_bwd(self.dt_u, _p(dx), _p(ws["uvt"]), P.ptr("vln_g"), _p(ws["mv"]), _p(ws["rv"]), _p(dyb), parts[2 * sp], NPART, T, D, st), "gelu_ln_bwd")
         fold(parts[2 * sp], 3 * D, P.ptr("vln_g", "G"))                                      # [vln_g | vln_b | bvt]
-        wgrad(_p(dyb), _p(ws["h"][-1]), "Wvt", D, D, D, D)
+        cenb = bool(ws.get("cen_fwd")) and OPT.cen_operand
+        xref = (lambda i_, j_: ws["refs"].data_ptr() + ((i_ * 4 + j_) * D) * 4) if cenb else (lambda i_, j_: 0)
+        wgrad(_p(dyb), _p(ws["h"][-1]), "Wvt", D, D, D, D, x_ref=xref(nl - 1, 3), db_slot="bvt")
         finish_layer(nl)
         dH, dHn = ws["dHa"], ws["dHb"]
         o.gemm(_p(dyb), P.ptr("Wvt", wsrc), _p(dH), T, D, D, D, D, D, b_km=1)
@@ -728,7 +805,7 @@ class Denoiser:
             wgrad(_p(dyd), _p(Lw["g"]), pre + "W2", D, Hd, D, Hd)
             o.gemm(_p(dyd), P.ptr(pre + "W2", wsrc), _p(du_), T, Hd, D, D, Hd, Hd, b_km=1, epi=EPI_MUL_AUX if ws["gelu_d"] else EPI_GELU_BWD,
                    aux=_p(Lw["u"]), ldaux=Hd)
-            wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1")                                # dW1 (+ db1)
+            wgrad(_p(du_), _p(Lw["sa"]), pre + "W1", Hd, D, Hd, D, bias_slot=pre + "b1", x_ref=xref(i, 1))             # dW1 (+ db1)
             if not pair:
                 flush_group()                         # the two FFN gradients go out now (72 tiles), out-proj + qkv at the end of the layer (36):
             flush_side()                              # one launch per layer starts the side stream too late to hide behind this layer's chain
@@ -746,7 +823,7 @@ class Denoiser:
             o.gemm(_p(dy1_), P.ptr(pre + "Wo", wsrc), _p(ws["dctx"]), T, D, D, D, D, D, b_km=1)
             _lib.check(lib.dic_attn_bwd(self.dt, _p(Lw["qkv"]), _p(ws["kmask"]), _p(ws["dctx"]), _p(dqkv_), N, Tk, self.n_heads, 64, pa,
                                         seed + 4 * i + 1, st), "attn_bwd")
-            wgrad(_p(dqkv_), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D, bias_slot=pre + "bqkv")                           # dWqkv (+ dbqkv)
+            wgrad(_p(dqkv_), _p(h), pre + "Wqkv", 3 * D, D, 3 * D, D, bias_slot=pre + "bqkv", x_ref=xref(i - 1, 3) if i > 0 else 0)   # dWqkv (+ dbqkv)
             o.gemm(_p(dqkv_), P.ptr(pre + "Wqkv", wsrc), _p(dHn), T, D, 3 * D, 3 * D, D, D, b_km=1, R=_p(dy1_), ldr=D)
             dH, dHn = dHn, dH
             finish_layer(i)

@@ -39,7 +39,9 @@ class Options:
     uvt32: bool = True               # bf16 engines keep the MLM-head pre-activation in fp32
     split_set: str = "auto"          # which forward Linears take the lo-weight correction: "auto" (bf16: all but FFN lin1; bf16w: all) | "all" | "vo2t"
     lo_row_stride: int = 16          # rows sampled for the mean row of a Linear's input: every 16th
+    qkv_pred: bool = True            # q|k|v of layers >= 1: the mean row comes PREDICTED out of the LayerNorm launch that writes their input (dic_ln_fwd_cen tail)
     cen: bool = True                 # parity mode: centred bf16 residual stream + dic_lin_prep (False: round 4's fp32 residual stream + dic_lo_mean_bias)
+    cen_operand: bool = True         # the centred tensor is ALSO the next Linear's MFMA operand (its bias carries W h_ref); False: a separate uncentred operand copy
     res32: str = "auto"              # fp32 residual stream: "auto" = the exact form bf16w (and bf16 with cen=False) | "1" | "0"
     sample_raw: bool = True          # sample(): encoder passes without the parity mode's corrections (per-row argmax: no batch mean to protect)
     # ---- step / sampling loop (diffusion.py)

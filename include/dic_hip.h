@@ -41,7 +41,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout or a signature in this header changes; a binding must refuse a library whose dic_version()
  * differs from the DIC_HIP_VERSION it was written against (diffusion-image-captioning_amd/_lib.py does).                          */
-#define DIC_HIP_VERSION 15
+#define DIC_HIP_VERSION 17
 int dic_version(void);
 const char* dic_last_error(void);
 
@@ -361,14 +361,20 @@ int dic_lo_mean_bias(const void* A, int T, int lda, int row_stride, int K, const
  *     bias_post[n] = r_ref[n] - y_ref[n]               -> DicGemmParams.bias2 (behind the dropout); fold_post = 1 (no dropout): added to bias_in instead
  *     r_ref: the reference row of the centred residual operand R_c = bf16(R - r_ref) (NULL: R is stored as it is).
  *     ws: dic_lin_prep_ws_bytes(K) bytes.  Deterministic (slabs of column sums added in a fixed order).
- *   dic_ln_fwd_cen: LayerNorm of y = y_c + y_ref (y_c bf16 [T][768], y_ref fp32 [768]) -> h = bf16(LN(y)) (the next Linear's operand), h_c =
- *     bf16(LN(y) - h_ref) (optional: the next residual operand), h_ref = LN(y_ref) (fp32 [768], optional output), mean / rstd as dic_ln_fwd.
+ *   dic_ln_fwd_cen: LayerNorm of y = y_c + y_ref (y_c bf16 [T][768], y_ref fp32 [768]) -> h = bf16(LN(y)) (optional) and / or h_c =
+ *     bf16(LN(y) - h_ref) (optional) with h_ref = LN(y_ref) (fp32 [768], optional output), mean / rstd as dic_ln_fwd.  The shipped engine writes
+ *     ONLY h_c: it is the residual operand of the next residual GEMM AND the MFMA operand of the next Linear, whose bias then carries W h_ref:
+ *     next_lo / next_hi (optional, bf16 [next_n][next_ldb], the halves of that Linear's fp32 weight): next_bias_out[n] = next_bias[n] +
+ *     (next_lo [+ next_hi])[n] . h_ref, computed inside this launch (one output per wave).  Its weight gradient needs dic_rank1_add.
  *   dic_ln_bwd_cen: dic_ln_bwd (bf16) with y given as (y_c, y_ref).                                                                             */
 size_t dic_lin_prep_ws_bytes(int K);
 int dic_lin_prep(const void* A, int T, int lda, int row_stride, int K, const void* w_hi, const void* w_lo, int ldb, int N, const float* bias,
                  const float* r_ref, int fold_post, float* bias_in, float* bias_post, float* y_ref, void* ws, void* stream);
 int dic_ln_fwd_cen(const void* y_c, const float* y_ref, const float* gamma, const float* beta, void* h, void* h_c, float* h_ref, float* mean,
-                   float* rstd, int T, int D, float eps, void* stream);
+                   float* rstd, int T, int D, float eps, const void* next_hi, const void* next_lo, int next_ldb, int next_n, const float* next_bias,
+                   float* next_bias_out, void* stream);
+/* dW[m][n] += db[m] * x_ref[n] (fp32): completes a weight gradient whose GEMM contracted dY with the CENTRED input X_c = X - 1 x_ref^T. */
+int dic_rank1_add(float* dW, const float* db, const float* x_ref, int M, int N, void* stream);
 int dic_ln_bwd_cen(const void* dh, const void* y_c, const float* y_ref, const float* gamma, const float* mean, const float* rstd, void* dx,
                    void* dx_drop, float p_drop, uint64_t seed, float* partial, int n_partial_blocks, int T, int D, void* stream);
 

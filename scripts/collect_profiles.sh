@@ -26,15 +26,13 @@ TILE=256 python scripts/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm
 COLD=1 TILE=256 python scripts/gemm_bench.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_microbench_cold.txt
 (for tk in 18 34; do echo "Tk=$tk"; TK=$tk python scripts/attn_bench.py 2>&1 | grep p_drop; done) > $O/${TAG}_attn_microbench.txt
 python scripts/gemm_in_step.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16.txt
-python scripts/gemm_in_step.py --dtype bf16m 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16m.txt
+python scripts/gemm_in_step.py --dtype bf16r 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16r.txt
 python scripts/gemm_in_step.py --dtype bf16w 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16w.txt
 timeout 300 python scripts/experiments/w4a_check.py time 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_w4a_check.txt
-bash scripts/experiments/power_probe.sh > $O/${TAG}_power_probe.txt 2>&1
+[ -f abl/libdic_clk.so ] && timeout 900 python scripts/power_ab.py --steps 400 --pin 1900 > $O/${TAG}_power_ab.txt 2>&1
 python bench.py --quick --dtype bf16w 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16w.json
-python bench.py --dtype bf16m --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16m.json
+python bench.py --quick --dtype bf16r 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16r.json
 timeout 900 python scripts/experiments/mode_trajectory_probe.py --time 2>&1 | grep -v amdgpu.ids > $O/${TAG}_mode_trajectory.txt
 # loss distance of the bf16 engines from fp32 ALONG a training run (which lo halves, which rounding points): DESIGN.md section 4
-timeout 900 python scripts/experiments/split_alloc_probe.py --only "none,all,default" --trajectory 1,2,3,5,7,10,15,20,30,40,60,80,120,160,240,320,480,640 2>&1 | grep -v amdgpu.ids > $O/${TAG}_split_alloc_trajectory_dense.txt
-timeout 300 python scripts/experiments/collapse_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_collapse_probe_current.txt
 if [ -f ab/libdic_trace.so ]; then DIC_HIP_LIB=$R/ab/libdic_trace.so python scripts/experiments/gemm_trace.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_phase_trace.txt; fi
 ls -la $O/${TAG}_*

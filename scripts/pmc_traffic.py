@@ -29,7 +29,7 @@ for k in names:
     n = max(fetch.get(k, [0, 0])[0], write.get(k, [0, 0])[0])
     f, w = fetch.get(k, [0, 0.0])[1], write.get(k, [0, 0.0])[1]
     tot_f += f; tot_w += w
-    if "gemm_bf16_kernel" in k or "gemm_kernel" in k or "wgrad_group_kernel" in k:      # = the dic_gemm / dic_wgrad_group calls bench.py counts
+    if "gemm_bf16_kernel" in k or "gemm_kernel" in k or "wgrad_group_kernel" in k or "gemm_w4a_kernel" in k:      # = the dic_gemm / dic_wgrad_group calls bench.py counts
         gemm["launches"] += n; gemm["fetch_kb"] += f; gemm["write_kb"] += w
     if "reduce_slabs_kernel" in k or "wgrad_group_fold_kernel" in k:
         folds["launches"] += n; folds["fetch_kb"] += f; folds["write_kb"] += w

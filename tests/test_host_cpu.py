@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(dic._lib.EXPORTS) == declared
-    assert L.dic_version() == dic._lib.ABI_VERSION == 15
+    assert L.dic_version() == dic._lib.ABI_VERSION == 17
 
 
 def test_gemm_params_ctypes_mirror_matches_the_header_struct():
@@ -63,7 +63,7 @@ def test_workspace_size_queries():
     assert L.dic_gemm_split_ws_bytes(768, 768, 1, 0) == 0
     assert L.dic_gemm_split_ws_bytes(3072, 768, 7, 1) == 7 * (3072 * 768 + 3072) * 4
     assert L.dic_ce_n_partials(30522, 128) == 2 * 239 and L.dic_ce_n_partials(30522, 256) == 4 * 120
-    assert L.dic_ce_partial_bytes(16384, 30522, 256) == 16384 * 480 * 16
+    assert L.dic_ce_partial_bytes(16384, 30522, 256) == 17384 * 480 * 16
     assert L.dic_colsum_ws_bytes(0, 512, 2304) == 0                      # fp32, <= 1024 rows: single launch, no workspace
     assert L.dic_colsum_ws_bytes(1, 18432, 768) == 64 * 768 * 4
     assert L.dic_ln_partial_bytes(512, 3, 768) == 512 * 3 * 768 * 4
@@ -532,7 +532,7 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     import dataclasses
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
-                   head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, cen=True, res32="auto", sample_raw=True, streamed_adamw=True,
+                   head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, qkv_pred=True, cen=True, cen_operand=True, res32="auto", sample_raw=True, streamed_adamw=True,
                    sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x73, gemm_two_heights=False, gemm_variant=0, dp_group=3,
                    dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=300)
     assert dataclasses.asdict(opts.Options()) == shipped
