@@ -63,7 +63,7 @@ def test_workspace_size_queries():
     assert L.dic_gemm_split_ws_bytes(768, 768, 1, 0) == 0
     assert L.dic_gemm_split_ws_bytes(3072, 768, 7, 1) == 7 * (3072 * 768 + 3072) * 4
     assert L.dic_ce_n_partials(30522, 128) == 2 * 239 and L.dic_ce_n_partials(30522, 256) == 4 * 120
-    assert L.dic_ce_partial_bytes(16384, 30522, 256) == 17384 * 480 * 16
+    assert L.dic_ce_partial_bytes(16384, 30522, 256) == 16384 * 480 * 16
     assert L.dic_colsum_ws_bytes(0, 512, 2304) == 0                      # fp32, <= 1024 rows: single launch, no workspace
     assert L.dic_colsum_ws_bytes(1, 18432, 768) == 64 * 768 * 4
     assert L.dic_ln_partial_bytes(512, 3, 768) == 512 * 3 * 768 * 4
