@@ -5,7 +5,7 @@ One process per arm (the library's switches are process-global); each arm loops 
   (c) ms per step, mean socket power, rocm-smi shader clock, JOULES per step = mean power x step time;
   (a) with the clock-probe build (abl/libdic_clk.so, scripts/build_variant.sh clk "-DDIC_CLOCK_PROBE"): the shader clock realised INSIDE every GEMM launch
       of the step (s_memtime / s_memrealtime stamped by workgroup 0 at its start and end), averaged per kernel shape, next to that launch's duration.
-Arms: the 8-wave kernel everywhere (shipped) / the four-wave asm kernel for every eligible launch (options.gemm_w4a), each in the raw engine (what round 4
+Arms: the 8-wave kernel everywhere (the default of rounds 1-4) / the four-wave asm kernel for every eligible launch (options.gemm_w4a), each in the raw engine (what round 4
 measured) -- and, when --pin is given, again under a pinned clock (b): `rocm-smi --setperfdeterminism MHZ` (falls back to --setsclk / a lowered power cap;
 prints which one the box accepted, or that it refused all of them).
 
@@ -102,8 +102,8 @@ def main():
 
     def run_arms(label):
         res = {}
-        for name, opts in (("8-wave kernel (shipped)", ""), ("four-wave asm kernel, every eligible launch", "gemm_w4a=1"),
-                           ("8-wave kernel (shipped), again", ""), ("four-wave asm kernel, again", "gemm_w4a=1")):
+        for name, opts in (("8-wave kernel everywhere", "gemm_w4a=0,sample_w4a=0"), ("four-wave asm kernel, every eligible launch", "gemm_w4a=1,gemm_w4a_mask=0xff"),
+                           ("8-wave kernel everywhere, again", "gemm_w4a=0,sample_w4a=0"), ("four-wave asm kernel, again", "gemm_w4a=1,gemm_w4a_mask=0xff")):
             env = dict(os.environ, DIC_OPTIONS=opts)
             if have_probe:
                 env["DIC_HIP_LIB"] = clk_lib
