@@ -16,7 +16,7 @@ _AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another bui
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
-ABI_VERSION = 17          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
+ABI_VERSION = 18          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
 EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [

@@ -1998,7 +1998,8 @@ extern "C" int dic_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_rows")) g_rows = value ? 1 : 0;
     else if (!strcmp(name, "gemm_two_heights")) g_two_heights = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4a")) g_w4a = value ? 1 : 0;
-    else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0xFF;
+    else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0x3FF;
+    else if (!strcmp(name, "gemm_w4a_rows")) { if (value != 0 && value != 224 && value != 256) { dic_set_error("dic_set_option: gemm_w4a_rows is 0 (per launch), 224 or 256"); return 1007; } g_w4a_rows = value; }
     else if (!strcmp(name, "gemm_variant")) return dic_gemm_set_variant(value);
     else { dic_set_error("dic_set_option: unknown option"); return 1007; }
     return 0;

@@ -467,6 +467,8 @@ class Denoiser:
         keep_u = torch.is_grad_enabled()            # the FFN pre-activation is only read by the backward: forward-only calls (no_grad) skip its store
         ws["has_u"] = keep_u
         gelu_d = ws["gelu_d"] = self.bf16 and OPT.gelu_d and not OPT.gemm_v1          # Lw["u"] then holds gelu'(u), not u
+        # forward-only calls (sampling, validation): nothing reads gelu'(u), so the epilogue that also evaluates it is not used (same g, bit for bit)
+        gelu_epi = EPI_BIAS_GELU_D if (gelu_d and keep_u) else EPI_BIAS_GELU
         if x_ptr is None:
             if x.data_ptr() != ws["xin"].data_ptr():
                 ws["xin"][:N].copy_(x)
@@ -525,7 +527,7 @@ class Denoiser:
                            bias=bias_of(pre + "Wo", pre + "bo", _p(Lw["ctx"]), D, D, resid=(h_ref, ref(i, 0), 0, 1)), R=_p(h) if i == 0 else _p(ws["hc"][i]), ldr=D)
                     _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y1"]), ref(i, 0), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["sac"]), ref(i, 1),
                                                   _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, 0, 0, 0, 0, 0, 0, st), "ln_fwd_cen")
-                    o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU,
+                    o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=gelu_epi,
                            bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd), aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
                     drop2 = ph > 0.0
                     o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D,
@@ -553,7 +555,7 @@ class Denoiser:
                 lo1 = P.ptr(pre + "W1", "Pl") if (sel is None or sel(pre + "W1")) else 0
                 _lib.check(lib.dic_ln_fwd_cen(_p(Lw["y1"]), ref(i, 0), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), 0, _p(Lw["sa"]), ref(i, 1),
                                               _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, P.ptr(pre + "W1", "Pb"), lo1, D, Hd, P.ptr(pre + "b1"), t1, st), "ln_fwd_cen")
-                o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU,
+                o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=gelu_epi,
                        bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd, bias_ptr=t1) if lo1 else t1, aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd)
                 drop2 = ph > 0.0
                 o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D,
@@ -579,7 +581,7 @@ class Denoiser:
             else:
                 _lib.check(lib.dic_ln_fwd(self.dt, _p(Lw["y1"]), P.ptr(pre + "ln1g"), P.ptr(pre + "ln1b"), _p(Lw["sa"]), _p(Lw["m1"]), _p(Lw["r1"]), T, D, LN_EPS, st), "ln_fwd")
             # K8: FFN
-            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=EPI_BIAS_GELU_D if gelu_d else EPI_BIAS_GELU, bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd),
+            o.gemm(_p(Lw["sa"]), P.ptr(pre + "W1", wsrc), _p(Lw["g"]), T, Hd, D, D, D, Hd, epi=gelu_epi, bias=bias_of(pre + "W1", pre + "b1", _p(Lw["sa"]), D, Hd),
                    aux=_p(Lw["u"]) if keep_u else 0, ldaux=Hd, B2=lo(pre + "W1"))
             o.gemm(_p(Lw["g"]), P.ptr(pre + "W2", wsrc), _p(Lw["y2"]), T, D, Hd, Hd, Hd, D, bias=bias_of(pre + "W2", pre + "b2", _p(Lw["g"]), Hd, D), R=_p(Lw["sa32"]) if r32 else _p(Lw["sa"]), ldr=D,
                    p_drop=ph, seed=seed + 4 * i + 2, B2=lo(pre + "W2"), out_f32=of)

@@ -52,8 +52,10 @@ class Options:
     # ---- C library (pushed through dic_set_option when the library is loaded)
     gemm_w4a: bool = True            # the four-wave asm GEMM for every eligible launch, training included (round 5: 14.76 -> 14.35 ms per step once the
                                      # weight gradients run as one launch per two layers; 18.5 -> 17.1 J per step -- profiles/r05_power_ab.txt)
-    gemm_w4a_mask: int = 0x73        # which (layout, epilogue) forms may take it: bit 4 * b_km + {0 plain, 1 + residual, 2 x aux, 3 dropout + residual};
-                                     # 0x73 = all but the forward dropout + residual form (FFN lin2 in training: 84 vs 81 us, profiles/r05_w4a_mask_ab.txt)
+    gemm_w4a_mask: int = 0x173       # which (layout, epilogue) forms may take it: bit 4 * b_km + {0 plain, 1 + residual, 2 x aux, 3 dropout + residual}, bit 8 GELU
+                                     # (forward-only FFN lin1), bit 9 GELU + GELU' (training FFN lin1).  0x173 = all but the forward dropout + residual form (FFN
+                                     # lin2 in training) and the two-output GELU form: both tie with the 8-wave kernel in the step (profiles/r05_w4a_mask_ab.txt)
+    gemm_w4a_rows: int = 0           # tile height of the asm GEMM: 0 = per launch (256 or 224 rows, by rounds x height), 224 / 256 = forced (A/B measurements)
     gemm_two_heights: bool = False   # two tile heights per launch everywhere
     gemm_variant: int = 0            # measurement builds (-DDIC_GEMM_VARIANTS): 1 ping-pong K loop, 2 four-wave C++ kernel
     # ---- data parallel (parallel.py)
@@ -82,7 +84,7 @@ LEGACY_ENV = {
     "DIC_GEMM_TWO_HEIGHTS": "gemm_two_heights", "DIC_GEMM_PP": "gemm_variant", "DIC_DP_GROUP": "dp_group", "DIC_DP_SINGLE": "dp_single",
     "DIC_DP_CU_CAP": "dp_cu_cap", "DIC_DP_TIMING": "dp_timing", "DIC_FORCE_REDUCER": "force_reducer", "DIC_SAMPLE_RAW": "sample_raw",
 }
-_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_two_heights", "gemm_variant")
+_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_w4a_rows", "gemm_two_heights", "gemm_variant")
 
 
 def _coerce(name: str, text: str):

@@ -41,7 +41,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout or a signature in this header changes; a binding must refuse a library whose dic_version()
  * differs from the DIC_HIP_VERSION it was written against (diffusion-image-captioning_amd/_lib.py does).                          */
-#define DIC_HIP_VERSION 17
+#define DIC_HIP_VERSION 18
 int dic_version(void);
 const char* dic_last_error(void);
 
@@ -144,7 +144,7 @@ size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
  * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
 int dic_gemm_set_variant(int pp);
 /* Every process-global switch of the library by name (the library reads no environment variable): "gemm_w4a" (0 / 1, default 0: the four-wave asm
- * GEMM where eligible), "gemm_w4a_mask" (default 0xFF; bit 4 * b_km + v allows epilogue form v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual), "gemm_two_heights" (default 0), "gemm_rows" (default 1: per-launch tile heights), "gemm_persist" (default 1: persistent grids),
+ * GEMM where eligible), "gemm_w4a_mask" (default 0x3FF; bit 4 * b_km + v allows epilogue form v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual; bit 8: BIAS_GELU / BIAS_GELU_D without aux, bit 9: BIAS_GELU_D with aux -- k-contiguous B only), "gemm_w4a_rows" (default 0: the asm kernel's tile height per launch -- 256 or 224 rows, whichever fills the rounds of resident workgroups better; 224 / 256 force one), "gemm_two_heights" (default 0), "gemm_rows" (default 1: per-launch tile heights), "gemm_persist" (default 1: persistent grids),
  * "gemm_v1" (default 0: bf16 on the register-staged fp32-style kernel), "gemm_variant" (= dic_gemm_set_variant).  Unknown name: 1007.                */
 int dic_set_option(const char* name, int value);
 /* Measurement / test switch (PROCESS-GLOBAL): 1 (default 0; env DIC_GEMM_TWO_HEIGHTS=1 turns it on everywhere) lets a forward GEMM of the 256-column

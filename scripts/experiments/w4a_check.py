@@ -2,13 +2,15 @@
 """The hand-scheduled four-wave GEMM (csrc/gemm_w4a.h, dic_gemm_set_w4a) against the default 8-wave kernel: results on eligible shapes for every
 variant (B k-contiguous / k-major x plain / + residual / x aux; differences beyond 2 bf16 ulp are errors -- the bias is added after the K loop
 instead of before it, so last-bit differences are expected), then timing with hot and cold operands.
-    python scripts/experiments/w4a_check.py [time]"""
+    python scripts/experiments/w4a_check.py [time] [rows=224|256]"""
 import ctypes as C, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 dic = importlib.import_module("diffusion-image-captioning_amd")
 L = dic.lib()
 GP = dic._lib.GemmParams
+ROWS = next((int(x[5:]) for x in sys.argv if x.startswith("rows=")), 0)       # rows=224 | rows=256: force that tile height of the asm kernel (default: per launch)
+assert L.dic_set_option(b"gemm_w4a_rows", ROWS) == 0
 bf = torch.bfloat16
 st = lambda: torch.cuda.current_stream().cuda_stream
 EPI_OF = {"plain": 0, "resid": 0, "mulaux": 7, "dropres": 0}

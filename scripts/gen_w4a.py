@@ -13,7 +13,9 @@ loads), so the two kernels produce the same results (the bias is added after the
 
 Variants (one asm body each): B operand k-contiguous (KC: nn.Linear forward) or k-major (KM: input gradients, read with
 ds_read_b64_tr_b16) x epilogue `plain` (+ bias), `resid` (+ bias + residual R), `mulaux` (x aux, the GELU' factor left by the forward), `dropres` (k-contiguous B
-only: dropout(acc + bias) + R, the mask regenerated bit for bit from common.h's pair hash).
+only: dropout(acc + bias) + R, the mask regenerated bit for bit from common.h's pair hash), `gelu` (k-contiguous B only: C = GELU(acc + bias), the FFN lin1
+forward of a forward-only call) and `gelud` (C = GELU(u), second output aux = GELU'(u), u = acc + bias: the training forward; the instruction sequence is the one
+the compiler emits for common.h's gelu_fast_with_grad4 -- Abramowitz-Stegun 7.1.26 on packed fp32 -- so both kernels produce the same values).
 
 LDS (bytes): A stage 0 [0, 32K), A stage 1 [32K, 64K), B stage 0 [64K, 96K), B stage 1 [96K, 128K), tile table [128K, +16K: 512 tiles x {16 B of A / B / C offsets + first column, 16 B holding the side-input offset}).
 
@@ -52,6 +54,11 @@ V_BOFF = 175             # bias lane offset (bytes)
 V_TBL = 176              # LDS address of the tile table (same in every lane)
 V_RST = 177              # side-input lane offset (bytes)
 V_PAIRB = 242            # dropout: the lane's element-pair index inside the tile
+V_GC = 178               # gelu / gelud: 8 constant pairs (both halves the same value) in v178..v193
+V_GX = 210               # gelu / gelud: the column group's second fragment (4 values) and the scratch pairs of its two pairs (v210..v225)
+V_T2 = 198               # gelud: the second output's 8 packed registers (v198..v205) and its 4 exchange temporaries (v206..v209)
+GELU_CONSTS = [0.3275911 * 0.70710678118654752, -0.72134752044448170, 1.061405429, -1.453152027, 1.421413741, -0.284496736, 0.254829592, 0.3989422804014327]
+GC_K1, GC_NC, GC_A5, GC_A4, GC_A3, GC_A2, GC_A1, GC_PHI = range(8)
 V_LAST = 242             # (v243..v255 stay with the compiler: the statement's ten vector operands live there)
 R_BLOCK = [0, 16, 178, 194, 210, 226, 64, 80]     # first register of side-input block i (16 registers: slab 0 {rows 0-7, rows 8-15}, slab 1 {..})
 
@@ -76,6 +83,7 @@ class Asm:
     def __init__(self):
         self.l = []
         self.lds = []          # tags of the LDS reads issued so far, in order
+        self.vm = []           # tags of the VMEM operations (loads, LDS-DMA pieces, stores) issued so far, in order: one in-order vmcnt
         self.uid = 0
 
     def __call__(self, s):
@@ -95,6 +103,15 @@ class Asm:
         if n < 15:
             self(f"s_waitcnt lgkmcnt({n})")
 
+    def vmem(self, tag, text):
+        self.vm.append(tag)
+        self(text)
+
+    def younger_vm(self, tag):
+        """VMEM operations issued after the last one tagged `tag` (straight-line code only: the caller knows nothing older is in a loop body)"""
+        idx = max(i for i, t in enumerate(self.vm) if t == tag)
+        return len(self.vm) - 1 - idx
+
     def label(self, stem):
         self.uid += 1
         return f"L{stem}{self.uid}_%="
@@ -113,12 +130,17 @@ def mfma(a, i, j, kk, first):
 
 
 class Gen:
-    def __init__(self, bkm, epi):
-        self.bkm, self.epi = bkm, epi
+    def __init__(self, bkm, epi, ni=8):
+        """ni: A fragments per wave = tile height / 32 (8: 256-row tiles; 7: 224-row tiles -- 17 408 tokens are 78 x 224: 234 / 702 / 936 tiles fill
+        1 / 3 / 4 rounds of 256 CUs where 204 / 612 / 816 tiles of 256 rows leave the last round 20-80 % empty)"""
+        assert ni in (7, 8)
+        self.bkm, self.epi, self.ni = bkm, epi, ni
         self.a = Asm()
         self.gen = 0
         self.side = epi in ("resid", "mulaux", "dropres")
         self.drop = epi == "dropres"
+        self.gelu = epi in ("gelu", "gelud")
+        self.two_out = epi == "gelud"
 
     # ---------------------------------------------------------------- fragment reads / DMA
     def read_b(self, j, kk, stage, gen):
@@ -138,15 +160,15 @@ class Gen:
 
     def dma_piece(self, p, stage):
         a = self.a
-        if p < 8:
+        if p < self.ni:                                       # A: ni pieces of 32 rows (4 waves x 8 rows x 128 B)
             a(f"s_add_u32 m0, s{S_M0A}, {A_ST[stage] + p * NW * 1024}")
             a("s_nop 0")
-            a(f"buffer_load_dwordx4 v{V_VOA + p}, s[{S_RSA}:{S_RSA + 3}], s{S_KA} offen lds")
+            a.vmem("dma", f"buffer_load_dwordx4 v{V_VOA + p}, s[{S_RSA}:{S_RSA + 3}], s{S_KA} offen lds")
         else:
-            q = p - 8
+            q = p - self.ni
             a(f"s_add_u32 m0, s{S_M0B}, {(B_ST[stage] - B_ST[0]) + q * 1024}")
             a("s_nop 0")
-            a(f"buffer_load_dwordx4 v{V_VOB + q}, s[{S_RSB}:{S_RSB + 3}], s{S_KB} offen lds")
+            a.vmem("dma", f"buffer_load_dwordx4 v{V_VOB + q}, s[{S_RSB}:{S_RSB + 3}], s{S_KB} offen lds")
 
     def side_load(self, blk, n):
         """load n (0..3) of side-input block blk: slab n >> 1, row half n & 1"""
@@ -156,13 +178,60 @@ class Gen:
         a(f"s_add_u32 s{S_T}, s{S_T}, {128 * (n >> 1)}")
         if n & 1:
             a(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDR8}")
-        a(f"buffer_load_dwordx4 v[{r}:{r + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen")
+        a.vmem(("side", blk), f"buffer_load_dwordx4 v[{r}:{r + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen")
+
+    def gelu_pairs(self, X, D, G, P):
+        """register pairs X[k] (u = acc + bias) -> GELU(u) in place; gelud: GELU'(u) left in D[k].  The arithmetic of common.h gelu_fast_parts2 /
+        gelu_fast_with_grad4, instruction for instruction as the compiler emits it for the 8-wave kernel; the len(X) pairs are interleaved
+        (one wave per SIMD: nothing else hides a dependent instruction's latency, and a transcendental's result may not be read by the very
+        next VALU instruction on gfx940+).  D, G, P: scratch pairs."""
+        a = self.a
+        pr = lambda r: f"v[{r}:{r + 1}]"
+        gc = lambda n: pr(V_GC + 2 * n)
+        R2 = range(len(X))
+        for k in R2:
+            a(f"v_and_b32 v{D[k]}, 0x7fffffff, v{X[k]}")
+            a(f"v_and_b32 v{D[k] + 1}, 0x7fffffff, v{X[k] + 1}")
+        for k in R2:
+            a(f"v_pk_fma_f32 {pr(D[k])}, {pr(D[k])}, {gc(GC_K1)}, 1.0 op_sel_hi:[1,1,0]")       # 1 + p |u| / sqrt 2
+        for k in R2:
+            a(f"v_pk_mul_f32 {pr(G[k])}, {pr(X[k])}, {pr(X[k])}")
+        for k in R2:
+            a(f"v_rcp_f32 v{D[k]}, v{D[k]}")                                                    # t
+            a(f"v_rcp_f32 v{D[k] + 1}, v{D[k] + 1}")
+        for k in R2:
+            a(f"v_pk_mul_f32 {pr(G[k])}, {pr(G[k])}, {gc(GC_NC)}")
+        for k in R2:
+            a(f"v_pk_fma_f32 {pr(P[k])}, {pr(D[k])}, {gc(GC_A5)}, {gc(GC_A4)}")
+        for k in R2:
+            a(f"v_exp_f32 v{G[k]}, v{G[k]}")                                                    # e^{-u^2 / 2}
+            a(f"v_exp_f32 v{G[k] + 1}, v{G[k] + 1}")
+        for c in (GC_A3, GC_A2, GC_A1):
+            for k in R2:
+                a(f"v_pk_fma_f32 {pr(P[k])}, {pr(P[k])}, {pr(D[k])}, {gc(c)}")
+        for k in R2:
+            a(f"v_pk_mul_f32 {pr(P[k])}, {pr(P[k])}, {pr(D[k])} neg_lo:[0,1] neg_hi:[0,1]")     # -(poly t)
+        for k in R2:
+            a(f"v_pk_fma_f32 {pr(P[k])}, {pr(P[k])}, {pr(G[k])}, 1.0 op_sel_hi:[1,1,0]")        # erf(|u| / sqrt 2)
+        for k in R2:
+            a(f"v_bfi_b32 v{P[k]}, s{S_HC1}, v{P[k]}, v{X[k]}")                                 # copysign(., u)
+            a(f"v_bfi_b32 v{P[k] + 1}, s{S_HC1}, v{P[k] + 1}, v{X[k] + 1}")
+        for k in R2:
+            a(f"v_pk_fma_f32 {pr(P[k])}, {pr(P[k])}, 0.5, 0.5 op_sel_hi:[1,0,0]")               # Phi(u)
+        if self.two_out:
+            for k in R2:
+                a(f"v_pk_mul_f32 {pr(D[k])}, {pr(X[k])}, {gc(GC_PHI)}")
+            for k in R2:
+                a(f"v_pk_fma_f32 {pr(D[k])}, {pr(D[k])}, {pr(G[k])}, {pr(P[k])}")               # Phi(u) + u phi(u)
+        for k in R2:
+            a(f"v_pk_mul_f32 {pr(X[k])}, {pr(X[k])}, {pr(P[k])}")
 
     # ---------------------------------------------------------------- one K-step
     def step(self, stage, first=False, n_e=8, bias_loads=False, last_of_tile=False):
         """first: accumulators start from 0.  n_e: vmcnt count of barrier E (None: no wait, only the barrier).  bias_loads: the tile's 8 bias
         quads ride in phase 0.  last_of_tile (side-input variants): no prefetch of the next tile's fragments; the side tile is requested."""
         a = self.a
+        ni = self.ni
         g0 = self.gen
         self.gen += 1
         fill = {}
@@ -171,15 +240,15 @@ class Gen:
             fill.setdefault(key, []).append(f)
         for j in range(8):
             put((j // 2, 2 + j % 2), lambda j=j: self.read_b(j, 1, stage, g0))      # (not the first slots: the previous phase's last MFMAs read this buffer)
-        put((0, 5), lambda: self.read_a(7, 0, stage, g0))                             # the last A(kk0) fragment (its registers were busy until now)
-        for i in range(7):
+        put((0, 5), lambda: self.read_a(ni - 1, 0, stage, g0))                        # the last A(kk0) fragment (its registers were busy until now)
+        for i in range(ni - 1):
             put((i + 1, 5), lambda i=i: self.read_a(i, 1, stage, g0))                 # A(kk1)[i] over A(kk0)[i], half a group after its MFMAs
         if bias_loads:
             for j in range(8):
                 off = (32 * (j >> 1) + 4 * (j & 1)) * 4
-                put((4 + j // 2, j % 2), lambda j=j, off=off: a(
+                put((ni - 4 + j // 2, j % 2), lambda j=j, off=off: a.vmem("bias",
                     f"buffer_load_dwordx4 v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 3}], v{V_BOFF}, s[{S_RSBIAS}:{S_RSBIAS + 3}], 0 offen offset:{off}"))
-        for i in range(8):
+        for i in range(ni):
             if i == 0:
                 a.wait_lds(("B", g0, 0, 7), ("A", g0, 0, 0))
             else:
@@ -194,14 +263,18 @@ class Gen:
             # side-input blocks 0-5 (24 loads) into the first B buffer and the high registers: before barrier E; block 6 (A[0..3]) after group 4
             side_q = [(blk, n) for blk in range(6) for n in range(4)]
         n_side_before_e = len(side_q)
-        for i in range(8):
+        # DMA pieces of K-step k+2 behind barrier E (8 went out in front of it): (group, slot)
+        after_e = ([(6, 5), (6, 6), (6, 7), (7, 1), (7, 2), (7, 3), (7, 4), (7, 5)] if ni == 8 else
+                   [(5, 1), (5, 3), (5, 5), (5, 7), (6, 5), (6, 6), (6, 7)])
+        assert len(after_e) == ni + 8 - 8
+        for i in range(ni):
             slots = {}
 
             def sput(j, f):
                 slots.setdefault(j, []).append(f)
             if i == 0:
                 a.wait_lds(("B", g0, 1, 7), ("A", g0, 1, 0))
-                sput(5, lambda: self.read_a(7, 1, stage, g0))
+                sput(5, lambda: self.read_a(ni - 1, 1, stage, g0))
             elif i == 1:
                 a.wait_lds(("A", g0, 1, 1))
             elif i == 2:
@@ -219,7 +292,9 @@ class Gen:
             if i == 5:
                 assert not side_q
                 if n_e is not None:
-                    a(f"s_waitcnt vmcnt({n_e + n_side_before_e})")   # K-step k+1 has landed (this wave's pieces) ...
+                    # K-step k+1 has landed (this wave's pieces) ...  (the counter has 6 bits: behind a two-output epilogue more than 63 operations are
+                    # younger, and the strongest expressible wait also asks for that epilogue's first stores -- issued microseconds earlier)
+                    a(f"s_waitcnt vmcnt({min(63, n_e + n_side_before_e)})")
                 a("s_barrier")                                # ... barrier E: everybody's
                 if not (last_of_tile and self.side):
                     for j in range(8):
@@ -231,20 +306,19 @@ class Gen:
                 if not (last_of_tile and self.side):
                     for q in range(5):
                         sput(q, lambda q=q: self.read_a(q, 0, stage ^ 1, g0 + 1))
-                for n, p in enumerate(range(8, 11)):
-                    sput(5 + n, lambda p=p: self.dma_piece(p, stage))
             if i == 7:
                 if not (last_of_tile and self.side):
                     sput(0, lambda: self.read_a(5, 0, stage ^ 1, g0 + 1))
-                for n, p in enumerate(range(11, 16)):
-                    sput(1 + n, lambda p=p: self.dma_piece(p, stage))
+            for n, (gi, sl) in enumerate(after_e):
+                if gi == i:
+                    sput(sl, lambda p=8 + n: self.dma_piece(p, stage))
             for j in range(8):
                 mfma(a, i, j, 1, False)
                 for f in slots.get(j, []):
                     f()
         if not (last_of_tile and self.side):
-            self.read_a(6, 0, stage ^ 1, g0 + 1)
-        else:
+            self.read_a(ni - 2, 0, stage ^ 1, g0 + 1)
+        elif ni == 8:
             for n in range(4):
                 self.side_load(7, n)
         a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
@@ -255,13 +329,14 @@ class Gen:
         g0 = self.gen
         for j in range(8):
             self.read_b(j, 0, stage, g0)
-        for i in range(7):
+        for i in range(self.ni - 1):
             self.read_a(i, 0, stage, g0)
 
     # ---------------------------------------------------------------- the whole body
     def body(self):
         a = self.a
         bkm = self.bkm
+        ni = self.ni
         a("s_nop 4")
         a(f"s_load_dwordx16 s[{S_ARG}:{S_ARG + 15}], {OP['karg']}, 0")
         a(f"s_load_dword s{S_LDR}, {OP['karg']}, 64")
@@ -270,8 +345,16 @@ class Gen:
         a(f"v_mov_b32 v{V_BOFF}, {OP['boff']}")
         a(f"v_mov_b32 v{V_RST}, {OP['rst']}")
         a(f"v_mov_b32 v{V_PAIRB}, {OP['pairb']}")
-        a(f"s_mov_b32 s{S_HC1}, 0x7feb352d")
-        a(f"s_mov_b32 s{S_HC2}, 0x846ca68b")
+        if self.gelu:
+            import struct
+            a(f"s_mov_b32 s{S_HC1}, 0x7fffffff")              # (the dropout multipliers' registers: no dropout in these variants) copysign mask
+            for n, c in enumerate(GELU_CONSTS):
+                bits = struct.unpack("<I", struct.pack("<f", c))[0]
+                a(f"v_mov_b32 v{V_GC + 2 * n}, 0x{bits:08x}")
+                a(f"v_mov_b32 v{V_GC + 2 * n + 1}, 0x{bits:08x}")
+        else:
+            a(f"s_mov_b32 s{S_HC1}, 0x7feb352d")
+            a(f"s_mov_b32 s{S_HC2}, 0x846ca68b")
         a(f"v_mov_b32 v{V_AA[0]}, {OP['aA0']}")
         a(f"v_xor_b32 v{V_AA[1]}, 64, {OP['aA0']}")
         a(f"v_mov_b32 v{V_AB[0]}, {OP['aB0']}")
@@ -406,17 +489,19 @@ class Gen:
         a(f"s_mov_b32 s{S_KA}, 0")
         a(f"s_mov_b32 s{S_KB}, 0")
         a("s_nop 4")
-        for p in range(16):
+        for p in range(ni + 8):
             self.dma_piece(p, 0)
         a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
         a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
-        for p in range(16):
+        for p in range(ni + 8):
             self.dma_piece(p, 1)
         a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
         a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
-        a("s_waitcnt vmcnt(16)")
+        a(f"s_waitcnt vmcnt({ni + 8})")
         a("s_barrier")
-        n_epi_vm = 32 + (4 if self.side else 0)              # VMEM operations between a tile's last DMA piece and the next tile's first K-step
+        # VMEM operations between a tile's last DMA piece and the next tile's first K-step: the epilogue's stores (4 per A fragment row) and, with
+        # 8 side blocks, the four loads of the block requested behind the last piece (checked against the generated order below)
+        n_epi_vm = 4 * ni * (2 if self.two_out else 1) + (4 if (self.side and ni == 8) else 0)
         for _ in range(n_epi_vm):
             a(f"buffer_store_dword v{V_T}, v{V_CST}, s[{S_NULL}:{S_NULL + 3}], 0 offen")
         a("s_nop 1")
@@ -458,11 +543,14 @@ class Gen:
         a(f"s_mov_b32 s{S_SOFF}, 0")
         T = V_T
         n_store = 0
-        for i in range(8):
+        for i in range(ni):
             if self.side:
                 if i == 0:
-                    a("s_waitcnt vmcnt(12)")                  # side blocks 0-6 are back (younger: DMA pieces 8-15 of the last step, block 7)
+                    n_y = a.younger_vm(("side", 6))
+                    assert n_y == (12 if ni == 8 else 4), n_y
+                    a(f"s_waitcnt vmcnt({n_y})")              # side blocks 0-6 are back (younger: the DMA pieces issued behind block 6, block 7)
                 if i == 7:
+                    assert a.younger_vm(("side", 7)) == n_store
                     a(f"s_waitcnt vmcnt({n_store})")          # block 7 (everything older than the stores issued so far)
             for slab in range(2):
                 if self.side:
@@ -477,6 +565,29 @@ class Gen:
                         a(f"v_mov_b32_dpp v{L1 + r}, v{T + 16 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
                 # P0 / P1: the lane's 8 consecutive columns of column groups q' = 0 / 1 of the slab (fragments 4 slab + 2 q' + e, e = 0, 1)
                 for qp in range(2):
+                    if self.gelu:
+                        # both fragments (e = 0, 1) of the column group at once: four independent pairs through the GELU arithmetic
+                        XB = V_GX                                  # second fragment's values; scratch pairs of pairs 2, 3 behind it
+                        for e in range(2):
+                            j = 4 * slab + 2 * qp + e
+                            d = acc(i, j)
+                            x0 = T + 8 if e == 0 else XB
+                            for r in range(4):
+                                a(f"v_accvgpr_read_b32 v{x0 + r}, a{d + r}")
+                            a(f"v_pk_add_f32 v[{x0}:{x0 + 1}], v[{x0}:{x0 + 1}], v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 1}]")
+                            a(f"v_pk_add_f32 v[{x0 + 2}:{x0 + 3}], v[{x0 + 2}:{x0 + 3}], v[{V_BIAS + 4 * j + 2}:{V_BIAS + 4 * j + 3}]")
+                        X = [T + 8, T + 10, XB, XB + 2]
+                        D = [T + 16, T + 20, XB + 4, XB + 6]
+                        G = [T + 18, T + 22, XB + 8, XB + 10]
+                        P = [T + 12, T + 14, XB + 12, XB + 14]
+                        self.gelu_pairs(X, D, G, P)
+                        for e in range(2):
+                            a(f"v_cvt_pk_bf16_f32 v{T + 4 * qp + 2 * e}, v{X[2 * e]}, v{X[2 * e] + 1}")
+                            a(f"v_cvt_pk_bf16_f32 v{T + 4 * qp + 2 * e + 1}, v{X[2 * e + 1]}, v{X[2 * e + 1] + 1}")
+                            if self.two_out:
+                                a(f"v_cvt_pk_bf16_f32 v{V_T2 + 4 * qp + 2 * e}, v{D[2 * e]}, v{D[2 * e] + 1}")
+                                a(f"v_cvt_pk_bf16_f32 v{V_T2 + 4 * qp + 2 * e + 1}, v{D[2 * e + 1]}, v{D[2 * e + 1] + 1}")
+                        continue
                     for e in range(2):
                         j = 4 * slab + 2 * qp + e
                         d = acc(i, j)
@@ -532,12 +643,30 @@ class Gen:
                 for r in range(4):
                     a(f"v_mov_b32_dpp v{T + 4 + r}, v{T + 12 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
                 a(f"s_add_u32 s{S_T}, s{S_SOFF}, {128 * slab}")
-                a(f"buffer_store_dwordx4 v[{T}:{T + 3}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen")
+                nt = " nt" if self.gelu else ""            # (the FFN activations: 107 MB per output that nothing reads before the next GEMM -- streaming stores, as in the 8-wave kernel)
+                a.vmem("store", f"buffer_store_dwordx4 v[{T}:{T + 3}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen{nt}")
                 a(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDC8}")
-                a(f"buffer_store_dwordx4 v[{T + 4}:{T + 7}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen")
+                a.vmem("store", f"buffer_store_dwordx4 v[{T + 4}:{T + 7}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen{nt}")
                 a("s_nop 1")
                 n_store += 2
+                if self.two_out:                              # the same exchange and two full-line stores for gelu'(u) -> aux (descriptor / strides of the side input)
+                    U = V_T2
+                    for r in range(4):
+                        a(f"v_mov_b32 v{U + 8 + r}, v{U + r}")
+                    a("s_nop 1")
+                    for r in range(4):
+                        a(f"v_mov_b32_dpp v{U + r}, v{U + 4 + r} row_ror:8 row_mask:0xf bank_mask:0xc")
+                    for r in range(4):
+                        a(f"v_mov_b32_dpp v{U + 4 + r}, v{U + 8 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
+                    a(f"s_mul_i32 s{S_T}, s{S_LDR16}, {i}")
+                    a(f"s_add_u32 s{S_T}, s{S_T}, {128 * slab}")
+                    a.vmem("store", f"buffer_store_dwordx4 v[{U}:{U + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen nt")
+                    a(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDR8}")
+                    a.vmem("store", f"buffer_store_dwordx4 v[{U + 4}:{U + 7}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen nt")
+                    a("s_nop 1")
+                    n_store += 2
             a(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, s{S_LDC16}")
+        assert a.younger_vm("dma") == n_epi_vm, (a.younger_vm("dma"), n_epi_vm)
         # ---- next tile
         a(f"s_sub_u32 s{S_TILE}, s{S_TILE}, 1")
         a(f"s_cmp_eq_u32 s{S_TILE}, 0")
@@ -559,10 +688,10 @@ def main():
         f.write("// operand order: " + " ".join(OPS) + "\n")
         f.write("#define W4A_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(V_LAST + 1)] + [f'"a{i}"' for i in range(256)] +
                                                     [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"vcc"', '"scc"', '"m0"', '"memory"']) + "\n")
-        for bkm in (False, True):
-            for epi in ("plain", "resid", "mulaux") + (() if bkm else ("dropres",)):
-                lines = Gen(bkm, epi).body()
-                name = f"W4A_BODY_{'KM' if bkm else 'KC'}_{epi.upper()}"
+        for ni, bkm in ((8, False), (8, True), (7, False), (7, True)):
+            for epi in ("plain", "resid", "mulaux") + (() if bkm else ("dropres", "gelu", "gelud")):
+                lines = Gen(bkm, epi, ni).body()
+                name = f"W4A_BODY{'' if ni == 8 else ni}_{'KM' if bkm else 'KC'}_{epi.upper()}"
                 f.write(f"#define {name} \\\n")
                 f.write(" \\\n".join('    "%s\\n\\t"' % x for x in lines))
                 f.write("\n")

@@ -205,14 +205,17 @@ def test_gemm_split_weight_second_pass(L, tile, M, N, K, epi):
     assert L.dic_gemm(BF16, 0, 1, 0, C.byref(gp), stream()) != 0
 
 
+@pytest.mark.parametrize("rows", [256, 224])
 @pytest.mark.parametrize("b_km", [0, 1])
-@pytest.mark.parametrize("kind", ["plain", "bias", "resid", "bias_resid", "mulaux", "bias_resid_drop"])
+@pytest.mark.parametrize("kind", ["plain", "bias", "resid", "bias_resid", "mulaux", "bias_resid_drop", "bias_gelu", "bias_gelud"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (768, 512, 384), (2304, 768, 3072), (4352, 2304, 768)])
-def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, N, K, kind, b_km):
+def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, N, K, kind, b_km, rows):
     """dic_gemm_set_w4a(1): eligible launches (bf16, k-contiguous A, M and N multiples of 256, K of 128; AFFINE with optional bias / residual, MUL_AUX)
     run on the hand-scheduled four-wave kernel (csrc/gemm_w4a.h: one generated asm statement per variant).  Every variant against float64 on the
     same operands and against the 8-wave kernel (which adds the bias before the K loop instead of after it: differences of at most 2 bf16 ulp);
-    launches outside its scope (dropout, fp32 output, ragged sizes) must fall through to the 8-wave kernel unchanged."""
+    launches outside its scope (dropout, fp32 output, ragged sizes) must fall through to the 8-wave kernel unchanged.
+    rows: both generated tile heights (dic_set_option gemm_w4a_rows; 0 = chosen per launch).  With 224-row tiles none of the M here is a multiple of the
+    tile height: the last row tile is ragged (32 ... 160 valid rows), its rows >= M must read as zeros and must not be stored (guard rows behind C)."""
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + b_km)
     A = torch.randn(M, K, generator=g) * 0.5
     W = torch.randn(N, K, generator=g) * 0.05
@@ -235,15 +238,40 @@ def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, 
             pytest.skip("dropout exists on the forward (k-contiguous B) launches only")
         kw.update(p_drop=0.1, seed=0xABCDEF0123 + M)
     epi = 7 if kind == "mulaux" else 0
+    auxs = []
+    if "gelu" in kind:        # FFN lin1 forward: C = GELU(u); "gelud" (training): also aux = GELU'(u), u = acc + bias
+        if b_km:
+            pytest.skip("the GELU epilogues exist on the forward (k-contiguous B) launches only")
+        epi = 6 if kind == "bias_gelud" else 1
+        u = exact
+        cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+        exact_d = cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+        exact = u * cdf
     outs = []
     for mode in (0, 1):
-        Cd = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        Cfull = torch.full((M + 8, N), 7.0, dtype=torch.bfloat16, device="cuda")
+        Cd = Cfull[:M]
+        Cd.fill_(float("nan"))
+        if kind == "bias_gelud":
+            Afull = torch.full((M + 8, N), 5.0, dtype=torch.bfloat16, device="cuda")
+            Afull[:M].fill_(float("nan"))
+            kw.update(aux=p(Afull), ldaux=N)
+            auxs.append(Afull)
         prev = L.dic_gemm_set_w4a(mode)
+        assert L.dic_set_option(b"gemm_w4a_rows", rows) == 0 and L.dic_set_option(b"gemm_w4a_mask", 0x3FF) == 0
         try:
             gemm(L, BF16, 0, b_km, epi, C=p(Cd), **kw)
         finally:
             L.dic_gemm_set_w4a(prev)
+            L.dic_set_option(b"gemm_w4a_rows", 0)
+            dic.options.push_to_library(L)
+        assert bool((Cfull[M:] == 7.0).all())
         outs.append(Cd)
+    if kind == "bias_gelud":
+        assert bool((auxs[0][M:] == 5.0).all()) and bool((auxs[1][M:] == 5.0).all())
+        assert relerr(auxs[1][:M].float(), exact_d) < 6e-3
+        dd = (auxs[1][:M].float() - auxs[0][:M].float()).abs()
+        assert int((dd > auxs[0][:M].float().abs() * 2 ** -6 + 2e-3).sum()) == 0
     if "drop" in kind:
         # the mask must be the 8-wave kernel's (ln_bwd regenerates it from the same hash): identical zero pattern of (out - R), kept elements scaled by 1 / 0.9
         kept0, kept1 = (outs[0].float() - Sd.float()) != 0, (outs[1].float() - Sd.float()) != 0

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(dic._lib.EXPORTS) == declared
-    assert L.dic_version() == dic._lib.ABI_VERSION == 17
+    assert L.dic_version() == dic._lib.ABI_VERSION == 18
 
 
 def test_gemm_params_ctypes_mirror_matches_the_header_struct():
@@ -533,7 +533,7 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, qkv_pred=True, cen=True, cen_operand=True, res32="auto", sample_raw=True, streamed_adamw=True,
-                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x73, gemm_two_heights=False, gemm_variant=0, dp_group=3,
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_two_heights=False, gemm_variant=0, dp_group=3,
                    dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=300)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
