@@ -1,14 +1,8 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_ops.py -x -q -k "four_wave" 2>&1 | tail -4 > gpurun_out/w4ag_pytest.txt
-for i in 1 2; do
-  python bench.py --mode sample 2>&1 | tail -1 | cut -c1-300 > gpurun_out/sampleg_mask073_$i.json
-  DIC_OPTIONS=gemm_w4a_mask=0x173 python bench.py --mode sample 2>&1 | tail -1 | cut -c1-300 > gpurun_out/sampleg_mask173_$i.json
-  python bench.py --quick --no-roofline --steps 40 2>&1 | tail -1 | cut -c1-200 > gpurun_out/traing_mask073_$i.json
-  DIC_OPTIONS=gemm_w4a_mask=0x273 python bench.py --quick --no-roofline --steps 40 2>&1 | tail -1 | cut -c1-200 > gpurun_out/traing_mask273_$i.json
-  DIC_OPTIONS=gemm_w4a_mask=0x07b python bench.py --quick --no-roofline --steps 40 2>&1 | tail -1 | cut -c1-200 > gpurun_out/traing_mask07b_$i.json
-done
-python scripts/gemm_in_step.py > gpurun_out/gis_073.txt 2>&1
-DIC_OPTIONS=gemm_w4a_mask=0x273 python scripts/gemm_in_step.py > gpurun_out/gis_273.txt 2>&1
-cat gpurun_out/w4ag_pytest.txt; cat gpurun_out/sampleg_*.json gpurun_out/traing_*.json; cat gpurun_out/gis_073.txt gpurun_out/gis_273.txt
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_gpu.txt
+bash scripts/collect_profiles.sh r05 > gpurun_out/collect.log 2>&1
+python scripts/experiments/tile_rows_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_tile_rows_probe.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/smoke.txt 2>&1
+cat gpurun_out/pytest_gpu.txt; tail -3 gpurun_out/smoke.txt; cut -c1-400 gpurun_out/r05_bench.json
