@@ -680,6 +680,30 @@ class Gen:
         return a.l
 
 
+def lint(lines, name):
+    """Static checks on a generated body: every register inside the ranges the clobber list declares (v243..v255 and s0..s14 belong to the compiler:
+    the statement's operands live there), 64-bit VGPR operands of packed instructions even-aligned, counted waits inside their counters' widths."""
+    import re
+    for ln in lines:
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", ln):
+            lo = int(m.group(1) if m.group(1) is not None else m.group(3))
+            hi = int(m.group(2) if m.group(2) is not None else m.group(3))
+            assert 0 <= lo <= hi <= V_LAST, (name, ln)
+            if ln.startswith("v_pk_") and m.group(1) is not None:
+                assert lo % 2 == 0 and hi == lo + 1, (name, ln)
+        for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", ln):
+            hi = int(m.group(2) if m.group(2) is not None else m.group(3))
+            assert hi <= 255, (name, ln)
+        for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", ln):
+            lo = int(m.group(1) if m.group(1) is not None else m.group(3))
+            hi = int(m.group(2) if m.group(2) is not None else m.group(3))
+            assert all((r in S_EXTRA) or (S0 <= r <= S_LAST) for r in range(lo, hi + 1)), (name, ln)
+        m = re.search(r"vmcnt\((\d+)\)", ln)
+        assert m is None or int(m.group(1)) <= 63, (name, ln)
+        m = re.search(r"lgkmcnt\((\d+)\)", ln)
+        assert m is None or int(m.group(1)) <= 15, (name, ln)
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
     with open(out, "w") as f:
@@ -691,6 +715,7 @@ def main():
         for ni, bkm in ((8, False), (8, True), (7, False), (7, True)):
             for epi in ("plain", "resid", "mulaux") + (() if bkm else ("dropres", "gelu", "gelud")):
                 lines = Gen(bkm, epi, ni).body()
+                lint(lines, (ni, bkm, epi))
                 name = f"W4A_BODY{'' if ni == 8 else ni}_{'KM' if bkm else 'KC'}_{epi.upper()}"
                 f.write(f"#define {name} \\\n")
                 f.write(" \\\n".join('    "%s\\n\\t"' % x for x in lines))
