@@ -437,13 +437,54 @@ def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_pat
     want = open(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "gemm_w4a_asm.inc")).read()
     got = open(out).read()
     assert got == want, "regenerate: python scripts/gen_w4a.py diffusion-image-captioning_amd/csrc/gemm_w4a_asm.inc"
-    bodies = re.findall(r"#define (W4A_BODY_\w+) \\\n((?:    \".*\n?)+)", got)
-    assert len(bodies) >= 6
+    bodies = re.findall(r"#define (W4A_BODY7?_\w+) \\\n((?:    \".*\n?)+)", got)
+    assert len(bodies) == 18                                   # two tile heights x (k-contiguous B: 6 epilogues, k-major B: 3)
     for name, text in bodies:
-        assert text.count("v_mfma_f32_16x16x32_bf16") % 256 == 0 and text.count("v_mfma_f32_16x16x32_bf16") >= 6 * 128, name      # whole K-steps only
+        per_pair = 2 * 2 * (7 if name.startswith("W4A_BODY7") else 8) * 8          # MFMAs of two K-steps
+        assert text.count("v_mfma_f32_16x16x32_bf16") % per_pair == 0 and text.count("v_mfma_f32_16x16x32_bf16") >= 3 * per_pair, name      # whole K-steps only
         assert all(int(n) <= 15 for n in re.findall(r"lgkmcnt\((\d+)\)", text)), name
         assert all(int(n) <= 63 for n in re.findall(r"vmcnt\((\d+)\)", text)), name
         assert text.count("s_barrier") >= 2 * 6, name
+
+
+def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic_execution():
+    """scripts/w4a_hazard_check.py executes every generated body through its real control flow (several K / tile counts) and checks, under the
+    weakest completion assumption the ISA allows, that no register is read before its load was waited for, that an LDS stage is read only
+    after publication (vmcnt wait + barrier) and refilled only after its reads returned (lgkmcnt wait + barrier), and that nothing is left
+    outstanding.  The checker itself is checked by mutation: every `vmcnt` weakened by one, a weakened `lgkmcnt` in front of an MFMA group
+    and a dropped barrier must each be reported."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import gen_w4a as G
+        import w4a_hazard_check as H
+    finally:
+        sys.path.pop(0)
+    assert H.check_all() == 18 * 4
+    for ni, bkm, epi in ((8, False, "plain"), (7, True, "resid"), (7, False, "gelud")):
+        lines = G.Gen(bkm, epi, ni).body()
+        H.Sim(lines, ni, 384, 2).run()
+
+        def mutated(pred, mut, nth):
+            idx = [i for i, l in enumerate(lines) if pred(l)]
+            out = list(lines)
+            new = mut(out[idx[nth]])
+            if new is None:
+                del out[idx[nth]]
+            else:
+                out[idx[nth]] = new
+            try:
+                H.Sim(out, ni, 384, 2).run()
+            except H.Violation:
+                return True
+            return False
+        is_vm = lambda l: bool(re.search(r"vmcnt\(\d+\)", l)) and "lgkmcnt" not in l
+        n_vm = sum(map(is_vm, lines))
+        assert n_vm >= 7 and all(mutated(is_vm, lambda l: re.sub(r"vmcnt\((\d+)\)", lambda m: f"vmcnt({int(m.group(1)) + 1})", l), k) for k in range(n_vm)), (ni, bkm, epi)
+        is_lg = lambda l: bool(re.fullmatch(r"s_waitcnt lgkmcnt\(\d+\)", l))
+        caught = sum(mutated(is_lg, lambda l: re.sub(r"\((\d+)\)", lambda m: f"({int(m.group(1)) + 1})", l), k) for k in range(sum(map(is_lg, lines))))
+        assert caught >= 0.75 * sum(map(is_lg, lines)), (ni, bkm, epi, caught)        # (a few waits are stricter than their consumer needs)
+        assert mutated(lambda l: l == "s_barrier", lambda l: None, 1) and mutated(lambda l: l == "s_barrier", lambda l: None, 4), (ni, bkm, epi)
 
 
 def _run_bench(argv, env_extra=None, timeout=600):
