@@ -16,11 +16,11 @@ _AB_LIB = os.environ.get("DIC_HIP_LIB")      # measurement aid: load another bui
 SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
 
 DIC_F32, DIC_BF16 = 0, 1
-ABI_VERSION = 18          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
+ABI_VERSION = 19          # include/dic_hip.h DIC_HIP_VERSION the struct mirrors / argtypes below were written for; lib() refuses any other library
 EPI_AFFINE, EPI_BIAS_GELU, EPI_GELU_BWD, EPI_CE_PARTIAL, EPI_CE_DLOGITS, EPI_CE_EXP, EPI_BIAS_GELU_D, EPI_MUL_AUX = range(8)
 
 EXPORTS = [
-    "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_set_w4a", "dic_gemm_two_heights_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_head_center", "dic_head_center_ws_bytes", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
+    "dic_version", "dic_last_error", "dic_gemm", "dic_gemm_set_two_heights", "dic_gemm_set_w4a", "dic_gemm_two_heights_plan", "dic_gemm_w4a_rows_plan", "dic_ce_combine", "dic_ce_target_logit", "dic_head_center", "dic_head_center_ws_bytes", "dic_ce_exp_combine", "dic_add_rows_scaled", "dic_embed_gather", "dic_qsample",
     "dic_fuse_ln_fwd", "dic_fuse_ln_bwd", "dic_ln_fwd", "dic_ln_fwd_r32", "dic_ln_bwd", "dic_lo_mean_bias", "dic_lo_mean_bias_ws_bytes", "dic_gelu_ln_fwd", "dic_gelu_ln_bwd",
     "dic_attn_fwd", "dic_attn_bwd", "dic_emb_loss", "dic_add_rows", "dic_seg_sum", "dic_cfg_mix_fwd",
     "dic_cfg_mix_bwd", "dic_seq_sum", "dic_colsum", "dic_colsum_pair", "dic_adamw", "dic_adamw_hl", "dic_cast_bf16", "dic_cast_bf16_hl", "dic_probe_tr16", "dic_prof_begin", "dic_prof_end", "dic_prof_algorithmic_bytes", "dic_prof_get",
@@ -123,6 +123,7 @@ def lib():
         L.dic_te_dx0.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
         L.dic_embed_scatter.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
         L.dic_ce_n_partials.argtypes = [C.c_int, C.c_int]
+        L.dic_gemm_w4a_rows_plan.argtypes = [C.c_int] * 4
         L.dic_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmParams), C.c_void_p]
         P, I, F, U64, I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64
         L.dic_ce_combine.argtypes = [P, P, I, I, P, P, P, P]

@@ -2028,6 +2028,13 @@ extern "C" int dic_gemm_two_heights_plan(int M, int N, int K, int cu_cap, int* o
     return 0;
 }
 
+// host-only query (a pure function of its arguments: no device needed): the tile height -- 256 or 224 rows -- the four-wave asm kernel takes for an
+// M x N x K problem on `cus` compute units under the current "gemm_w4a_rows" option (gemm_w4a.h, w4a_pick_ni)
+extern "C" int dic_gemm_w4a_rows_plan(int M, int N, int K, int cus) {
+    if (M <= 0 || N <= 0 || K <= 0 || cus <= 0) { dic_set_error("dic_gemm_w4a_rows_plan: M, N, K, cus must be positive"); return -1; }
+    return 32 * w4a_pick_ni(M, N, K, cus);
+}
+
 // ---- optional per-launch timing (bench.py roofline leg), see launch_timed above
 namespace {
 ProfRec* g_prof = nullptr;

@@ -41,7 +41,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a struct layout or a signature in this header changes; a binding must refuse a library whose dic_version()
  * differs from the DIC_HIP_VERSION it was written against (diffusion-image-captioning_amd/_lib.py does).                          */
-#define DIC_HIP_VERSION 18
+#define DIC_HIP_VERSION 19
 int dic_version(void);
 const char* dic_last_error(void);
 
@@ -161,6 +161,9 @@ int dic_gemm_set_w4a(int on);
 /* host-only: the plan for an M x N x K forward problem on this device -- out[0] / out[1] = 16-row fragments per wave of the tall / the
  * last-round tiles (out[0] == 0: one height), out[2] = rows covered by the tall tiles */
 int dic_gemm_two_heights_plan(int M, int N, int K, int cu_cap, int* out3);
+/* host-only, needs no device: the tile height (256 or 224 rows) the four-wave asm kernel takes for an M x N x K problem on `cus` compute units under the
+ * current "gemm_w4a_rows" option -- rounds of resident workgroups x (16-row fragments per wave + a fixed per-tile cost); -1 on bad arguments            */
+int dic_gemm_w4a_rows_plan(int M, int N, int K, int cus);
 
 /* hipGraph support for the training step (PROCESS-GLOBAL state: one capture at a time).  Kernel arguments are frozen by a capture, but the
  * dropout / noise / timestep seeds, AdamW's bias corrections and the slot the step's losses go to change every step.  While a context is set,

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(dic._lib.EXPORTS) == declared
-    assert L.dic_version() == dic._lib.ABI_VERSION == 18
+    assert L.dic_version() == dic._lib.ABI_VERSION == 19
 
 
 def test_gemm_params_ctypes_mirror_matches_the_header_struct():
@@ -445,6 +445,26 @@ def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_pat
         assert all(int(n) <= 15 for n in re.findall(r"lgkmcnt\((\d+)\)", text)), name
         assert all(int(n) <= 63 for n in re.findall(r"vmcnt\((\d+)\)", text)), name
         assert text.count("s_barrier") >= 2 * 6, name
+
+
+def test_asm_gemm_tile_height_plan_fills_the_rounds_of_resident_workgroups():
+    """Host logic of the two-height asm GEMM (dic_gemm_w4a_rows_plan, a pure function: no device): 224-row tiles where they turn a partly filled last
+    round into a fuller one of shorter tiles -- the step's 17 408 tokens (78 x 224: 234 / 702 / 936 tiles = 1 / 3 / 4 rounds on 256 CUs instead of 204 / 612 /
+    816) and the sampling pass's N = 768 shapes -- 256-row tiles where the shorter ones would add a round (34 816 x 2304: 5 rounds against 6) or where
+    nothing is gained; the option forces either height."""
+    L = dic.lib()
+    plan = lambda M, N, K, cus=256: L.dic_gemm_w4a_rows_plan(M, N, K, cus)
+    assert [plan(17408, n, 768) for n in (768, 2304, 3072)] == [224, 224, 224] and plan(17408, 768, 3072) == 224
+    assert plan(34816, 768, 768) == 224 and plan(34816, 768, 3072) == 224
+    assert plan(34816, 2304, 768) == 256 and plan(34816, 3072, 768) == 256
+    assert plan(256, 256, 256) == 256 and plan(65536, 4096, 4096) == 256           # tiny: one tile; huge: rounds dominate either way, ties keep 256
+    assert plan(17408, 768, 768, cus=64) in (224, 256) and plan(0, 1, 1, 1) == -1
+    try:
+        assert L.dic_set_option(b"gemm_w4a_rows", 256) == 0 and plan(17408, 768, 768) == 256
+        assert L.dic_set_option(b"gemm_w4a_rows", 224) == 0 and plan(34816, 2304, 768) == 224 and plan(128, 256, 256) == 256
+        assert L.dic_set_option(b"gemm_w4a_rows", 192) != 0
+    finally:
+        assert L.dic_set_option(b"gemm_w4a_rows", 0) == 0
 
 
 def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic_execution():
