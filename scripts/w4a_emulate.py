@@ -1,0 +1,535 @@
+#!/usr/bin/env python3
+"""Functional emulator for the generated four-wave GEMM bodies (scripts/gen_w4a.py): runs a body on the CPU, no GPU, no assembler.
+
+scripts/w4a_hazard_check.py proves the TIMING side of a body (every counted wait, both barriers).  This script checks the other half -- addressing and
+arithmetic: it interprets the ~50 gfx950 instructions the generator uses on a register file of one workgroup (4 waves x 64 lanes, 256 VGPRs + 256
+accumulation registers per lane, per-wave scalars, 160 KB of LDS, a flat byte array as global memory), with memory operations completing at issue,
+sets up exactly what the C++ around the asm statement sets up (csrc/gemm_w4a.h: kernel arguments, the tile table in LDS, the per-lane constants), runs
+the body, and compares C (and the second output of the two-output GELU form) with numpy on the same bf16 operands.
+
+What it pins down that nothing else does without a GPU: the swizzled LDS image written by the LDS-DMA against the addresses of the fragment reads
+(ds_read_b128, and ds_read_b64_tr_b16 for k-major B), the MFMA operand / result lane layout against the epilogue's chunk exchange (DPP) and full-line
+stores, ragged last row tiles (rows >= M must read as zeros and must not be stored), the bias / residual / aux / dropout-mask / GELU arithmetic, the
+persistent tile loop's descriptor hand-over from tile to tile.
+
+Instruction semantics are those of the CDNA3 / CDNA4 ISA documents as the shipped kernels rely on them; the two that are not obvious are pinned by GPU tests
+of their own: ds_read_b64_tr_b16 (tests/test_gpu_ops.py::test_tr16_layout_assumption) and the MFMA lane layout (every GEMM parity test).
+
+    python scripts/w4a_emulate.py            (every body on a small problem with a ragged last tile; exit code 1 on the first mismatch)
+"""
+import os
+import re
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_w4a as G  # noqa: E402
+
+NL = 256            # lanes of the workgroup (4 waves x 64)
+U32 = np.uint32
+np.seterr(all="ignore")
+
+
+def bf16_round(x):
+    """fp32 -> bf16 bits (uint32 holding 16 bits), round to nearest even (v_cvt_pk_bf16_f32)"""
+    u = np.asarray(x, dtype=np.float32).view(U32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF
+    return r.astype(U32)
+
+
+def bf16_to_f32(h):
+    return (np.asarray(h, dtype=U32) << 16).view(np.float32)
+
+
+def key_a(row):
+    return (row >> 1) & 7
+
+
+def key_b(row):
+    return ((((row >> 3) & 3) << 1) | ((row >> 1) & 1)) & 7
+
+
+def km_key(k):
+    return 2 * ((k & 3) | (((k >> 3) & 1) << 2))
+
+
+def hash32(x):
+    x = np.asarray(x, dtype=np.uint64)
+    x = (x ^ (x >> 16)) * 0x7FEB352D & 0xFFFFFFFF
+    x = (x ^ (x >> 15)) * 0x846CA68B & 0xFFFFFFFF
+    return (x ^ (x >> 16)) & 0xFFFFFFFF
+
+
+class Emu:
+    LDS_BYTES = 163840
+
+    def __init__(self, lines, operands_v, operands_s, args_bytes, mem):
+        self.lines = lines
+        self.labels = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
+        self.V = np.zeros((256, NL), dtype=U32)
+        self.A = np.zeros((256, NL), dtype=np.float32)
+        self.S = np.zeros((128, 4), dtype=np.uint64)          # per wave
+        self.scc = 0
+        self.vcc = np.zeros(NL, dtype=bool)
+        self.m0 = np.zeros(4, dtype=np.uint64)
+        self.lds = np.zeros(self.LDS_BYTES, dtype=np.uint8)
+        self.mem = mem                                          # flat global memory (np.uint8)
+        self.args = args_bytes
+        self.opv, self.ops = operands_v, operands_s             # "%i" operands: per-lane arrays / per-wave arrays
+        self.n = 0
+
+    # ------------------------------------------------------------------ operand access
+    def lanes(self, per_wave):
+        return np.repeat(np.asarray(per_wave, dtype=np.uint64), 64)
+
+    def src(self, tok, as_float=False):
+        """a 32-bit source operand as a per-lane uint32 array"""
+        tok = tok.strip()
+        m = re.fullmatch(r"v(\d+)", tok)
+        if m:
+            return self.V[int(m.group(1))]
+        m = re.fullmatch(r"s(\d+)", tok)
+        if m:
+            return self.lanes(self.S[int(m.group(1))]).astype(U32)
+        if tok.startswith("%"):
+            name = G.OPS[int(tok[1:])]
+            if name in self.opv:
+                return self.opv[name].astype(U32)
+            return self.lanes(self.ops[name]).astype(U32)
+        if tok == "vcc":
+            return self.vcc.astype(U32)
+        if re.fullmatch(r"-?\d+\.\d+", tok):
+            return np.full(NL, np.float32(float(tok)), dtype=np.float32).view(U32)
+        v = int(tok, 0)
+        if as_float and -16 <= v <= 64:                          # (integer inline constants used as floats do not occur in the generated text)
+            raise ValueError(tok)
+        return np.full(NL, v & 0xFFFFFFFF, dtype=U32)
+
+    def ssrc(self, tok):
+        """a scalar source as a per-wave uint64 array"""
+        tok = tok.strip()
+        m = re.fullmatch(r"s(\d+)", tok)
+        if m:
+            return self.S[int(m.group(1))].copy()
+        if tok.startswith("%"):
+            return np.asarray(self.ops[G.OPS[int(tok[1:])]], dtype=np.uint64)
+        if tok == "m0":
+            return self.m0.copy()
+        return np.full(4, int(tok, 0) & 0xFFFFFFFF, dtype=np.uint64)
+
+    def pair(self, tok, sel_hi=1):
+        """a 64-bit packed-fp32 source: (lo, hi) float32 arrays; sel_hi = 0: the high result also takes the low dword"""
+        tok = tok.strip()
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo = self.V[int(m.group(1))].view(np.float32)
+            hi = self.V[int(m.group(1)) + 1].view(np.float32)
+            return lo, (hi if sel_hi else lo)
+        c = np.full(NL, np.float32(float(tok)), dtype=np.float32)
+        return c, c
+
+    @staticmethod
+    def vrange(tok):
+        m = re.fullmatch(r"[va]\[(\d+):(\d+)\]", tok.strip())
+        if m:
+            return int(m.group(1)), int(m.group(2)) - int(m.group(1)) + 1
+        return int(tok.strip()[1:]), 1
+
+    def desc(self, tok):
+        d = int(re.fullmatch(r"s\[(\d+):(\d+)\]", tok.strip()).group(1))
+        base = (self.S[d] | ((self.S[d + 1] & 0xFFFF) << 32)).astype(np.int64)
+        return self.lanes(base).astype(np.int64), self.lanes(self.S[d + 2]).astype(np.int64)
+
+    # ------------------------------------------------------------------ memory
+    def gather(self, addr, ok, nbytes):
+        out = np.zeros((NL, nbytes), dtype=np.uint8)
+        idx = np.where(ok)[0]
+        if idx.size:
+            a = addr[idx][:, None] + np.arange(nbytes)[None, :]
+            assert a.min() >= 0 and a.max() < self.mem.size, "global address outside the emulated memory"
+            out[idx] = self.mem[a]
+        return out
+
+    def buffer_addr(self, args, rest, nbytes):
+        vaddr = self.src(args[1]).astype(np.int64)
+        base, nrec = self.desc(args[2])
+        soff = self.lanes(self.ssrc(args[3].split()[0])).astype(np.int64)
+        m = re.search(r"offset:(\d+)", rest)
+        imm = int(m.group(1)) if m else 0
+        off = vaddr + imm + soff            # (raw buffers: the scalar offset takes part in the range check -- the kernel's row clipping relies on it, and the
+        return base + off, off, nrec        #  GPU tests with guard rows behind a ragged last tile confirm it)
+
+    # ------------------------------------------------------------------ execution
+    def run(self, max_instr=3_000_000):
+        i, n = 0, len(self.lines)
+        while i < n:
+            i = self.step(i)
+            self.n += 1
+            if self.n > max_instr:
+                raise RuntimeError("does not terminate")
+
+    def step(self, i):
+        ln = self.lines[i]
+        if ln.endswith(":"):
+            return i + 1
+        op, _, rest = ln.partition(" ")
+        args = [a.strip() for a in re.split(r",\s*(?![^\[]*\])", rest)] if rest else []
+        S, V = self.S, self.V
+        # ---------------- control
+        if op in ("s_nop", "s_waitcnt", "s_barrier"):
+            return i + 1
+        if op == "s_branch":
+            return self.labels[args[0]]
+        if op == "s_cbranch_scc0":
+            return self.labels[args[0]] if self.scc == 0 else i + 1
+        if op == "s_cbranch_scc1":
+            return self.labels[args[0]] if self.scc == 1 else i + 1
+        # ---------------- scalar ALU (values are wave-uniform except those derived from the m0 bases: the flags never depend on those)
+        if op.startswith("s_"):
+            if op in ("s_cmp_eq_u32", "s_cmp_lt_u32"):
+                a, b = self.ssrc(args[0]), self.ssrc(args[1])
+                r = (a == b) if op == "s_cmp_eq_u32" else (a < b)
+                assert r.all() or not r.any()
+                self.scc = int(r[0])
+                return i + 1
+            if op.startswith("s_load_dword"):
+                m = re.match(r"s\[(\d+):(\d+)\]|s(\d+)", args[0])
+                lo, hi = (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
+                off = int(args[2], 0)
+                for k in range(hi - lo + 1):
+                    S[lo + k] = struct.unpack_from("<I", self.args, off + 4 * k)[0]
+                return i + 1
+            dst = args[0]
+            a = self.ssrc(args[1]) if len(args) > 1 else None
+            b = self.ssrc(args[2]) if len(args) > 2 else None
+            if op == "s_mov_b32":
+                r = a
+            elif op == "s_add_u32":
+                r = a + b
+                self.scc = int((r >> 32)[0] != 0)
+            elif op == "s_addc_u32":
+                r = a + b + self.scc
+                self.scc = int((r >> 32)[0] != 0)
+            elif op == "s_sub_u32":
+                self.scc = int(a[0] < b[0])
+                r = a - b
+            elif op == "s_and_b32":
+                r = a & b
+                self.scc = int(r[0] != 0)
+            elif op == "s_or_b32":
+                r = a | b
+                self.scc = int(r[0] != 0)
+            elif op == "s_lshl_b32":
+                r = a << (b & 31)
+            elif op == "s_lshr_b32":
+                r = a >> (b & 31)
+            elif op == "s_mul_i32":
+                r = a * b
+            elif op == "s_max_i32":
+                sa, sb = a.astype(np.int64), b.astype(np.int64)
+                sa = np.where(sa >= 2 ** 31, sa - 2 ** 32, sa)
+                sb = np.where(sb >= 2 ** 31, sb - 2 ** 32, sb)
+                r = np.maximum(sa, sb).astype(np.uint64)
+            elif op == "s_cselect_b32":
+                r = a if self.scc else b
+            else:
+                raise NotImplementedError(ln)
+            r = np.asarray(r, dtype=np.uint64) & 0xFFFFFFFF
+            if dst == "m0":
+                self.m0 = r
+            else:
+                S[int(dst[1:])] = r
+            return i + 1
+        # ---------------- LDS
+        if op in ("ds_read_b128", "ds_read_b64"):
+            d, _ = self.vrange(args[0])
+            m = re.search(r"offset:(\d+)", rest)
+            addr = self.src(args[1].split()[0]).astype(np.int64) + (int(m.group(1)) if m else 0)
+            nb = 16 if op == "ds_read_b128" else 8
+            data = self.lds[addr[:, None] + np.arange(nb)[None, :]].reshape(NL, nb // 4, 4)
+            words = data.view(U32).reshape(NL, nb // 4)
+            for k in range(nb // 4):
+                V[d + k] = words[:, k]
+            return i + 1
+        if op == "ds_read_b64_tr_b16":
+            d, _ = self.vrange(args[0])
+            m = re.search(r"offset:(\d+)", rest)
+            addr = self.src(args[1].split()[0]).astype(np.int64) + (int(m.group(1)) if m else 0)
+            raw = self.lds[addr[:, None] + np.arange(8)[None, :]].reshape(NL, 4, 2).view(np.uint16).reshape(NL, 4)      # each lane's four 16-bit elements
+            lane = np.arange(NL)
+            grp, t = lane & ~15, lane & 15
+            out = np.zeros((NL, 4), dtype=np.uint16)
+            for j in range(4):                                    # element j of lane t <- element (t & 3) of the group's lane 4 j + (t >> 2)
+                out[:, j] = raw[grp + 4 * j + (t >> 2), t & 3]
+            V[d] = out[:, 0].astype(U32) | (out[:, 1].astype(U32) << 16)
+            V[d + 1] = out[:, 2].astype(U32) | (out[:, 3].astype(U32) << 16)
+            return i + 1
+        # ---------------- global memory through buffer descriptors
+        if op == "buffer_load_dwordx4":
+            if rest.rstrip().endswith(" lds"):
+                vaddr = self.src(args[0]).astype(np.int64)
+                base, nrec = self.desc(args[1])
+                soff = self.lanes(self.ssrc(args[2].split()[0])).astype(np.int64)
+                ok = vaddr + soff + 16 <= nrec
+                data = self.gather(base + vaddr + soff, ok, 16)
+                dst = self.lanes(self.m0).astype(np.int64) + (np.arange(NL) & 63) * 16
+                self.lds[dst[:, None] + np.arange(16)[None, :]] = data
+                return i + 1
+            d, _ = self.vrange(args[0])
+            addr, off, nrec = self.buffer_addr(args, rest, 16)
+            for k in range(4):
+                ok = off + 4 * k + 4 <= nrec
+                V[d + k] = self.gather(addr + 4 * k, ok, 4).view(U32).reshape(NL)
+            return i + 1
+        if op in ("buffer_store_dwordx4", "buffer_store_dword"):
+            d, _ = self.vrange(args[0])
+            nw = 4 if op.endswith("x4") else 1
+            addr, off, nrec = self.buffer_addr(args, rest, 4 * nw)
+            for k in range(nw):
+                ok = off + 4 * k + 4 <= nrec
+                idx = np.where(ok)[0]
+                if idx.size:
+                    a = addr[idx] + 4 * k
+                    assert a.min() >= 0 and a.max() + 4 <= self.mem.size
+                    self.mem[a[:, None] + np.arange(4)[None, :]] = V[d + k][idx].copy().view(np.uint8).reshape(-1, 4)
+            return i + 1
+        # ---------------- matrix core: D[n][m] = sum_k src0[n][k] src1[m][k] (+ C); lane l holds k = 8 (l / 16) .. + 7 of row l % 16 of either operand,
+        # and of the result column m = l % 16 the rows n = 4 (l / 16) .. + 3
+        if op == "v_mfma_f32_16x16x32_bf16":
+            d, _ = self.vrange(args[0])
+            b0, _ = self.vrange(args[1])
+            a0, _ = self.vrange(args[2])
+
+            def frag(r0):
+                w = np.stack([V[r0 + k] for k in range(4)], axis=1)                       # [lane][4 dwords]
+                e = np.stack([w & 0xFFFF, w >> 16], axis=2).reshape(NL, 8)                # [lane][8 k-values]
+                f = bf16_to_f32(e.astype(U32)).reshape(4, 4, 16, 8)                       # [wave][k-group][row][8]
+                return f.transpose(0, 2, 1, 3).reshape(4, 16, 32)                         # [wave][row][k]
+            Bn, Am = frag(b0), frag(a0)
+            D = np.einsum("wnk,wmk->wnm", Bn.astype(np.float64), Am.astype(np.float64)).astype(np.float32)      # [wave][n][m]
+            res = D.reshape(4, 4, 4, 16).transpose(0, 1, 3, 2).reshape(NL, 4)             # lane (w, g, m): n = 4 g + r
+            for r in range(4):
+                self.A[d + r] = res[:, r] + (0 if args[3] == "0" else self.A[d + r])
+            return i + 1
+        # ---------------- vector ALU
+        if op == "v_accvgpr_read_b32":
+            V[int(args[0][1:])] = self.A[int(args[1][1:])].view(U32)
+            return i + 1
+        if op == "v_readfirstlane_b32":
+            S[int(args[0][1:])] = self.src(args[1]).reshape(4, 64)[:, 0].astype(np.uint64)
+            return i + 1
+        if op == "v_mov_b32_dpp":
+            m = re.match(r"(v\d+)\s+row_ror:(\d+)\s+row_mask:(0x[0-9a-f]+)\s+bank_mask:(0x[0-9a-f]+)", args[1])
+            srcv, ror, bank = self.src(m.group(1)), int(m.group(2)), int(m.group(4), 16)
+            lane = np.arange(NL)
+            from_lane = (lane & ~15) | ((lane - ror) & 15)
+            en = ((bank >> ((lane & 15) >> 2)) & 1).astype(bool)
+            dst = int(args[0][1:])
+            V[dst] = np.where(en, srcv[from_lane], V[dst])
+            return i + 1
+        if op.startswith("v_pk_"):
+            d, _ = self.vrange(args[0])
+            mods = " ".join(a for a in args[1:] if ":" in a and not a.startswith("v["))
+            srcs = []
+            for a in args[1:]:
+                first = a.split()[0]
+                srcs.append(first)
+                mods += " " + " ".join(a.split()[1:])
+            n_src = 3 if op == "v_pk_fma_f32" else 2
+            srcs = srcs[:n_src]
+            m = re.search(r"op_sel_hi:\[([\d,]+)\]", mods)
+            sel_hi = [int(x) for x in m.group(1).split(",")] if m else [1] * n_src
+            m = re.search(r"neg_lo:\[([\d,]+)\]", mods)
+            neg_lo = [int(x) for x in m.group(1).split(",")] if m else [0] * n_src
+            m = re.search(r"neg_hi:\[([\d,]+)\]", mods)
+            neg_hi = [int(x) for x in m.group(1).split(",")] if m else [0] * n_src
+            lo, hi = [], []
+            for k, s_ in enumerate(srcs):
+                l_, h_ = self.pair(s_, sel_hi[k] if k < len(sel_hi) else 1)
+                lo.append(-l_ if neg_lo[k] else l_)
+                hi.append(-h_ if neg_hi[k] else h_)
+            if op == "v_pk_add_f32":
+                rl, rh = lo[0] + lo[1], hi[0] + hi[1]
+            elif op == "v_pk_mul_f32":
+                rl, rh = lo[0] * lo[1], hi[0] * hi[1]
+            else:                                                  # fused: one rounding
+                rl = (lo[0].astype(np.float64) * lo[1].astype(np.float64) + lo[2].astype(np.float64)).astype(np.float32)
+                rh = (hi[0].astype(np.float64) * hi[1].astype(np.float64) + hi[2].astype(np.float64)).astype(np.float32)
+            V[d], V[d + 1] = np.asarray(rl, dtype=np.float32).view(U32), np.asarray(rh, dtype=np.float32).view(U32)
+            return i + 1
+        if op == "v_cmp_le_u32":
+            self.vcc = self.src(args[1]) <= self.src(args[2])
+            return i + 1
+        d = int(args[0][1:])
+        if op == "v_mov_b32":
+            r = self.src(args[1])
+        elif op == "v_xor_b32":
+            r = self.src(args[1]) ^ self.src(args[2])
+        elif op == "v_and_b32":
+            r = self.src(args[1]) & self.src(args[2])
+        elif op == "v_lshlrev_b32":
+            r = (self.src(args[2]).astype(np.uint64) << (self.src(args[1]).astype(np.uint64) & 31)).astype(U32)
+        elif op == "v_lshrrev_b32":
+            r = self.src(args[2]) >> (self.src(args[1]) & 31)
+        elif op == "v_add_u32":
+            r = (self.src(args[1]).astype(np.uint64) + self.src(args[2]).astype(np.uint64)).astype(U32)
+        elif op == "v_add3_u32":
+            r = (self.src(args[1]).astype(np.uint64) + self.src(args[2]).astype(np.uint64) + self.src(args[3]).astype(np.uint64)).astype(U32)
+        elif op == "v_mul_lo_u32":
+            r = (self.src(args[1]).astype(np.uint64) * self.src(args[2]).astype(np.uint64)).astype(U32)
+        elif op == "v_mul_f32":
+            r = (self.src(args[1]).view(np.float32) * self.src(args[2]).view(np.float32)).view(U32)
+        elif op == "v_cndmask_b32":
+            r = np.where(self.vcc, self.src(args[2]), self.src(args[1]))
+        elif op == "v_bfi_b32":
+            s0, s1, s2 = self.src(args[1]), self.src(args[2]), self.src(args[3])
+            r = (s0 & s1) | (~s0 & s2)
+        elif op == "v_cvt_pk_bf16_f32":
+            r = bf16_round(self.src(args[1]).view(np.float32)) | (bf16_round(self.src(args[2]).view(np.float32)) << 16)
+        elif op == "v_rcp_f32":
+            r = (np.float32(1.0) / self.src(args[1]).view(np.float32)).astype(np.float32).view(U32)
+        elif op == "v_exp_f32":
+            r = np.exp2(self.src(args[1]).view(np.float32).astype(np.float64)).astype(np.float32).view(U32)
+        else:
+            raise NotImplementedError(ln)
+        V[d] = np.asarray(r, dtype=U32)
+        return i + 1
+
+
+# ---------------------------------------------------------------------------------------------------- harness: what gemm_w4a.h does around the statement
+def gelu_parts(u):
+    from math import erf, sqrt, pi
+    u = np.asarray(u, dtype=np.float64)
+    cdf = 0.5 * (1.0 + np.vectorize(erf)(u / sqrt(2.0)))
+    return u * cdf, cdf + u * np.exp(-0.5 * u * u) / sqrt(2.0 * pi)
+
+
+def run_case(ni, bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False):
+    """one workgroup walks every tile of an M x N x K problem; returns the worst deviation from numpy in units of the tolerance (<= 1 passes)"""
+    rng = np.random.default_rng(seed + 17 * ni + 3 * bkm + len(epi))
+    TM, WM = 32 * ni, 16 * ni
+    lda, ldc = K, N + 8                                            # (a leading dimension wider than the row, as the engine's fused q|k|v buffer has)
+    ldb = N if bkm else K
+    side = epi in ("resid", "mulaux", "dropres", "gelud")
+    ldr = N + 16
+    A = bf16_round(rng.standard_normal((M, K)).astype(np.float32) * 0.5)
+    Bm = bf16_round(rng.standard_normal((K, N) if bkm else (N, K)).astype(np.float32) * 0.25)
+    bias = (rng.standard_normal(N).astype(np.float32)) if epi != "mulaux" else None
+    R = bf16_round(rng.standard_normal((M, ldr)).astype(np.float32)) if epi in ("resid", "mulaux", "dropres") else None
+    # ---- global memory image (addresses: offsets into `mem`; every buffer 256-byte aligned, guard bytes behind each)
+    mem = np.full(32 << 20, 0xA5, dtype=np.uint8)
+    cur = [4096]
+
+    def place(arr_bytes):
+        a = cur[0]
+        mem[a:a + arr_bytes.size] = arr_bytes
+        cur[0] = (a + arr_bytes.size + 4096 + 255) & ~255
+        return a
+    pA = place(A.astype(np.uint16).view(np.uint8).reshape(-1))
+    pB = place(Bm.astype(np.uint16).view(np.uint8).reshape(-1))
+    C_rows = M + 8
+    pC = place(np.full(C_rows * ldc * 2, 0x5C, dtype=np.uint8))
+    pBias = place(bias.view(np.uint8).reshape(-1)) if bias is not None else 0
+    if R is not None:
+        pR = place(R.astype(np.uint16).view(np.uint8).reshape(-1))
+    elif epi == "gelud":
+        pR = place(np.full(C_rows * ldr * 2, 0x6D, dtype=np.uint8))
+    else:
+        pR = 0
+    args = struct.pack("<5Q8i", pA, pB, pC, pBias, pR, M, N, K, lda, ldb, ldc, ldr, 0)
+    # ---- tile table + per-lane constants (csrc/gemm_w4a.h)
+    lds_base = 0
+    tiles = [(bm, bn) for bm in range((M + TM - 1) // TM) for bn in range(N // 256)]
+    emu_lds = np.zeros(Emu.LDS_BYTES, dtype=np.uint8)
+    for k, (bm, bn) in enumerate(tiles):
+        m0, n0 = bm * TM, bn * 256
+        e = struct.pack("<4I", (m0 * lda * 2) & 0xFFFFFFFF, (n0 * 2 if bkm else n0 * ldb * 2) & 0xFFFFFFFF, ((m0 * ldc + n0) * 2) & 0xFFFFFFFF, n0)
+        emu_lds[131072 + 16 * k: 131072 + 16 * k + 16] = np.frombuffer(e, dtype=np.uint8)
+        e2 = struct.pack("<2I", ((m0 * ldr + n0) * 2) & 0xFFFFFFFF, ((m0 * N + n0) >> 1) & 0xFFFFFFFF)
+        o2 = 131072 + 16 * 512 + 16 * k
+        emu_lds[o2:o2 + 8] = np.frombuffer(e2, dtype=np.uint8)
+    tid = np.arange(NL)
+    lane, wave = tid & 63, tid >> 6
+    wm, wn, g, t = wave >> 1, wave & 1, lane >> 4, lane & 15
+    r8, chunk = lane >> 3, lane & 7
+    rowA0 = 8 * wave + r8
+    voA0 = rowA0 * lda * 2 + ((chunk ^ key_a(rowA0)) << 4)
+    if not bkm:
+        voBbase = (64 * wave + r8) * ldb * 2
+        chunkx = chunk ^ ((r8 >> 1) & 1)
+        rowb = wn * 128 + 8 * (t >> 2) + (t & 3)
+        aB0 = lds_base + 65536 + rowb * 128 + ((g ^ key_b(rowb)) << 4)
+    else:
+        r1 = lane >> 5
+        voBbase = (16 * wave + r1) * ldb * 2
+        chunkx = (lane & 31) ^ (2 * r1)
+        rho, c0 = 8 * g + (t >> 2), wn * 16 + (t & 3)
+        aB0 = lds_base + 65536 + rho * 512 + ((c0 ^ km_key(rho)) << 4)
+    rowa = wm * WM + t
+    aA0 = lds_base + rowa * 128 + ((g ^ key_a(rowa)) << 4)
+    lrow, lcol = wm * WM + (t & 7), wn * 128 + 8 * (g + 4 * (t >> 3))
+    seed64 = 0x123456789ABCDEF
+    dkey = (seed64 & 0xFFFFFFFF) ^ int(hash32(seed64 >> 32))
+    thr = int(p_drop * 65536.0 + 0.5)
+    opv = dict(tbl=np.full(NL, lds_base + 131072), voA0=voA0, voBbase=voBbase, chunkx=chunkx, aA0=aA0, aB0=aB0, cst=(lrow * ldc + lcol) * 2, boff=(wn * 128 + 8 * g) * 4,
+               rst=(lrow * ldr + lcol) * 2, pairb=((wm * WM + t) * N + (wn * 128 + 8 * g)) >> 1)
+    w4 = np.arange(4)
+    ops = dict(karg=np.zeros(4), ntiles=np.full(4, len(tiles)), m0A=lds_base + w4 * 1024, m0B=lds_base + 65536 + w4 * 8192, dkey=np.full(4, dkey), dthr=np.full(4, thr),
+               dinv=np.full(4, int(np.float32(65536.0 / (65536.0 - thr)).view(np.uint32))))
+    lines = G.Gen(bkm, epi, ni).body()
+    emu = Emu(lines, {k: np.asarray(v, dtype=np.uint64) for k, v in opv.items()}, ops, args, mem)
+    emu.lds[:] = emu_lds
+    emu.run()
+    # ---- reference on the same bf16 operands
+    Af, Bf = bf16_to_f32(A).astype(np.float64), bf16_to_f32(Bm).astype(np.float64)
+    acc = Af @ (Bf if bkm else Bf.T)
+    if bias is not None:
+        acc = acc + bias.astype(np.float64)
+    want_aux = None
+    if epi in ("resid", "dropres", "mulaux"):
+        Rf = bf16_to_f32(R[:, :N]).astype(np.float64)
+    if epi == "dropres":
+        mi, nj = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+        pairi = (mi * N + nj) >> 1
+        h = hash32(np.uint64(dkey) ^ pairi.astype(np.uint64))
+        u16 = np.where((nj & 1) == 0, h & 0xFFFF, h >> 16)
+        keep = u16 >= thr
+        acc = np.where(keep, acc * float(np.float32(65536.0 / (65536.0 - thr))), 0.0) + Rf
+    elif epi == "resid":
+        acc = acc + Rf
+    elif epi == "mulaux":
+        acc = acc * Rf
+    elif epi in ("gelu", "gelud"):
+        acc, want_aux = gelu_parts(acc)
+    got_raw = mem[pC:pC + C_rows * ldc * 2].view(np.uint16).reshape(C_rows, ldc)
+    got = bf16_to_f32(got_raw[:M, :N].astype(U32)).astype(np.float64)
+    tol = np.abs(acc) * 2.0 ** -7 + 2e-3
+    worst = float((np.abs(got - acc) / tol).max())
+    guard_ok = bool((got_raw[M:] == 0x5C5C).all() and (got_raw[:M, N:] == 0x5C5C).all())
+    if epi == "gelud":
+        aux_raw = mem[pR:pR + C_rows * ldr * 2].view(np.uint16).reshape(C_rows, ldr)
+        gaux = bf16_to_f32(aux_raw[:M, :N].astype(U32)).astype(np.float64)
+        worst = max(worst, float((np.abs(gaux - want_aux) / (np.abs(want_aux) * 2.0 ** -7 + 2e-3)).max()))
+        guard_ok = guard_ok and bool((aux_raw[M:] == 0x6D6D).all() and (aux_raw[:M, N:] == 0x6D6D).all())
+    if verbose:
+        print(f"ni={ni} {'KM' if bkm else 'KC'} {epi:8s} M={M} N={N} K={K}: {len(tiles)} tiles, {emu.n} instructions, worst deviation {worst:.3f} of the tolerance, guards {'intact' if guard_ok else 'OVERWRITTEN'}", flush=True)
+    return worst, guard_ok
+
+
+def bodies():
+    for ni, bkm in ((8, False), (8, True), (7, False), (7, True)):
+        for epi in ("plain", "resid", "mulaux") + (() if bkm else ("dropres", "gelu", "gelud")):
+            yield ni, bkm, epi
+
+
+if __name__ == "__main__":
+    bad = 0
+    for ni, bkm, epi in bodies():
+        # two row tiles, the second ragged (rows >= M inside the last tile), two column tiles, three K-step pairs (first / middle / last)
+        M = 32 * ni + 80
+        worst, guard_ok = run_case(ni, bkm, epi, M, 512, 384, verbose=True)
+        bad += (worst > 1.0) or not guard_ok
+    print("all bodies reproduce numpy" if not bad else f"{bad} bodies DIFFER")
+    sys.exit(1 if bad else 0)

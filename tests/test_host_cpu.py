@@ -447,6 +447,40 @@ def test_generated_asm_of_the_four_wave_gemm_is_what_its_generator_emits(tmp_pat
         assert text.count("s_barrier") >= 2 * 6, name
 
 
+def test_every_generated_asm_gemm_body_reproduces_numpy_in_emulation():
+    """scripts/w4a_emulate.py interprets the generated gfx950 text on the CPU (one workgroup: 4 waves x 64 lanes, LDS, a flat global memory; the C++
+    prologue of csrc/gemm_w4a.h restated next to it) and compares C -- and GELU' of the two-output form -- with numpy on the same bf16 operands: all 18
+    bodies (two tile heights x layouts x epilogues incl. the dropout mask and GELU), a problem with two row tiles of which the last is ragged, two column
+    tiles and three K-step pairs; guard bytes behind C's last valid row and column must survive.  The emulator is itself checked by mutation: one
+    fragment-read offset, one DPP bank mask and one LDS-DMA piece changed must each change the result."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import gen_w4a as G
+        import w4a_emulate as W
+    finally:
+        sys.path.pop(0)
+    for ni, bkm, epi in W.bodies():
+        worst, guards = W.run_case(ni, bkm, epi, 32 * ni + 80, 512, 384)
+        assert worst <= 1.0 and guards, (ni, bkm, epi, worst, guards)
+    # mutations of one body: the emulator must notice
+    real = G.Gen.body
+
+    def mutated(pred, mut):
+        def body(self):
+            lines = real(self)
+            k = next(i for i, l in enumerate(lines) if pred(l))
+            lines[k] = mut(lines[k])
+            return lines
+        G.Gen.body = body
+        try:
+            return W.run_case(8, False, "resid", 336, 256, 256)
+        finally:
+            G.Gen.body = real
+    assert mutated(lambda l: False or l.startswith("ds_read_b128") and "offset:2048" in l, lambda l: l.replace("offset:2048", "offset:4096"))[0] > 1.0
+    assert mutated(lambda l: "bank_mask:0xc" in l, lambda l: l.replace("bank_mask:0xc", "bank_mask:0x3"))[0] > 1.0
+    assert mutated(lambda l: l.startswith("s_add_u32 m0") and l.endswith(", 4096"), lambda l: l[:-4] + "8192")[0] > 1.0
+
+
 def test_asm_gemm_tile_height_plan_fills_the_rounds_of_resident_workgroups():
     """Host logic of the two-height asm GEMM (dic_gemm_w4a_rows_plan, a pure function: no device): 224-row tiles where they turn a partly filled last
     round into a fuller one of shorter tiles -- the step's 17 408 tokens (78 x 224: 234 / 702 / 936 tiles = 1 / 3 / 4 rounds on 256 CUs instead of 204 / 612 /
