@@ -29,6 +29,7 @@ python scripts/gemm_in_step.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_ste
 python scripts/gemm_in_step.py --dtype bf16r 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16r.txt
 python scripts/gemm_in_step.py --dtype bf16w 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_in_step_bf16w.txt
 timeout 300 python scripts/experiments/w4a_check.py time 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gemm_w4a_check.txt
+timeout 300 python scripts/experiments/tile_rows_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_tile_rows_probe.txt
 [ -f abl/libdic_clk.so ] && timeout 900 python scripts/power_ab.py --steps 400 --pin 1900 > $O/${TAG}_power_ab.txt 2>&1
 python bench.py --quick --dtype bf16w 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16w.json
 python bench.py --quick --dtype bf16r 2>/dev/null | tail -1 > $O/${TAG}_bench_bf16r.json
