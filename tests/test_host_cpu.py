@@ -481,6 +481,15 @@ def test_every_generated_asm_gemm_body_reproduces_numpy_in_emulation():
     assert mutated(lambda l: l.startswith("s_add_u32 m0") and l.endswith(", 4096"), lambda l: l[:-4] + "8192")[0] > 1.0
 
 
+def test_driver_build_entry_point_runs_on_the_shipped_library(monkeypatch):
+    """__graft_entry__.build() is the driver's "does it build" check; with DIC_BUILD_REUSE=1 it skips the compile and must still load the library,
+    find every symbol and agree with its ABI version (a hard-coded version number in the entry point once outlived two version bumps)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('BUILD OK')"], cwd=ROOT, env=dict(os.environ, DIC_BUILD_REUSE="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BUILD OK" in r.stdout, (r.stdout + r.stderr)[-1500:]
+
+
 def test_asm_gemm_tile_height_plan_fills_the_rounds_of_resident_workgroups():
     """Host logic of the two-height asm GEMM (dic_gemm_w4a_rows_plan, a pure function: no device): 224-row tiles where they turn a partly filled last
     round into a fuller one of shorter tiles -- the step's 17 408 tokens (78 x 224: 234 / 702 / 936 tiles = 1 / 3 / 4 rounds on 256 CUs instead of 204 / 612 /
