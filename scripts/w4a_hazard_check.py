@@ -13,7 +13,11 @@ taken, under the weakest assumption the ISA allows (a memory operation has compl
   R3  the LDS-DMA starts refilling stage s only after every fragment read of the previous K-step has returned (lgkmcnt) AND a barrier has been
       passed since (the other waves' reads);
   R4  every K-step's DMA is complete (ni + 8 pieces into each of the A and B halves) when it is published, every counted wait fits its counter;
-  R5  at the end nothing is outstanding that the kernel has not waited for (the final vmcnt(0) lgkmcnt(0)).
+  R5  at the end nothing is outstanding that the kernel has not waited for (the final vmcnt(0) lgkmcnt(0));
+  R6-R10  the fixed-latency hazards gfx940-class hardware does NOT interlock, counted in wait states (one per instruction, n + 1 per `s_nop n`):
+      an MFMA's accumulator read by v_accvgpr_read (>= 11: covers matrix operations of up to 8 passes), a VALU result read by a DPP instruction (>= 2),
+      a transcendental's result read by another VALU instruction (>= 1), m0 written by the SALU and used by an LDS-DMA (>= 1), an SGPR written by
+      v_readfirstlane and used by a buffer instruction (>= 5).
 
 Loads and stores retire in order per counter (gfx950: ONE in-order vmcnt for global loads, LDS-DMA and stores; LDS reads return in order), which is what
 the generator assumes; a counter of w bits cannot hold more than 2^w - 1 operations, so the oldest of more than that has completed.
@@ -62,6 +66,9 @@ class Sim:
         self.m0 = None                   # (operand, stage) the next LDS-DMA writes
         self.n_instr = 0
         self.stats = dict(mfma=0, ksteps=0, tiles=0)
+        self.ws = 0                      # wait-state clock: instructions issued so far (s_nop n counts n + 1)
+        self.acc_w, self.valu_w, self.trans_w, self.rfl_w = {}, {}, {}, {}   # register -> wait-state clock right after the instruction that wrote it
+        self.m0_w = -100
 
     # ------------------------------------------------------------------ helpers
     def fail(self, i, msg):
@@ -144,13 +151,32 @@ class Sim:
                 rg["drained"] = len(rg["reads"])
 
     # ------------------------------------------------------------------ one instruction
+    def gap(self, i, table, regs, need, rule):
+        for r in regs:
+            if r in table and self.ws - table[r] < need:
+                self.fail(i, f"{rule}: {self.ws - table[r]} wait states since the producer of register {r}, {need} required")
+
     def step(self, i):
+        nxt = self.step_(i)
+        ln = self.lines[i]
+        if not ln.endswith(":"):
+            self.ws += (int(ln.split()[1], 0) + 1) if ln.startswith("s_nop") else 1
+        return nxt
+
+    def step_(self, i):
         ln = self.lines[i]
         self.n_instr += 1
         if ln.endswith(":"):
             return i + 1
         op, _, rest = ln.partition(" ")
         args = [a.strip() for a in rest.split(",")] if rest else []
+        if op.startswith("buffer_"):            # R10: SGPRs a buffer instruction uses (descriptor, scalar offset) against v_readfirstlane
+            used = []
+            for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", rest):
+                used += list(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else [int(m.group(3))]
+            self.gap(i, self.rfl_w, used, 5, "R10")
+            if rest.rstrip().endswith(" lds") and self.ws - self.m0_w < 1:
+                self.fail(i, "R9: LDS-DMA in the wait state right behind the SALU write of m0")
         # ---- control flow / scalar
         if op == "s_branch":
             return self.labels[args[0]]
@@ -193,6 +219,7 @@ class Sim:
                 return i + 1
             dst = args[0]
             if dst == "m0":
+                self.m0_w = self.ws + 1
                 base = int(re.fullmatch(r"s(\d+)", args[1]).group(1))
                 const = int(args[2], 0)
                 self.m0 = ("A" if base == G.S_M0A else "B", 1 if const >= 32768 else 0)
@@ -255,6 +282,9 @@ class Sim:
         if op.startswith("v_mfma"):
             self.read_v(i, vregs(args[1]) + vregs(args[2]))
             self.stats["mfma"] += 1
+            m = re.fullmatch(r"a\[(\d+):(\d+)\]", args[0])
+            for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                self.acc_w[r] = self.ws + 1
             return i + 1
         if op.startswith("v_"):
             srcs = []
@@ -271,6 +301,21 @@ class Sim:
                 srcs += dst                 # (bank-masked DPP moves / selects keep part of the old value)
             self.read_v(i, srcs)
             self.write_v(i, dst)
+            if op == "v_accvgpr_read_b32":
+                self.gap(i, self.acc_w, [int(args[1][1:])], 11, "R6")
+            if "_dpp" in op:
+                self.gap(i, self.valu_w, vregs(args[1].split()[0]), 2, "R7")
+            trans = op in ("v_rcp_f32", "v_exp_f32")
+            if not trans:
+                self.gap(i, self.trans_w, srcs, 1, "R8")
+            for r in dst:
+                self.valu_w[r] = self.ws + 1
+                if trans:
+                    self.trans_w[r] = self.ws + 1
+                else:
+                    self.trans_w.pop(r, None)
+            if op == "v_readfirstlane_b32":
+                self.rfl_w[int(args[0][1:])] = self.ws + 1
             return i + 1
         self.fail(i, "instruction the checker does not know")
 

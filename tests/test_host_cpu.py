@@ -514,7 +514,8 @@ def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic
     """scripts/w4a_hazard_check.py executes every generated body through its real control flow (several K / tile counts) and checks, under the
     weakest completion assumption the ISA allows, that no register is read before its load was waited for, that an LDS stage is read only
     after publication (vmcnt wait + barrier) and refilled only after its reads returned (lgkmcnt wait + barrier), and that nothing is left
-    outstanding.  The checker itself is checked by mutation: every `vmcnt` weakened by one, a weakened `lgkmcnt` in front of an MFMA group
+    outstanding -- and the fixed-latency hazards the hardware does not interlock (MFMA result -> v_accvgpr_read, VALU -> DPP, transcendental -> VALU,
+    m0 -> LDS-DMA).  The checker itself is checked by mutation: every `vmcnt` weakened by one, a weakened `lgkmcnt` in front of an MFMA group
     and a dropped barrier must each be reported."""
     import re
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -548,6 +549,22 @@ def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic
         caught = sum(mutated(is_lg, lambda l: re.sub(r"\((\d+)\)", lambda m: f"({int(m.group(1)) + 1})", l), k) for k in range(sum(map(is_lg, lines))))
         assert caught >= 0.75 * sum(map(is_lg, lines)), (ni, bkm, epi, caught)        # (a few waits are stricter than their consumer needs)
         assert mutated(lambda l: l == "s_barrier", lambda l: None, 1) and mutated(lambda l: l == "s_barrier", lambda l: None, 4), (ni, bkm, epi)
+    # the fixed-latency rules (R6-R9) on minimal sequences: each must be reported without, and accepted with, the wait states the hardware needs
+    def runs(lines):
+        sim = H.Sim(lines, 8, 256, 1)
+        try:
+            for k in range(len(lines)):
+                sim.step(k)
+        except H.Violation:
+            return False
+        return True
+    mf = "v_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[64:67], 0"
+    assert not runs([mf, "s_nop 5", "v_accvgpr_read_b32 v136, a0"]) and runs([mf, "s_nop 10", "v_accvgpr_read_b32 v136, a0"])
+    dpp = "v_mov_b32_dpp v3, v1 row_ror:8 row_mask:0xf bank_mask:0xc"
+    assert not runs(["v_mov_b32 v1, v2", "s_nop 0", dpp]) and runs(["v_mov_b32 v1, v2", "s_nop 1", dpp])
+    assert not runs(["v_rcp_f32 v1, v1", "v_mul_f32 v2, v1, v1"]) and runs(["v_rcp_f32 v1, v1", "s_nop 0", "v_mul_f32 v2, v1, v1"])
+    dma = "buffer_load_dwordx4 v152, s[52:55], s88 offen lds"
+    assert not runs([f"s_add_u32 m0, s{G.S_M0A}, 0", dma]) and runs([f"s_add_u32 m0, s{G.S_M0A}, 0", "s_nop 0", dma])
 
 
 def _run_bench(argv, env_extra=None, timeout=600):
