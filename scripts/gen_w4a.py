@@ -130,7 +130,7 @@ def mfma(a, i, j, kk, first):
 
 
 class Gen:
-    def __init__(self, bkm, epi, ni=8):
+    def __init__(self, bkm, epi, ni=8, opts=()):
         """ni: A fragments per wave = tile height / 32 (8: 256-row tiles; 7: 224-row tiles -- 17 408 tokens are 78 x 224: 234 / 702 / 936 tiles fill
         1 / 3 / 4 rounds of 256 CUs where 204 / 612 / 816 tiles of 256 rows leave the last round 20-80 % empty)"""
         assert ni in (7, 8)
@@ -141,6 +141,11 @@ class Gen:
         self.drop = epi == "dropres"
         self.gelu = epi in ("gelu", "gelud")
         self.two_out = epi == "gelud"
+        # measurement options (NOT in the shipped .inc; `python scripts/gen_w4a.py OUT block_waits early_side` writes a variant file for scripts/build_variant.sh):
+        #   block_waits: the epilogue waits for side-input block i in front of row block i instead of for blocks 0-6 in front of row block 0
+        #   early_side:  the side-input blocks that live in registers the K loop never uses (2-5: v178..v241) are requested one K-step earlier
+        self.opts = frozenset(opts)
+        assert self.opts <= {"block_waits", "early_side"}
 
     # ---------------------------------------------------------------- fragment reads / DMA
     def read_b(self, j, kk, stage, gen):
@@ -227,7 +232,7 @@ class Gen:
             a(f"v_pk_mul_f32 {pr(X[k])}, {pr(X[k])}, {pr(P[k])}")
 
     # ---------------------------------------------------------------- one K-step
-    def step(self, stage, first=False, n_e=8, bias_loads=False, last_of_tile=False):
+    def step(self, stage, first=False, n_e=8, bias_loads=False, last_of_tile=False, early_side=False):
         """first: accumulators start from 0.  n_e: vmcnt count of barrier E (None: no wait, only the barrier).  bias_loads: the tile's 8 bias
         quads ride in phase 0.  last_of_tile (side-input variants): no prefetch of the next tile's fragments; the side tile is requested."""
         a = self.a
@@ -261,7 +266,9 @@ class Gen:
         side_q = []
         if last_of_tile and self.side:
             # side-input blocks 0-5 (24 loads) into the first B buffer and the high registers: before barrier E; block 6 (A[0..3]) after group 4
-            side_q = [(blk, n) for blk in range(6) for n in range(4)]
+            side_q = [(blk, n) for blk in ((0, 1) if "early_side" in self.opts else range(6)) for n in range(4)]
+        if early_side and self.side:
+            side_q = [(blk, n) for blk in (2, 3, 4, 5) for n in range(4)]
         n_side_before_e = len(side_q)
         # DMA pieces of K-step k+2 behind barrier E (8 went out in front of it): (group, slot)
         after_e = ([(6, 5), (6, 6), (6, 7), (7, 1), (7, 2), (7, 3), (7, 4), (7, 5)] if ni == 8 else
@@ -533,7 +540,7 @@ class Gen:
         next_to_cur()                                         # last pair: its DMA slots carry the next tile's first two K-steps
         a(f"s_mov_b32 s{S_KA}, 0")
         a(f"s_mov_b32 s{S_KB}, 0")
-        self.step(0)
+        self.step(0, early_side="early_side" in self.opts)
         self.step(1, last_of_tile=True)
         if not self.side:
             assert tail_state == [(t[0],) + t[2:] for t in a.lds[-24:]]
@@ -544,7 +551,9 @@ class Gen:
         T = V_T
         n_store = 0
         for i in range(ni):
-            if self.side:
+            if self.side and "block_waits" in self.opts:
+                a(f"s_waitcnt vmcnt({min(63, a.younger_vm(('side', i)))})")       # side block i is back
+            elif self.side:
                 if i == 0:
                     n_y = a.younger_vm(("side", 6))
                     assert n_y == (12 if ni == 8 else 4), n_y
@@ -706,6 +715,7 @@ def lint(lines, name):
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
+    opts = tuple(sys.argv[2:])
     with open(out, "w") as f:
         f.write("// GENERATED by scripts/gen_w4a.py -- do not edit; the schedule is described there\n")
         f.write(f"#define W4A_N_OPERANDS {len(OPS)}\n")
@@ -714,7 +724,7 @@ def main():
                                                     [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"vcc"', '"scc"', '"m0"', '"memory"']) + "\n")
         for ni, bkm in ((8, False), (8, True), (7, False), (7, True)):
             for epi in ("plain", "resid", "mulaux") + (() if bkm else ("dropres", "gelu", "gelud")):
-                lines = Gen(bkm, epi, ni).body()
+                lines = Gen(bkm, epi, ni, opts).body()
                 lint(lines, (ni, bkm, epi))
                 name = f"W4A_BODY{'' if ni == 8 else ni}_{'KM' if bkm else 'KC'}_{epi.upper()}"
                 f.write(f"#define {name} \\\n")

@@ -406,7 +406,7 @@ def gelu_parts(u):
     return u * cdf, cdf + u * np.exp(-0.5 * u * u) / sqrt(2.0 * pi)
 
 
-def run_case(ni, bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False):
+def run_case(ni, bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False, opts=()):
     """one workgroup walks every tile of an M x N x K problem; returns the worst deviation from numpy in units of the tolerance (<= 1 passes)"""
     rng = np.random.default_rng(seed + 17 * ni + 3 * bkm + len(epi))
     TM, WM = 32 * ni, 16 * ni
@@ -478,7 +478,7 @@ def run_case(ni, bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False):
     w4 = np.arange(4)
     ops = dict(karg=np.zeros(4), ntiles=np.full(4, len(tiles)), m0A=lds_base + w4 * 1024, m0B=lds_base + 65536 + w4 * 8192, dkey=np.full(4, dkey), dthr=np.full(4, thr),
                dinv=np.full(4, int(np.float32(65536.0 / (65536.0 - thr)).view(np.uint32))))
-    lines = G.Gen(bkm, epi, ni).body()
+    lines = G.Gen(bkm, epi, ni, opts).body()
     emu = Emu(lines, {k: np.asarray(v, dtype=np.uint64) for k, v in opv.items()}, ops, args, mem)
     emu.lds[:] = emu_lds
     emu.run()

@@ -344,10 +344,10 @@ def bodies():
             yield ni, bkm, epi
 
 
-def check_all(shapes=((256, 1), (256, 3), (384, 2), (768, 2)), verbose=False):
+def check_all(shapes=((256, 1), (256, 3), (384, 2), (768, 2)), verbose=False, opts=()):
     n = 0
     for ni, bkm, epi in bodies():
-        lines = G.Gen(bkm, epi, ni).body()
+        lines = G.Gen(bkm, epi, ni, opts).body()
         for K, ntiles in shapes:
             st = Sim(lines, ni, K, ntiles, name=f"ni={ni} {'KM' if bkm else 'KC'} {epi}").run()
             n += 1

@@ -490,6 +490,23 @@ def test_driver_build_entry_point_runs_on_the_shipped_library(monkeypatch):
     assert r.returncode == 0 and "BUILD OK" in r.stdout, (r.stdout + r.stderr)[-1500:]
 
 
+def test_measurement_options_of_the_asm_generator_are_correct_on_paper():
+    """scripts/gen_w4a.py OUT block_waits early_side writes a VARIANT file for a measurement build (scripts/experiments/w4a_variant_ab.sh; the shipped .inc is
+    generated without options): per-block side-input waits in the epilogue, and the side-input blocks that live in registers the K loop never uses requested
+    one K-step earlier.  Both must pass the race checker and reproduce numpy in emulation before they cost a GPU minute."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import w4a_emulate as W
+        import w4a_hazard_check as H
+    finally:
+        sys.path.pop(0)
+    opts = ("block_waits", "early_side")
+    assert H.check_all(shapes=((256, 2), (384, 2)), opts=opts) == 18 * 2
+    for ni, bkm, epi in ((8, False, "dropres"), (7, True, "mulaux"), (7, False, "resid")):
+        worst, guards = W.run_case(ni, bkm, epi, 32 * ni + 80, 512, 384, opts=opts)
+        assert worst <= 1.0 and guards, (ni, bkm, epi, worst, guards)
+
+
 def test_asm_gemm_tile_height_plan_fills_the_rounds_of_resident_workgroups():
     """Host logic of the two-height asm GEMM (dic_gemm_w4a_rows_plan, a pure function: no device): 224-row tiles where they turn a partly filled last
     round into a fuller one of shorter tiles -- the step's 17 408 tokens (78 x 224: 234 / 702 / 936 tiles = 1 / 3 / 4 rounds on 256 CUs instead of 204 / 612 /
