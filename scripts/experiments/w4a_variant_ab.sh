@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of generator options of the four-wave asm GEMM (scripts/gen_w4a.py OUT <options>) against the shipped bodies, on the GPU box:
-#   bash scripts/experiments/w4a_variant_ab.sh block_waits early_side        (run through gpurun; ~6 minutes)
+#   bash scripts/experiments/w4a_variant_ab.sh block_waits early_side defer_stores       (any subset; run through gpurun; ~8 minutes)
 # The variant text is first proven on the CPU (race checker + emulator), then built into abl/libdic_w4avar.so (-DW4A_ASM_INC), checked against the
 # 8-wave kernel on the GPU (w4a_check.py) and timed: per shape (tile_rows_probe.py) and in the step / the sampling pass, interleaved with the shipped library.
 set -e

@@ -54,6 +54,8 @@ V_BOFF = 175             # bias lane offset (bytes)
 V_TBL = 176              # LDS address of the tile table (same in every lane)
 V_RST = 177              # side-input lane offset (bytes)
 V_PAIRB = 242            # dropout: the lane's element-pair index inside the tile
+V_HOLD = 178             # defer_stores: 8 units x 8 packed registers (v178..v241)
+S_PREVC = 15             # defer_stores: the previous tile's C descriptor (s15..s18: the dropout scalars' registers -- plain bodies have no dropout)
 V_GC = 178               # gelu / gelud: 8 constant pairs (both halves the same value) in v178..v193
 V_GX = 210               # gelu / gelud: the column group's second fragment (4 values) and the scratch pairs of its two pairs (v210..v225)
 V_T2 = 198               # gelud: the second output's 8 packed registers (v198..v205) and its 4 exchange temporaries (v206..v209)
@@ -144,8 +146,11 @@ class Gen:
         # measurement options (NOT in the shipped .inc; `python scripts/gen_w4a.py OUT block_waits early_side` writes a variant file for scripts/build_variant.sh):
         #   block_waits: the epilogue waits for side-input block i in front of row block i instead of for blocks 0-6 in front of row block 0
         #   early_side:  the side-input blocks that live in registers the K loop never uses (2-5: v178..v241) are requested one K-step earlier
+        #   defer_stores (plain bodies): the packed output of the tile's last four row blocks waits in v178..v241 and is stored from the MFMA slots of the NEXT
+        #                tile's first K-step (the epilogue's store burst halves: 64 KB per CU instead of 128 KB in front of the next K loop's loads)
         self.opts = frozenset(opts)
-        assert self.opts <= {"block_waits", "early_side"}
+        assert self.opts <= {"block_waits", "early_side", "defer_stores"}
+        self.defer = "defer_stores" in self.opts and epi == "plain"
 
     # ---------------------------------------------------------------- fragment reads / DMA
     def read_b(self, j, kk, stage, gen):
@@ -231,6 +236,17 @@ class Gen:
         for k in R2:
             a(f"v_pk_mul_f32 {pr(X[k])}, {pr(X[k])}, {pr(P[k])}")
 
+    def flush_unit(self, u):
+        """deferred stores of unit u = 2 (row block - (ni - 4)) + slab: two full-line stores through the PREVIOUS tile's C descriptor (s15..s18)"""
+        a = self.a
+        i, slab = self.ni - 4 + (u >> 1), u & 1
+        H = V_HOLD + 8 * u
+        a(f"s_mul_i32 s{S_T}, s{S_LDC16}, {i}")
+        a(f"s_add_u32 s{S_T}, s{S_T}, {128 * slab}")
+        a.vmem("store", f"buffer_store_dwordx4 v[{H}:{H + 3}], v{V_CST}, s[{S_PREVC}:{S_PREVC + 3}], s{S_T} offen")
+        a(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDC8}")
+        a.vmem("store", f"buffer_store_dwordx4 v[{H + 4}:{H + 7}], v{V_CST}, s[{S_PREVC}:{S_PREVC + 3}], s{S_T} offen")
+
     # ---------------------------------------------------------------- one K-step
     def step(self, stage, first=False, n_e=8, bias_loads=False, last_of_tile=False, early_side=False):
         """first: accumulators start from 0.  n_e: vmcnt count of barrier E (None: no wait, only the barrier).  bias_loads: the tile's 8 bias
@@ -248,6 +264,10 @@ class Gen:
         put((0, 5), lambda: self.read_a(ni - 1, 0, stage, g0))                        # the last A(kk0) fragment (its registers were busy until now)
         for i in range(ni - 1):
             put((i + 1, 5), lambda i=i: self.read_a(i, 1, stage, g0))                 # A(kk1)[i] over A(kk0)[i], half a group after its MFMAs
+        if first and self.defer:
+            free = [(g, sl) for g in range(ni) for sl in (4, 6, 7)][:8]
+            for u, key in enumerate(free):
+                put(key, lambda u=u: self.flush_unit(u))
         if bias_loads:
             for j in range(8):
                 off = (32 * (j >> 1) + 4 * (j & 1)) * 4
@@ -426,6 +446,9 @@ class Gen:
         a(f"s_mov_b32 s{S_NULL + 1}, 0")
         a(f"s_mov_b32 s{S_NULL + 2}, 0")
         a(f"s_mov_b32 s{S_NULL + 3}, 0x00020000")
+        if self.defer:                                        # nothing is held in front of the first tile: its flush goes through a null descriptor
+            for k in range(4):
+                a(f"s_mov_b32 s{S_PREVC + k}, s{S_NULL + k}")
         a(f"s_mov_b32 s{S_TIDX}, 0")
 
         def load_next():
@@ -484,7 +507,8 @@ class Gen:
             a(f"s_mov_b32 s{S_CUR_C_OFF}, s{S_NXC_OFF}")
             a(f"s_mov_b32 s{S_CUR_N0}, s{S_NXN0}")
             a(f"s_mov_b32 s{S_CUR_R_OFF}, s{S_NXR_OFF}")
-            a(f"s_mov_b32 s{S_CURPAIR}, s{S_NXPAIR}")
+            if not self.defer:                                # (s18 is part of the held tile's descriptor there)
+                a(f"s_mov_b32 s{S_CURPAIR}, s{S_NXPAIR}")
 
         # ---- kernel prologue: tile 0's descriptors, its first two K-steps, 32 null stores (the first K-step's vmcnt count assumes an epilogue
         # before it; side-input variants: + the 4 loads of side block 7), its first fragments
@@ -508,7 +532,7 @@ class Gen:
         a("s_barrier")
         # VMEM operations between a tile's last DMA piece and the next tile's first K-step: the epilogue's stores (4 per A fragment row) and, with
         # 8 side blocks, the four loads of the block requested behind the last piece (checked against the generated order below)
-        n_epi_vm = 4 * ni * (2 if self.two_out else 1) + (4 if (self.side and ni == 8) else 0)
+        n_epi_vm = 4 * ni * (2 if self.two_out else 1) + (4 if (self.side and ni == 8) else 0) - (16 if self.defer else 0)
         for _ in range(n_epi_vm):
             a(f"buffer_store_dword v{V_T}, v{V_CST}, s[{S_NULL}:{S_NULL + 3}], 0 offen")
         a("s_nop 1")
@@ -523,7 +547,7 @@ class Gen:
         a(f"s_mov_b32 s{S_PAIRS}, s{S_NPAIRS}")
         # first pair.  vmcnt of its first barrier E: younger than this tile's second K-step (issued during the previous tile's last step) are
         # the previous epilogue's VMEM operations, the 8 bias loads of phase 0 and the 8 DMA pieces issued before the barrier
-        self.step(0, first=True, n_e=n_epi_vm + 8 + 8, bias_loads=True)
+        self.step(0, first=True, n_e=n_epi_vm + (16 if self.defer else 0) + 8 + 8, bias_loads=True)
         self.step(1)
         tail_state = [(t[0],) + t[2:] for t in a.lds[-24:]]
         a(f"s_sub_u32 s{S_PAIRS}, s{S_PAIRS}, 1")
@@ -651,6 +675,11 @@ class Gen:
                     a(f"v_mov_b32_dpp v{T + r}, v{T + 4 + r} row_ror:8 row_mask:0xf bank_mask:0xc")
                 for r in range(4):
                     a(f"v_mov_b32_dpp v{T + 4 + r}, v{T + 12 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
+                if self.defer and i >= ni - 4:
+                    H = V_HOLD + 8 * (2 * (i - (ni - 4)) + slab)
+                    for r in range(8):
+                        a(f"v_mov_b32 v{H + r}, v{T + r}")
+                    continue
                 a(f"s_add_u32 s{S_T}, s{S_SOFF}, {128 * slab}")
                 nt = " nt" if self.gelu else ""            # (the FFN activations: 107 MB per output that nothing reads before the next GEMM -- streaming stores, as in the 8-wave kernel)
                 a.vmem("store", f"buffer_store_dwordx4 v[{T}:{T + 3}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen{nt}")
@@ -676,6 +705,9 @@ class Gen:
                     n_store += 2
             a(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, s{S_LDC16}")
         assert a.younger_vm("dma") == n_epi_vm, (a.younger_vm("dma"), n_epi_vm)
+        if self.defer:
+            for k in range(4):
+                a(f"s_mov_b32 s{S_PREVC + k}, s{S_RSC + k}")
         # ---- next tile
         a(f"s_sub_u32 s{S_TILE}, s{S_TILE}, 1")
         a(f"s_cmp_eq_u32 s{S_TILE}, 0")
@@ -685,6 +717,9 @@ class Gen:
         load_next()
         a(f"s_branch {l_tile}")
         a(f"{l_done}:")
+        if self.defer:
+            for u in range(8):
+                self.flush_unit(u)
         a("s_waitcnt vmcnt(0) lgkmcnt(0)")
         return a.l
 

@@ -491,18 +491,19 @@ def test_driver_build_entry_point_runs_on_the_shipped_library(monkeypatch):
 
 
 def test_measurement_options_of_the_asm_generator_are_correct_on_paper():
-    """scripts/gen_w4a.py OUT block_waits early_side writes a VARIANT file for a measurement build (scripts/experiments/w4a_variant_ab.sh; the shipped .inc is
-    generated without options): per-block side-input waits in the epilogue, and the side-input blocks that live in registers the K loop never uses requested
-    one K-step earlier.  Both must pass the race checker and reproduce numpy in emulation before they cost a GPU minute."""
+    """scripts/gen_w4a.py OUT block_waits early_side defer_stores writes a VARIANT file for a measurement build (scripts/experiments/w4a_variant_ab.sh; the
+    shipped .inc is generated without options): per-block side-input waits in the epilogue, the side-input blocks that live in registers the K loop never
+    uses requested one K-step earlier, and (plain bodies) half of a tile's stores issued from the next tile's first K-step.  All must pass the race checker
+    and reproduce numpy in emulation before they cost a GPU minute."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     try:
         import w4a_emulate as W
         import w4a_hazard_check as H
     finally:
         sys.path.pop(0)
-    opts = ("block_waits", "early_side")
+    opts = ("block_waits", "early_side", "defer_stores")
     assert H.check_all(shapes=((256, 2), (384, 2)), opts=opts) == 18 * 2
-    for ni, bkm, epi in ((8, False, "dropres"), (7, True, "mulaux"), (7, False, "resid")):
+    for ni, bkm, epi in ((8, False, "dropres"), (7, True, "mulaux"), (7, False, "resid"), (8, True, "plain"), (7, False, "plain")):
         worst, guards = W.run_case(ni, bkm, epi, 32 * ni + 80, 512, 384, opts=opts)
         assert worst <= 1.0 and guards, (ni, bkm, epi, worst, guards)
 
