@@ -67,7 +67,10 @@ def relaunch(n):
 def csrc_sha():
     """Identity of the kernel sources a PMC traffic file must have been collected on to be quoted."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "*.h*"))):
+    d = os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc")
+    # every text the compiler reads: *.hip, *.h and the generated *.inc (the asm GEMM's bodies are in gemm_w4a_asm.inc)
+    for f in sorted(glob.glob(os.path.join(d, "*.h*")) + glob.glob(os.path.join(d, "*.inc"))):
+        h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
