@@ -60,14 +60,13 @@ class WgradItem(C.Structure):
 LAST_BUILD = None        # "compiled" | "reused": what the last build() call did (printed by __graft_entry__.build)
 
 
-def build(verbose: bool = False, force: bool = False, variants: bool = False) -> str:
+def build(verbose: bool = False, force: bool = False) -> str:
     """Compile every HIP source for gfx950 into one shared library, in-tree (it travels with the snapshot).
-    force: compile even when the library is newer than every source (the driver's "does it build" check must compile, not trust mtimes).
-    variants: -DDIC_GEMM_VARIANTS, the measurement build that also carries the round-3 K-loop alternatives (gemm_pp.h, gemm_w4.h)."""
+    force: compile even when the library is newer than every source (the driver's "does it build" check must compile, not trust mtimes)."""
     global LAST_BUILD
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "gemm_w4a.h", "gemm_w4a_asm.inc")] + [os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
-    if not force and not variants and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         LAST_BUILD = "reused"
         return LIB_PATH
     LAST_BUILD = "compiled"
@@ -78,8 +77,6 @@ def build(verbose: bool = False, force: bool = False, variants: bool = False) ->
         o = s[:-4] + ".o"
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
-        if variants:
-            cmd.insert(3, "-DDIC_GEMM_VARIANTS")
         if s.endswith("misc.hip"):
             # q_sample must round a*x, eps*b and their sum separately to be bit-exact with the reference (ref :360-362);
             # everything in misc.hip is HBM-bound, so no FMA contraction in this file costs nothing
@@ -189,6 +186,11 @@ def lib():
         options.push_to_library(L)          # the library reads no environment: its process-global switches come from the one record
         _lib = L
     return _lib
+
+
+def loaded() -> bool:
+    """True once lib() has dlopened the library in this process."""
+    return _lib is not None
 
 
 def check(rc: int, what: str = ""):

@@ -212,7 +212,8 @@ inline SeedArg make_seed(unsigned long long seed, unsigned long long stride) {
 __device__ __forceinline__ long long step_delta(const long long* ctr, long long ctr0) { return ctr ? ctr[0] - ctr0 : 0; }
 
 // ---- error plumbing for the C-ABI ----------------------------------------------------------------
-extern "C" void dic_set_error(const char* msg);
+// internal to the library (hidden visibility: not part of the C-ABI include/dic_hip.h declares; callers read dic_last_error())
+extern "C" __attribute__((visibility("hidden"))) void dic_set_error(const char* msg);
 #define DIC_CHECK_LAUNCH()                                  \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

@@ -1557,18 +1557,8 @@ __global__ __launch_bounds__(Geo<T256>::NTH, 2) void wgrad_group_kernel(DicGemmP
     cp.end();
 }
 
-// The two K-loop alternatives measured in round 3 (ping-pong loop, four-wave 256 x 256 kernel: equal or slower) are
-// compiled only into measurement builds (-DDIC_GEMM_VARIANTS, scripts/gemm_pp_check.py): the shipped library carries ONE K loop.
-#ifdef DIC_GEMM_VARIANTS
-#include "gemm_pp.h"          // gemm_pp_kernel / wgrad_group_pp_kernel: the ping-pong K loop (variant 1)
-int g_pp = 0;
-int gemm_variant() { return g_pp; }
-#include "gemm_w4.h"          // gemm_w4_kernel: 256 x 256 tiles on four waves (variant 2, k-contiguous operands only)
-#else
-int g_pp = 0;
-constexpr int gemm_variant() { return 0; }
-#endif
-inline bool pp_enabled() { return gemm_variant() == 1; }
+// (The two K-loop alternatives measured in round 3 -- ping-pong loop, C++ four-wave 256 x 256 kernel: equal or slower, DESIGN.md section 7.0 -- are no
+// longer part of the library: scripts/experiments/attic/ keeps their text.  The shipped library carries ONE 8-wave K loop + the generated asm kernel.)
 // Fold of a grouped launch: tile t = sum of its K-slices' slabs in slice order (deterministic).  Block = (tile, 16-row chunk); 256 threads x
 // (4 rows x 4 columns).  The bias gradient rides in each slab's tail.
 __global__ __launch_bounds__(256) void wgrad_group_fold_kernel(WgradGroupDev grp) {
@@ -1693,29 +1683,6 @@ void launch_bf16_cnt(const DicGemmParams& q, hipStream_t st, int grid) {
     static bool attr_set[2][64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-#ifdef DIC_GEMM_VARIANTS
-    if constexpr (std::is_same_v<C, T256> && !AKM && !BKM) {
-        if (gemm_variant() == 2) {
-            static bool attr_w4[64] = {};
-            if (dev >= 0 && dev < 64 && !attr_w4[dev]) {
-                (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-                attr_w4[dev] = true;
-            }
-            launch_timed(gemm_w4_kernel<E, CNT>, dim3(grid), dim3(256), (unsigned)G::LDS, st, q);
-            return;
-        }
-    }
-    if constexpr (std::is_same_v<C, T256>) {
-        if (pp_enabled()) {
-            if (dev >= 0 && dev < 64 && !attr_set[1][dev]) {
-                (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AKM, BKM, E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-                attr_set[1][dev] = true;
-            }
-            launch_timed(gemm_pp_kernel<AKM, BKM, E, CNT>, dim3(grid), dim3(G::NTH), (unsigned)G::LDS, st, q);
-            return;
-        }
-    }
-#endif
     if (dev >= 0 && dev < 64 && !attr_set[0][dev]) {           // per device: one process may drive several GPUs
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<C, AKM, BKM, E, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         attr_set[0][dev] = true;
@@ -1781,7 +1748,7 @@ void launch_bf16(const DicGemmParams& q, hipStream_t st) {
     const int grid = ((persist_enabled() || q.cu_cap > 0) && units > resident) ? resident : units;
 #ifndef DIC_GEMM_MIN
     if constexpr (std::is_same_v<C, T256> && !AKM && !BKM && (E == DIC_EPI_AFFINE || E == DIC_EPI_BIAS_GELU || E == DIC_EPI_BIAS_GELU_D)) {
-        if (q.split_k <= 1 && persist_enabled() && gemm_variant() == 0) {
+        if (q.split_k <= 1 && persist_enabled()) {
             const TwoHeights th = plan_two_heights(q.M, nbn_split, resident, q.K, rows);
             if (th.cA) {
 #define DIC_TWO(A_, B_) if (th.cA == A_ && th.cB == B_) { launch_bf16_two<C, BKM, E, A_, B_>(q, st, resident, th.row_split); return; }
@@ -1957,9 +1924,6 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-#ifdef DIC_GEMM_VARIANTS
-        (void)hipFuncSetAttribute((const void*)wgrad_group_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-#endif
         attr_set[dev] = true;
     }
     DicGemmParams q{};
@@ -1967,10 +1931,6 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     hipStream_t st = (hipStream_t)stream;
     tl_prof = prof_slot([&] { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * items[i].M * items[i].N * T; return f; }(),
                         [&] { double b = 0; for (int i = 0; i < n; ++i) b += ((double)items[i].M + items[i].N) * T * 2.0 + (double)items[i].M * items[i].N * 4.0; return b; }());
-#ifdef DIC_GEMM_VARIANTS
-    if (pp_enabled()) launch_timed(wgrad_group_pp_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
-    else
-#endif
     launch_timed(wgrad_group_kernel, dim3(pl.grid), dim3(G::NTH), (unsigned)G::LDS, st, q, pl.dev);
     const int tiles = pl.dev.tiles;
     if (pl.dev.split > 1) launch_timed(wgrad_group_fold_kernel, dim3(tiles, G::BM / 16), dim3(256), 0u, st, pl.dev);      // (one slice per tile: written in place)
@@ -1979,16 +1939,11 @@ extern "C" int dic_wgrad_group(const DicWgradItem* items, int n, int T, void* ws
     return 0;
 }
 
-// measurement switch (process-global, like dic_prof_*): 1 = ping-pong K loop for the 256-column geometry, 0 = the lock-step loop (default)
+// kept for ABI stability: the alternative K loops (round 3) left the library; 0 is the only variant
 extern "C" int dic_gemm_set_variant(int v) {
-#ifdef DIC_GEMM_VARIANTS
-    g_pp = (v == 1 || v == 2) ? v : 0;
-    return 0;
-#else
     if (v == 0) return 0;
-    dic_set_error("dic_gemm_set_variant: this library was built without -DDIC_GEMM_VARIANTS (the alternative K loops are measurement-build only)");
+    dic_set_error("dic_gemm_set_variant: the library carries one K loop (the round-3 alternatives are in scripts/experiments/attic/)");
     return 1006;
-#endif
 }
 // One setter for every process-global switch of the library (include/dic_hip.h lists the names); returns 0, or 1007 for an unknown name.
 extern "C" int dic_set_option(const char* name, int value) {
@@ -2000,7 +1955,6 @@ extern "C" int dic_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_w4a")) g_w4a = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0x3FF;
     else if (!strcmp(name, "gemm_w4a_rows")) { if (value != 0 && value != 224 && value != 256) { dic_set_error("dic_set_option: gemm_w4a_rows is 0 (per launch), 224 or 256"); return 1007; } g_w4a_rows = value; }
-    else if (!strcmp(name, "gemm_variant")) return dic_gemm_set_variant(value);
     else { dic_set_error("dic_set_option: unknown option"); return 1007; }
     return 0;
 }
@@ -2140,15 +2094,15 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
                     "dic_gemm: split-K needs the plain fp32-output AFFINE epilogue, ldc == N and a workspace of split_k*(M*N [+M]) floats");
     if (p.out_f32 & DIC_RES_IS_F32)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && epi == DIC_EPI_AFFINE && (p.out_f32 & DIC_OUT_F32) && p.R != nullptr && p.N % 8 == 0 && !p.accumulate &&
-                    p.split_k <= 1 && gemm_variant() == 0,
+                    p.split_k <= 1,
                     "dic_gemm: an fp32 residual (out_f32 = DIC_OUT_F32 | DIC_RES_IS_F32) is an option of the bf16 LDS-DMA kernels' AFFINE epilogue (row-major A, N % 8 == 0, fp32 C)");
     if (p.B2)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && !b_km && (epi == DIC_EPI_AFFINE || epi == DIC_EPI_BIAS_GELU || epi == DIC_EPI_BIAS_GELU_D) && p.split_k <= 1 &&
-                    ((uintptr_t)p.B2 % 16) == 0 && gemm_variant() == 0 && p.b2_col0 >= 0 && p.b2_col0 % 256 == 0,
+                    ((uintptr_t)p.B2 % 16) == 0 && p.b2_col0 >= 0 && p.b2_col0 % 256 == 0,
                     "dic_gemm: B2 (low-order weight half) is an option of the bf16 forward GEMMs (k-contiguous A and B, AFFINE / BIAS_GELU, no split-K)");
     if (p.bias2)
         DIC_REQUIRE(dtype == DIC_BF16 && !bf16_on_v1() && !a_km && epi == DIC_EPI_AFFINE && p.R != nullptr && p.p_drop > 0.f && !p.out_f32 && !p.accumulate && p.N % 8 == 0 &&
-                    p.split_k <= 1 && ((uintptr_t)p.bias2 % 16) == 0 && (p.tile == 256 || p.tile == 0 || p.tile == 128) && gemm_variant() == 0,
+                    p.split_k <= 1 && ((uintptr_t)p.bias2 % 16) == 0 && (p.tile == 256 || p.tile == 0 || p.tile == 128),
                     "dic_gemm: bias2 (a bias row behind the dropout) is an option of the bf16 forward AFFINE epilogue with dropout and a bf16 residual (N % 8 == 0); "
                     "without dropout add it to `bias`");
     if (epi == DIC_EPI_CE_EXP)

@@ -6,7 +6,7 @@
 #include <string.h>
 
 static thread_local char g_err[256] = "";
-extern "C" void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
+extern "C" __attribute__((visibility("hidden"))) void dic_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* dic_last_error(void) { return g_err; }
 extern "C" int dic_version(void) { return DIC_HIP_VERSION; }
 

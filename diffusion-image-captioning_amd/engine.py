@@ -439,7 +439,7 @@ class Denoiser:
 
         cen = self.cen and not raw
         tails = {}                                     # Linear -> bias row (b + W h_ref) that the LayerNorm launch writing its CENTRED input has left for it
-        assert not (raw and torch.is_grad_enabled() and self.training and self.cen), "encode(raw=True) is forward-only: backward() would read reference rows this pass did not write"
+        ws["raw_fwd"] = bool(raw) and (self.cen or self.res32 or self.split_w)      # backward() refuses a pass that skipped the parity corrections it differentiates
 
         def slot(n):
             out = _p(ws["beff"]) + beff_off[0] * 4
@@ -605,6 +605,9 @@ class Denoiser:
         ws = self._saved
         assert ws is not None, "backward() without a saved forward"
         assert ws.get("has_u", True), "backward() after a forward run under torch.no_grad() (the FFN pre-activations were not kept)"
+        if ws.get("raw_fwd", False):
+            raise RuntimeError("backward() after encode(raw=True): the raw pass is forward-only (it skipped the reference rows / fp32 residual copies / "
+                               "lo-weight corrections this engine's backward reads)")
         N, L, Tk, T, D, Hd = ws["N"], ws["L"], ws["Tk"], ws["T"], self.dim, self.hidden
         o, P, lib = self.ops, self.params, self.ops.L
         o.begin()
@@ -699,11 +702,10 @@ class Denoiser:
 
         rank1 = []                                    # (dW, db, x_ref, M, N): weight gradients whose X was stored centred
 
-        def flush_rank1():
+        def flush_rank1(todo):
             """dW += db x_ref^T for the Linears that read a CENTRED tensor (X = X_c + 1 x_ref^T; the GEMM contracted dY with X_c): behind
-            the launch that wrote dW and db, on the same stream."""
-            todo = list(rank1)
-            rank1.clear()
+            the launch that wrote dW and db, on the same stream.  `todo` = the entries of THAT launch only -- entries of grouped items still
+            waiting in `items` stay in `rank1` until flush_group launches them (dic_wgrad_group overwrites dW in place)."""
             if todo:
                 def launch():
                     for dW_, db_, xr_, M_, N_ in todo:
@@ -714,10 +716,10 @@ class Denoiser:
             """dW[M][N] = dY^T X over all T tokens: (k-major, k-major) GEMM, split along K to fill the chip; in bf16 mode the
             bias gradient colsum(dY) comes out of the same launch (fp32 mode: separate dic_colsum).
             x_ref: X holds bf16(input - x_ref) (centred stream): dW is completed by db x_ref^T (db: the gradient of bias_slot / db_slot)."""
-            if x_ref:
-                rank1.append((P.ptr(slot, "G"), P.ptr(bias_slot if bias_slot is not None else db_slot, "G"), x_ref, M, N))
+            r1 = [(P.ptr(slot, "G"), P.ptr(bias_slot if bias_slot is not None else db_slot, "G"), x_ref, M, N)] if x_ref else []
             if group and M % 256 == 0 and N % 8 == 0 and (gmode in ("1", "pair") or slot.endswith(("Wo", "Wqkv"))):
                 items.append(_lib.WgradItem(dY=dY, ldy=lda, X=X, ldx=ldb, dW=P.ptr(slot, "G"), db=P.ptr(bias_slot, "G") if bias_slot is not None else 0, M=M, N=N))
+                rank1.extend(r1)                      # completed behind the group launch that writes this dW (flush_group)
                 return
             sk, tile = pick_split_k(M, N, T, 64 if self.bf16 else 32)
             if not self.bf16:
@@ -730,7 +732,7 @@ class Denoiser:
                 o.gemm(dY, X, P.ptr(slot, "G"), M, N, T, lda, ldb, N, a_km=1, b_km=1, out_f32=1, split_k=sk, split_ws=skw if sk > 1 else 0,
                        colsum_out=cs, tile=tile, cu_cap=OPT.wgrad_cu_cap if use_side else 0)
             on_side(launch)
-            flush_rank1()
+            flush_rank1(r1)
             if bias_slot is not None and not self.bf16:
                 colsum(self.dt, dY, T, M, lda, P.ptr(bias_slot, "G"))
 

@@ -85,8 +85,10 @@ def fit(model, trainer, train_loader, val_loader, epochs=None, scheduler="linspa
     early_stopped = False
     history = []
     model.train()
-    if parallel.world_size() > 1 and not diffusion._state.get("t_seed_shared", False):
-        parallel.share_timestep_seed()           # the explicit synchronisation point of the shared timestep stream (every rank is here)
+    if parallel.world_size() > 1:
+        # the explicit synchronisation point of the shared timestep stream.  UNCONDITIONAL: the "already shared" flag is rank-local (a seed set or a
+        # checkpoint restored on some ranks only would make them disagree on whether to enter the broadcast); re-sharing a stream that is in step is a no-op
+        parallel.share_timestep_seed()
     for epoch in range(epochs):
         acc = [0, 0, 0, 0]
         if cfg.END_LEARNING_RATE != cfg.LEARNING_RATE:

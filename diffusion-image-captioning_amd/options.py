@@ -57,14 +57,13 @@ class Options:
                                      # lin2 in training) and the two-output GELU form: both tie with the 8-wave kernel in the step (profiles/r05_w4a_mask_ab.txt)
     gemm_w4a_rows: int = 0           # tile height of the asm GEMM: 0 = per launch (256 or 224 rows, by rounds x height), 224 / 256 = forced (A/B measurements)
     gemm_two_heights: bool = False   # two tile heights per launch everywhere
-    gemm_variant: int = 0            # measurement builds (-DDIC_GEMM_VARIANTS): 1 ping-pong K loop, 2 four-wave C++ kernel
     # ---- data parallel (parallel.py)
     dp_group: int = 3                # encoder layers per gradient slice / collective
     dp_single: bool = False          # exactly one all-reduce of the whole flat buffer after the backward
     dp_cu_cap: int = 0               # > 0: the backward's persistent GEMMs keep to this many CUs while a slice is on the wire
     dp_timing: bool = False          # bracket every collective with events
     force_reducer: bool = False      # run the exchange path at world size 1 (single-GPU test of the data-parallel code path)
-    dp_timeout_s: int = 300          # rendezvous / collective timeout of the process group: a missing or dead peer ends the job with a message
+    dp_timeout_s: int = 600          # rendezvous / collective timeout of the process group: a missing or dead peer ends the job with a message
 
     def non_default(self) -> dict:
         ref = Options()
@@ -81,10 +80,13 @@ LEGACY_ENV = {
     "DIC_LN_NPART": "ln_npart", "DIC_GEMM_TILE": "gemm_tile", "DIC_GEMM": "gemm_v1", "DIC_GELU_D": "gelu_d", "DIC_CE_FUSED": "ce_fused",
     "DIC_HEAD_CENTER": "head_center", "DIC_UVT32": "uvt32", "DIC_SPLIT_SET": "split_set", "DIC_LO_ROW_STRIDE": "lo_row_stride", "DIC_CEN": "cen",
     "DIC_RES32": "res32", "DIC_STREAMED_ADAMW": "streamed_adamw", "DIC_SAMPLE_GRAPH": "sample_graph", "DIC_GEMM_W4A": "gemm_w4a",
-    "DIC_GEMM_TWO_HEIGHTS": "gemm_two_heights", "DIC_GEMM_PP": "gemm_variant", "DIC_DP_GROUP": "dp_group", "DIC_DP_SINGLE": "dp_single",
+    "DIC_GEMM_TWO_HEIGHTS": "gemm_two_heights", "DIC_DP_GROUP": "dp_group", "DIC_DP_SINGLE": "dp_single",
     "DIC_DP_CU_CAP": "dp_cu_cap", "DIC_DP_TIMING": "dp_timing", "DIC_FORCE_REDUCER": "force_reducer", "DIC_SAMPLE_RAW": "sample_raw",
 }
-_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_w4a_rows", "gemm_two_heights", "gemm_variant")
+# switches deleted with their losing branch: setting one means the caller expects a code path that no longer exists -- refuse instead of ignoring
+DELETED_ENV = ("DIC_SIDE_BATCH", "DIC_SIDE_PRIO", "DIC_WGRAD_GROUP_HALVES", "DIC_PAIR_FOLDS", "DIC_MUL_AUX_TILE", "DIC_GELU_FWD_TILE", "DIC_GELU_BWD_TILE",
+               "DIC_WGRAD_MAX_SPLIT", "DIC_WGRAD_TILE", "DIC_LO_MODE", "DIC_SPLIT_W", "DIC_SAMPLE_GRAPH_OFF", "DIC_GEMM_PERSIST", "DIC_GEMM_ROWS", "DIC_GEMM_PP")
+_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_w4a_rows", "gemm_two_heights")
 
 
 def _coerce(name: str, text: str):
@@ -104,6 +106,9 @@ def _coerce(name: str, text: str):
 def from_env(env=None) -> Options:
     env = os.environ if env is None else env
     o = Options()
+    gone = [v for v in DELETED_ENV if v in env]
+    if gone:
+        raise ValueError(f"{', '.join(gone)}: this switch was deleted together with the code path it selected (options.py lists the live ones)")
     for var, name in LEGACY_ENV.items():
         if var in env:
             if var == "DIC_GEMM_W4A" and env[var] == "0":       # (legacy meaning of "0": off inside sample() too)
@@ -126,8 +131,23 @@ def push_to_library(L) -> None:
     """The C library keeps four process-global switches of its own (include/dic_hip.h, dic_set_option): set them from the record."""
     for name in _LIB_OPTIONS:
         v = getattr(OPT, name)
-        if name == "gemm_variant" and not v:
-            continue                      # (a shipped build refuses a non-zero variant; zero is its only state)
         rc = L.dic_set_option(name.encode(), int(v))
         if rc:
             raise RuntimeError(f"dic_set_option({name}, {int(v)}) failed: {L.dic_last_error().decode(errors='replace')}")
+
+
+def set_option(name: str, value) -> None:
+    """Change one option at run time.  The C library's own switches (`_LIB_OPTIONS`) are process-global state of the LOADED library: assigning
+    `OPT.gemm_w4a = ...` would change what `non_default()` reports but not what runs, so they go through here (tests, A/B scripts)."""
+    if name not in {f.name for f in dataclasses.fields(Options)}:
+        raise ValueError(f"unknown option {name!r} (diffusion-image-captioning_amd/options.py lists them)")
+    if isinstance(value, str):
+        value = _coerce(name, value)
+    if name in _LIB_OPTIONS:
+        from . import _lib
+        if _lib.loaded():
+            L = _lib.lib()
+            rc = L.dic_set_option(name.encode(), int(value))
+            if rc:
+                raise RuntimeError(f"dic_set_option({name}, {int(value)}) failed: {L.dic_last_error().decode(errors='replace')}")
+    setattr(OPT, name, value)

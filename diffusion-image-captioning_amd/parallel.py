@@ -101,14 +101,14 @@ class GradReducer:
         self.G = model.params.G
         self.store = model.params
         self.handles = []            # (work handle, lo, hi) in issue order
-        # DIC_FORCE_REDUCER=1: run the exchange path at world size 1 too (single-GPU test of the data-parallel code path)
+        # options.force_reducer: run the exchange path at world size 1 too (single-GPU test of the data-parallel code path)
         from .options import OPT
         self.active = is_initialized() and (world_size() > 1 or OPT.force_reducer)
         self.group = max(1, int(OPT.dp_group))
-        # DIC_DP_SINGLE=1: north_star's literal design -- exactly ONE all-reduce of the whole flat buffer, after the backward (nothing
+        # options.dp_single: north_star's literal design -- exactly ONE all-reduce of the whole flat buffer, after the backward (nothing
         # overlaps it; A/B partner of the sliced default on the first multi-GPU run)
         self.single = bool(OPT.dp_single)
-        # DIC_DP_CU_CAP=n: while a slice is on the wire, the backward's persistent GEMMs keep to n CUs' worth of workgroups so that RCCL's
+        # options.dp_cu_cap = n: while a slice is on the wire, the backward's persistent GEMMs keep to n CUs' worth of workgroups so that RCCL's
         # kernels find free CUs (the 256-column GEMM holds 128 KB of LDS on every CU it runs on); 0 = no cap
         self.cu_cap = int(OPT.dp_cu_cap)
         self.model = model
@@ -118,7 +118,7 @@ class GradReducer:
 
     def layer_done(self, i):
         """Called by Denoiser.backward right after layer i's parameter gradients are complete (layers finish in descending
-        order).  Layers are exchanged in groups of DIC_DP_GROUP (default 3: 85 MB per collective at 12 layers -- xGMI rings are
+        order).  Layers are exchanged in groups of options.dp_group (default 3: 85 MB per collective at 12 layers -- xGMI rings are
         per-link bound, fewer and larger collectives use them better than one per layer) as soon as a group is complete."""
         if not self.active or self.single:
             return
@@ -189,7 +189,7 @@ class GradReducer:
 
 
     def allreduce_ms(self):
-        """Issue-to-completion time of this step's collectives on the compute stream (DIC_DP_TIMING=1), summed; synchronises."""
+        """Issue-to-completion time of this step's collectives on the compute stream (options.dp_timing), summed; synchronises."""
         if not self._ev:
             return None
         torch.cuda.synchronize()

@@ -139,13 +139,12 @@ size_t dic_ce_partial_bytes(int M, int N, int tile);
 size_t dic_colsum_ws_bytes(int in_dtype, int rows, int cols);
 size_t dic_ln_partial_bytes(int n_partial_blocks, int n_vectors, int D);
 
-/* Measurement switch (PROCESS-GLOBAL state, like dic_prof_* below -- not for concurrent use from several threads): which K loop the bf16
- * 256-column geometry runs.  0 (default) = the lock-step loop, 1 (env DIC_GEMM_PP=1) = the ping-pong loop of csrc/gemm_pp.h.  Results are
- * identical bit for bit (same MFMA order per accumulator); only the schedule differs.                                              */
+/* Kept for ABI stability.  The library carries ONE 8-wave K loop (+ the generated four-wave asm kernel); the round-3 alternatives it once
+ * selected are no longer built.  0 is accepted, anything else returns 1006.                                                          */
 int dic_gemm_set_variant(int pp);
 /* Every process-global switch of the library by name (the library reads no environment variable): "gemm_w4a" (0 / 1, default 0: the four-wave asm
  * GEMM where eligible), "gemm_w4a_mask" (default 0x3FF; bit 4 * b_km + v allows epilogue form v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual; bit 8: BIAS_GELU / BIAS_GELU_D without aux, bit 9: BIAS_GELU_D with aux -- k-contiguous B only), "gemm_w4a_rows" (default 0: the asm kernel's tile height per launch -- 256 or 224 rows, whichever fills the rounds of resident workgroups better; 224 / 256 force one), "gemm_two_heights" (default 0), "gemm_rows" (default 1: per-launch tile heights), "gemm_persist" (default 1: persistent grids),
- * "gemm_v1" (default 0: bf16 on the register-staged fp32-style kernel), "gemm_variant" (= dic_gemm_set_variant).  Unknown name: 1007.                */
+ * "gemm_v1" (default 0: bf16 on the register-staged fp32-style kernel).  Unknown name: 1007.                */
 int dic_set_option(const char* name, int value);
 /* Measurement / test switch (PROCESS-GLOBAL): 1 (default 0; env DIC_GEMM_TWO_HEIGHTS=1 turns it on everywhere) lets a forward GEMM of the 256-column
  * geometry run whole rounds of tall tiles followed by ONE round of shorter tiles over the remaining rows, when its units would otherwise end

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r3d
-timeout 300 python scripts/gemm_pp_check.py > gpurun_out/r3d/check.log 2>&1; tail -2 gpurun_out/r3d/check.log
+timeout 300 python scripts/experiments/attic/gemm_pp_check.py > gpurun_out/r3d/check.log 2>&1; tail -2 gpurun_out/r3d/check.log
 timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -k "gemm or wgrad or rounding" > gpurun_out/r3d/pytest_gemm.log 2>&1; tail -3 gpurun_out/r3d/pytest_gemm.log
 for i in 1 2; do
 COLD=1 TILE=256 timeout 200 python scripts/gemm_bench.py > gpurun_out/r3d/bench_xt1_$i.log 2>&1

@@ -672,8 +672,8 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, qkv_pred=True, cen=True, cen_operand=True, res32="auto", sample_raw=True, streamed_adamw=True,
-                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_two_heights=False, gemm_variant=0, dp_group=3,
-                   dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=300)
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_two_heights=False, dp_group=3,
+                   dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=600)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
     o = opts.from_env({"DIC_OPTIONS": "cen=0, wgrad_group=1,dp_group=4,gemm_w4a_mask=0xff", "DIC_WGRAD_STREAM": "0", "DIC_GEMM_W4A": "0"})
@@ -692,7 +692,20 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     for src in ("gemm.hip", "gemm_w4a.h", "attn.hip", "misc.hip", "common.h"):
         assert "getenv" not in open(os.path.join(pkg, "csrc", src)).read(), src
     L = dic.lib()
-    assert L.dic_set_option(b"gemm_w4a", 0) == 0 and L.dic_set_option(b"no_such_option", 1) != 0
+    assert L.dic_set_option(b"no_such_option", 1) != 0
+    # a switch deleted with its code path is refused, not ignored; run-time changes of the library's switches go through set_option (record and library together)
+    with pytest.raises(ValueError):
+        opts.from_env({"DIC_LO_MODE": "pass2"})
+    try:
+        opts.set_option("gemm_w4a", False)
+        assert opts.OPT.non_default().get("gemm_w4a") is False and L.dic_gemm_set_w4a(0) == 0
+        with pytest.raises(RuntimeError):
+            opts.set_option("gemm_w4a_rows", 192)
+        with pytest.raises(ValueError):
+            opts.set_option("no_such_switch", 1)
+    finally:
+        opts.set_option("gemm_w4a", True)
+    assert L.dic_gemm_set_w4a(1) == 1 and "gemm_w4a" not in opts.OPT.non_default()
 
 
 def test_unknown_precision_mode_is_refused_before_anything_else():
