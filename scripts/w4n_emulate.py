@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Functional emulation of the NARROW-tile four-wave GEMM bodies (scripts/gen_w4n.py) -- the instruction interpreter is scripts/w4a_emulate.py's; this
+file restates what csrc/gemm_w4n.h does around the asm statement for the 256 x 128 geometry (kernel arguments, tile table at LDS + 144K, per-lane
+constants with 64 columns per wave, three LDS stages) and compares C -- and GELU' of the two-output form -- with numpy on the same bf16 operands.
+
+What it pins down beyond the wide bodies' emulation: the accumulator hand-over (a[0:127] -> a[128:255] in front of the next tile's first MFMAs), the
+epilogue running as a queue under the NEXT tile's K loop (every store must hit the finished tile, through descriptors set at the tile switch; the first
+tile's phantom predecessor must store nowhere; the last tile's epilogue must run after the loop), the three-stage ring and the k-major B image at 256 B per
+k-row.
+
+    python scripts/w4n_emulate.py            (every body, K = 576 / 768 / 960: zero, one and two passes of the middle loop)
+"""
+import os
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_w4n as G  # noqa: E402
+import w4a_emulate as E  # noqa: E402
+from w4a_emulate import NL, U32, bf16_round, bf16_to_f32, key_a, key_b, km_key, hash32, gelu_parts  # noqa: E402
+
+
+class Emu(E.Emu):
+    LDS_BYTES = G.LDS_BYTES
+
+    def step(self, i):
+        ln = self.lines[i]
+        if ln.startswith("v_accvgpr_mov_b32"):
+            d, s_ = [int(x.strip()[1:]) for x in ln.split(None, 1)[1].split(",")]
+            self.A[d] = self.A[s_].copy()
+            return i + 1
+        return super().step(i)
+
+
+_BODY_CACHE = {}
+
+
+def body_lines(bkm, epi):
+    if (bkm, epi) not in _BODY_CACHE:
+        _BODY_CACHE[(bkm, epi)] = G.generate(bkm, epi)[0]
+    return _BODY_CACHE[(bkm, epi)]
+
+
+def run_case(bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False, lines=None):
+    """one workgroup walks every 256 x 128 tile of an M x N x K problem; returns (worst deviation from numpy in units of the tolerance, guards intact)"""
+    rng = np.random.default_rng(seed + 3 * bkm + len(epi) + K)
+    TM, TN = 256, 128
+    lda, ldc = K, N + 8
+    ldb = N if bkm else K
+    ldr = N + 16
+    A = bf16_round(rng.standard_normal((M, K)).astype(np.float32) * 0.5)
+    Bm = bf16_round(rng.standard_normal((K, N) if bkm else (N, K)).astype(np.float32) * 0.25)
+    bias = (rng.standard_normal(N).astype(np.float32)) if epi != "mulaux" else None
+    R = bf16_round(rng.standard_normal((M, ldr)).astype(np.float32)) if epi in ("resid", "mulaux", "dropres") else None
+    mem = np.full(32 << 20, 0xA5, dtype=np.uint8)
+    cur = [4096]
+
+    def place(arr_bytes):
+        a = cur[0]
+        mem[a:a + arr_bytes.size] = arr_bytes
+        cur[0] = (a + arr_bytes.size + 4096 + 255) & ~255
+        return a
+    pA = place(A.astype(np.uint16).view(np.uint8).reshape(-1))
+    pB = place(Bm.astype(np.uint16).view(np.uint8).reshape(-1))
+    C_rows = M + 8
+    pC = place(np.full(C_rows * ldc * 2, 0x5C, dtype=np.uint8))
+    pBias = place(bias.view(np.uint8).reshape(-1)) if bias is not None else 0
+    if R is not None:
+        pR = place(R.astype(np.uint16).view(np.uint8).reshape(-1))
+    elif epi == "gelud":
+        pR = place(np.full(C_rows * ldr * 2, 0x6D, dtype=np.uint8))
+    else:
+        pR = 0
+    args = struct.pack("<5Q8i", pA, pB, pC, pBias, pR, M, N, K, lda, ldb, ldc, ldr, 0)
+    # ---- tile table + per-lane constants (csrc/gemm_w4n.h)
+    tiles = [(bm, bn) for bm in range((M + TM - 1) // TM) for bn in range(N // TN)]
+    emu_lds = np.zeros(Emu.LDS_BYTES, dtype=np.uint8)
+    for k, (bm, bn) in enumerate(tiles):
+        m0, n0 = bm * TM, bn * TN
+        e = struct.pack("<4I", (m0 * lda * 2) & 0xFFFFFFFF, (n0 * 2 if bkm else n0 * ldb * 2) & 0xFFFFFFFF, ((m0 * ldc + n0) * 2) & 0xFFFFFFFF, n0)
+        emu_lds[G.TABLE_OFF + 16 * k: G.TABLE_OFF + 16 * k + 16] = np.frombuffer(e, dtype=np.uint8)
+        e2 = struct.pack("<2I", ((m0 * ldr + n0) * 2) & 0xFFFFFFFF, ((m0 * N + n0) >> 1) & 0xFFFFFFFF)
+        o2 = G.TABLE_OFF + 16 * 512 + 16 * k
+        emu_lds[o2:o2 + 8] = np.frombuffer(e2, dtype=np.uint8)
+    tid = np.arange(NL)
+    lane, wave = tid & 63, tid >> 6
+    wm, wn, g, t = wave >> 1, wave & 1, lane >> 4, lane & 15
+    r8, chunk = lane >> 3, lane & 7
+    rowA0 = 8 * wave + r8
+    voA0 = rowA0 * lda * 2 + ((chunk ^ key_a(rowA0)) << 4)
+    if not bkm:
+        voBbase = (32 * wave + r8) * ldb * 2                              # B piece j covers tile rows 8 (4 wave + j) + r8
+        chunkx = chunk ^ ((r8 >> 1) & 1)
+        rowb = wn * 64 + 8 * (t >> 2) + (t & 3)
+        aB0 = G.B_BASE + rowb * 128 + ((g ^ key_b(rowb)) << 4)
+    else:
+        r4 = lane >> 4                                                    # B piece j covers k-rows 4 (4 wave + j) + r4, 16 chunks of 16 B each
+        voBbase = (16 * wave + r4) * ldb * 2
+        chunkx = (lane & 15) ^ (2 * r4)
+        rho, c0 = 8 * g + (t >> 2), wn * 8 + (t & 3)
+        aB0 = G.B_BASE + rho * 256 + ((c0 ^ km_key(rho)) << 4)
+    rowa = wm * 128 + t
+    aA0 = rowa * 128 + ((g ^ key_a(rowa)) << 4)
+    lrow, lcol = wm * 128 + (t & 7), wn * 64 + 8 * (g + 4 * (t >> 3))
+    seed64 = 0x123456789ABCDEF
+    dkey = (seed64 & 0xFFFFFFFF) ^ int(hash32(seed64 >> 32))
+    thr = int(p_drop * 65536.0 + 0.5)
+    opv = dict(tbl=np.full(NL, G.TABLE_OFF), voA0=voA0, voBbase=voBbase, chunkx=chunkx, aA0=aA0, aB0=aB0, cst=(lrow * ldc + lcol) * 2, boff=(wn * 64 + 8 * g) * 4,
+               rst=(lrow * ldr + lcol) * 2, pairb=((wm * 128 + t) * N + (wn * 64 + 8 * g)) >> 1)
+    w4 = np.arange(4)
+    ops = dict(karg=np.zeros(4), ntiles=np.full(4, len(tiles)), m0A=w4 * 1024, m0B=G.B_BASE + w4 * 4096, dkey=np.full(4, dkey), dthr=np.full(4, thr),
+               dinv=np.full(4, int(np.float32(65536.0 / (65536.0 - thr)).view(np.uint32))))
+    if lines is None:
+        lines = body_lines(bkm, epi)
+    emu = Emu(lines, {k: np.asarray(v, dtype=np.uint64) for k, v in opv.items()}, ops, args, mem)
+    emu.lds[:] = emu_lds
+    emu.run(max_instr=6_000_000)
+    # ---- reference on the same bf16 operands
+    Af, Bf = bf16_to_f32(A).astype(np.float64), bf16_to_f32(Bm).astype(np.float64)
+    acc = Af @ (Bf if bkm else Bf.T)
+    if bias is not None:
+        acc = acc + bias.astype(np.float64)
+    want_aux = None
+    if epi in ("resid", "dropres", "mulaux"):
+        Rf = bf16_to_f32(R[:, :N]).astype(np.float64)
+    if epi == "dropres":
+        mi, nj = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+        pairi = (mi * N + nj) >> 1
+        h = hash32(np.uint64(dkey) ^ pairi.astype(np.uint64))
+        u16 = np.where((nj & 1) == 0, h & 0xFFFF, h >> 16)
+        keep = u16 >= thr
+        acc = np.where(keep, acc * float(np.float32(65536.0 / (65536.0 - thr))), 0.0) + Rf
+    elif epi == "resid":
+        acc = acc + Rf
+    elif epi == "mulaux":
+        acc = acc * Rf
+    elif epi in ("gelu", "gelud"):
+        acc, want_aux = gelu_parts(acc)
+    got_raw = mem[pC:pC + C_rows * ldc * 2].view(np.uint16).reshape(C_rows, ldc)
+    got = bf16_to_f32(got_raw[:M, :N].astype(U32)).astype(np.float64)
+    tol = np.abs(acc) * 2.0 ** -7 + 2e-3
+    worst = float((np.abs(got - acc) / tol).max())
+    guard_ok = bool((got_raw[M:] == 0x5C5C).all() and (got_raw[:M, N:] == 0x5C5C).all())
+    if epi == "gelud":
+        aux_raw = mem[pR:pR + C_rows * ldr * 2].view(np.uint16).reshape(C_rows, ldr)
+        gaux = bf16_to_f32(aux_raw[:M, :N].astype(U32)).astype(np.float64)
+        worst = max(worst, float((np.abs(gaux - want_aux) / (np.abs(want_aux) * 2.0 ** -7 + 2e-3)).max()))
+        guard_ok = guard_ok and bool((aux_raw[M:] == 0x6D6D).all() and (aux_raw[:M, N:] == 0x6D6D).all())
+    if verbose:
+        print(f"{'KM' if bkm else 'KC'} {epi:8s} M={M} N={N} K={K}: {len(tiles)} tiles, {emu.n} instructions, worst deviation {worst:.3f} of the tolerance, "
+              f"guards {'intact' if guard_ok else 'OVERWRITTEN'}", flush=True)
+    return worst, guard_ok
+
+
+if __name__ == "__main__":
+    bad = 0
+    shapes = [(336, 256, 576), (336, 256, 768)] if len(sys.argv) < 2 else [tuple(int(x) for x in sys.argv[1:4])]
+    for bkm, epi in G.BODIES:
+        for M, N, K in shapes:                                # two row tiles (the second ragged) x two column tiles
+            worst, guard_ok = run_case(bkm, epi, M, N, K, verbose=True)
+            bad += (worst > 1.0) or not guard_ok
+    print("all narrow bodies reproduce numpy" if not bad else f"{bad} (body, shape) cases DIFFER")
+    sys.exit(1 if bad else 0)
