@@ -65,7 +65,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     force: compile even when the library is newer than every source (the driver's "does it build" check must compile, not trust mtimes)."""
     global LAST_BUILD
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "gemm_w4a.h", "gemm_w4a_asm.inc")] + [os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "gemm_w4a.h", "gemm_w4a_asm.inc", "gemm_w4n.h", "gemm_w4n_asm.inc")] + [os.path.join(os.path.dirname(HERE), "include", "dic_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         LAST_BUILD = "reused"
         return LIB_PATH

@@ -1648,6 +1648,7 @@ bool persist_enabled() { return g_persist == 1; }
 bool rows_enabled() { return g_rows == 1; }          // 0: always full-height tiles (A/B measurements)
 
 #include "gemm_w4a.h"         // gemm_w4a_kernel: the hand-scheduled four-wave kernel (round 4; DIC_GEMM_W4A)
+#include "gemm_w4n.h"         // gemm_w4n_kernel: its narrow-tile form with the epilogue under the next tile's K loop (round 6; option gemm_w4n)
 
 // Tile height for a k-contiguous A (the token dimension of the forward / input-gradient GEMMs).  With full-height tiles the tile count
 // rarely fills whole rounds of resident workgroups (17 408 tokens x 768 columns = 204 tiles of 256x256 on 256 CUs: one round at 80 %;
@@ -1954,6 +1955,9 @@ extern "C" int dic_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_two_heights")) g_two_heights = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4a")) g_w4a = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0x3FF;
+    else if (!strcmp(name, "gemm_w4n")) g_w4n = value ? 1 : 0;
+    else if (!strcmp(name, "gemm_w4n_mask")) g_w4n_mask = value & 0x3FF;
+    else if (!strcmp(name, "gemm_w4n_kmax")) { if (value < 576) { dic_set_error("dic_set_option: gemm_w4n_kmax is at least 576 (the narrow bodies need nine K-steps)"); return 1007; } g_w4n_kmax = value; }
     else if (!strcmp(name, "gemm_w4a_rows")) { if (value != 0 && value != 224 && value != 256) { dic_set_error("dic_set_option: gemm_w4a_rows is 0 (per launch), 224 or 256"); return 1007; } g_w4a_rows = value; }
     else { dic_set_error("dic_set_option: unknown option"); return 1007; }
     return 0;
@@ -2114,7 +2118,8 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (w4a_mode() == 1) {
         const int w4v = w4a_variant(dtype, a_km, b_km, epi, p);
         if (w4v >= 0) {
-            launch_w4a(p, b_km, w4v, st);
+            if (w4n_eligible(w4v, b_km, p)) launch_w4n(p, b_km, w4v, st);
+            else launch_w4a(p, b_km, w4v, st);
             DIC_CHECK_LAUNCH();
             return 0;
         }

@@ -80,6 +80,7 @@ class Queue:
 
     def __init__(self):
         self.items = []
+        self.n_head = 0
 
     def __call__(self, text):
         self.items.append(("ins", text))
@@ -215,7 +216,8 @@ class Gen:
                     if n:
                         q(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDR8}")
                     q.vmem(("side", blk), f"buffer_load_dwordx4 v[{r}:{r + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen")
-        q(f"s_mov_b32 s{S_SOFF}, 0")
+        q.n_head = len(q)                                     # the load section: issued during the first K-step, consumed from the second on (a wait for
+        q(f"s_mov_b32 s{S_SOFF}, 0")                          # these loads also waits for every OLDER operation -- the DMA pieces of the K-steps in flight)
         if self.epi != "mulaux":
             q.wait_vm("bias")
         for i in range(NI):
@@ -595,14 +597,18 @@ class Gen:
         l_tile, l_mid, l_last, l_done = a.label("tile"), a.label("mid"), a.label("last"), a.label("done")
         q = self.epilogue_queue()
         total = len(q)
-        # MFMA slots that drain the queue: the first triple from its second phase on (the first phase carries the accumulator moves) + the last triple
-        n_slots = (6 * 64 - 32)
-        quota = max(2, -(-total // (n_slots - 24)))            # (a margin of 24 slots: wait markers that turn into nothing still use their turn)
+        # MFMA slots that drain the queue: the first K-step's second phase issues its loads (the first phase carries the accumulator moves), the
+        # arithmetic and the stores go into the other two K-steps of the first triple and the three of the last
+        n_slots = 5 * 64
+        quota = max(2, -(-(total - q.n_head) // (n_slots - 24)))            # (a margin of 24 slots: wait markers that turn into nothing still use their turn)
         self.quota = quota
         a(f"{l_tile}:")
         a(f"s_sub_u32 s{S_CNT}, s{S_TRIP}, 3")
         self.region += 1
-        self.step(0, first=True, q=q, quota=quota, q_from_phase=1)
+        head = Queue()
+        head.items, q.items = q.items[:q.n_head], q.items[q.n_head:]
+        self.step(0, first=True, q=head, quota=-(-q.n_head // 32), q_from_phase=1)
+        assert not head.items
         self.step(1, q=q, quota=quota)
         self.step(2, q=q, quota=quota)
         self.close_loads()

@@ -585,6 +585,88 @@ def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic
     assert not runs([f"s_add_u32 m0, s{G.S_M0A}, 0", dma]) and runs([f"s_add_u32 m0, s{G.S_M0A}, 0", "s_nop 0", dma])
 
 
+def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(tmp_path):
+    """Round 6: the narrow-tile bodies (scripts/gen_w4n.py -> csrc/gemm_w4n_asm.inc; 256 x 128 tiles, three LDS stages, the finished tile's epilogue drained as
+    filler instructions under the next tile's K loop).  (1) the committed file is what the committed generator writes; 12 unrolled K-steps of 64 MFMAs and 13
+    barriers (one per K-step + the prologue's) per body.  (2) functional emulation (scripts/w4n_emulate.py): all nine bodies reproduce numpy on a problem with
+    a ragged second row tile and two column tiles, with zero and with one pass of the middle loop, guard bytes intact; a single-tile launch (prologue + post-loop
+    epilogue only) too; mutations -- one accumulator move dropped, one fragment-read offset, one B piece's LDS target -- must change the result.  (3) symbolic
+    execution (scripts/w4n_hazard_check.py): every counted wait, the barrier of every K-step and the accumulator hand-over (each of a[128:255] filled once and
+    read once per tile) hold for K = 576 ... 2304 and 1-3 tiles; mutations -- every barrier dropped, lgkmcnt(0) removed from every barrier's wait, the barrier
+    waits' vmcnt weakened -- must be reported."""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import gen_w4n as G
+        import w4n_emulate as W
+        import w4n_hazard_check as H
+    finally:
+        sys.path.pop(0)
+    out = tmp_path / "w4n.inc"
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_w4n.py"), str(out)], check=True, capture_output=True)
+    want = open(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "gemm_w4n_asm.inc")).read()
+    assert open(out).read() == want, "regenerate: python scripts/gen_w4n.py diffusion-image-captioning_amd/csrc/gemm_w4n_asm.inc"
+    bodies = re.findall(r"#define (W4N_BODY_\w+) \\\n((?:    \".*\n?)+)", want)
+    assert len(bodies) == 9
+    for name, text in bodies:
+        assert text.count("v_mfma_f32_16x16x32_bf16") == 12 * 64 and text.count("s_barrier") == 13, name
+        assert text.count("v_accvgpr_mov_b32") == 2 * 128, name                         # the first K-step's hand-over + the one in front of the last tile's epilogue
+        assert all(int(n) <= 15 for n in re.findall(r"lgkmcnt\((\d+)\)", text)) and all(int(n) <= 63 for n in re.findall(r"vmcnt\((\d+)\)", text)), name
+    # (2) emulation
+    for bkm, epi in G.BODIES:
+        for K in (576, 768):
+            worst, guards = W.run_case(bkm, epi, 336, 256, K)
+            assert worst <= 1.0 and guards, (bkm, epi, K, worst, guards)
+    worst, guards = W.run_case(False, "gelud", 200, 128, 576)
+    assert worst <= 1.0 and guards
+    lines = W.body_lines(False, "resid")
+
+    def emu_mutated(pred, mut):
+        idx = [i for i, l in enumerate(lines) if pred(l)]
+        out_ = list(lines)
+        new = mut(out_[idx[len(idx) // 2]])
+        if new is None:
+            del out_[idx[len(idx) // 2]]
+        else:
+            out_[idx[len(idx) // 2]] = new
+        try:
+            worst_, guards_ = W.run_case(False, "resid", 336, 256, 576, lines=out_)
+        except (AssertionError, IndexError):
+            return True                                       # (an address outside the emulated memory / LDS is a detection too)
+        return worst_ > 1.0 or not guards_
+    assert emu_mutated(lambda l: l.startswith("v_accvgpr_mov_b32 a200,"), lambda l: None)
+    assert emu_mutated(lambda l: l.startswith("ds_read_b128 v[40:43]"), lambda l: re.sub(r"offset:(\d+)", lambda m: f"offset:{int(m.group(1)) + 2048}", l))
+    assert emu_mutated(lambda l: l.startswith(f"s_add_u32 m0, s{G.S_M0B}, {16384 + 2048}"), lambda l: l.replace(str(16384 + 2048), str(16384 + 3072)))
+    # (3) symbolic execution
+    assert H.check_all() == 9 * 5
+    for bkm, epi in ((False, "plain"), (True, "mulaux"), (False, "gelud")):
+        lines = G.generate(bkm, epi)[0]
+
+        def reported(pred, mut, nth):
+            idx = [i for i, l in enumerate(lines) if pred(l)]
+            out_ = list(lines)
+            new = mut(out_[idx[nth]])
+            if new is None:
+                del out_[idx[nth]]
+            else:
+                out_[idx[nth]] = new
+            for K in (576, 768):
+                try:
+                    H.Sim(out_, K, 3).run()
+                except H.Violation:
+                    return True
+            return False
+        is_bar = lambda l: l == "s_barrier"
+        assert all(reported(is_bar, lambda l: None, k) for k in range(13)), (bkm, epi)
+        is_c = lambda l: "lgkmcnt(0)" in l and "vmcnt(" in l and "vmcnt(0)" not in l
+        n_c = sum(map(is_c, lines))
+        assert n_c == 12 and all(reported(is_c, lambda l: l.replace(" lgkmcnt(0)", ""), k) for k in range(n_c)), (bkm, epi)
+        weaker = lambda l: re.sub(r"vmcnt\((\d+)\)", lambda m: f"vmcnt({int(m.group(1)) + 1})", l)
+        caught = sum(reported(is_c, weaker, k) for k in range(n_c))
+        assert caught >= 9, (bkm, epi, caught)                # (a barrier's wait that a stricter, older wait of the epilogue queue already covers is not reportable)
+
+
 def _run_bench(argv, env_extra=None, timeout=600):
     import subprocess
     env = dict(os.environ, **(env_extra or {}))
@@ -672,7 +754,7 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, qkv_pred=True, cen=True, cen_operand=True, res32="auto", sample_raw=True, streamed_adamw=True,
-                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_two_heights=False, dp_group=3,
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_w4n=False, gemm_w4n_mask=0x3FF, gemm_w4n_kmax=1024, gemm_two_heights=False, dp_group=3,
                    dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=600)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
