@@ -2116,10 +2116,15 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % (dtype == DIC_BF16 ? 8 : 4) == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
     if (w4a_mode() == 1) {
+        const int w4nv = w4n_variant(dtype, a_km, b_km, epi, p);
+        if (w4nv >= 0) {
+            launch_w4n(p, b_km, w4nv, st);
+            DIC_CHECK_LAUNCH();
+            return 0;
+        }
         const int w4v = w4a_variant(dtype, a_km, b_km, epi, p);
         if (w4v >= 0) {
-            if (w4n_eligible(w4v, b_km, p)) launch_w4n(p, b_km, w4v, st);
-            else launch_w4a(p, b_km, w4v, st);
+            launch_w4a(p, b_km, w4v, st);
             DIC_CHECK_LAUNCH();
             return 0;
         }

@@ -55,7 +55,8 @@ V_TBL = 176              # LDS address of the tile table (same in every lane)
 V_RST = 177              # side-input lane offset (bytes)
 V_PAIRB = 242            # dropout: the lane's element-pair index inside the tile
 V_HOLD = 178             # defer_stores: 8 units x 8 packed registers (v178..v241)
-S_PREVC = 15             # defer_stores: the previous tile's C descriptor (s15..s18: the dropout scalars' registers -- plain bodies have no dropout)
+S_PREVC = 76             # defer_stores: the previous tile's C descriptor (s76..s79 = S_RSR, the side-input descriptor: plain bodies have no side input; a buffer resource must be 4-aligned --
+                         # round 5 had it in s15..s18, which the emulator and the race checker accept and the ASSEMBLER refuses: lint() now checks the alignment)
 V_GC = 178               # gelu / gelud: 8 constant pairs (both halves the same value) in v178..v193
 V_GX = 210               # gelu / gelud: the column group's second fragment (4 values) and the scratch pairs of its two pairs (v210..v225)
 V_T2 = 198               # gelud: the second output's 8 packed registers (v198..v205) and its 4 exchange temporaries (v206..v209)
@@ -501,7 +502,8 @@ class Gen:
             desc(S_RSC, S_C, S_CBYTES, S_CUR_C_OFF)
             a(f"s_lshl_b32 s{S_T + 2}, s{S_CUR_N0}, 2")
             desc(S_RSBIAS, S_BIAS, S_BIASBYTES, S_T + 2)
-            desc(S_RSR, S_R, S_RBYTES, S_CUR_R_OFF)
+            if not self.defer:                                # (defer_stores keeps the held tile's C descriptor in these registers)
+                desc(S_RSR, S_R, S_RBYTES, S_CUR_R_OFF)
 
         def take_next_offsets():
             a(f"s_mov_b32 s{S_CUR_C_OFF}, s{S_NXC_OFF}")
@@ -742,6 +744,9 @@ def lint(lines, name):
             lo = int(m.group(1) if m.group(1) is not None else m.group(3))
             hi = int(m.group(2) if m.group(2) is not None else m.group(3))
             assert all((r in S_EXTRA) or (S0 <= r <= S_LAST) for r in range(lo, hi + 1)), (name, ln)
+        if ln.startswith("buffer_"):                             # a buffer resource is four SGPRs aligned to four (the assembler refuses anything else)
+            quads = [(int(a_), int(b_)) for a_, b_ in re.findall(r"\bs\[(\d+):(\d+)\]", ln)]
+            assert quads and all(b_ - a_ == 3 and a_ % 4 == 0 for a_, b_ in quads), (name, ln)
         m = re.search(r"vmcnt\((\d+)\)", ln)
         assert m is None or int(m.group(1)) <= 63, (name, ln)
         m = re.search(r"lgkmcnt\((\d+)\)", ln)

@@ -95,9 +95,25 @@ class Queue:
         return len(self.items)
 
 
+def parse_opts(opts):
+    """measurement options (NOT in the shipped .inc; `python scripts/gen_w4n.py OUT bar=2 quota=4` writes a variant file for scripts/build_variant.sh):
+         bar=g     the K-step's barrier stands in front of phase-1 group g (default 3; 2 ... 4)
+         quota=n   at least n queued epilogue instructions per MFMA slot (default 2: light epilogues spread into the last triple; 4 keeps a plain /
+                   residual epilogue -- and all of its stores -- inside the tile's first triple)"""
+    d = dict(bar=3, quota=2)
+    for o in opts:
+        k, _, v = o.partition("=")
+        assert k in d, o
+        d[k] = int(v)
+    assert 2 <= d["bar"] <= 4 and 1 <= d["quota"] <= 16
+    return d
+
+
 class Gen:
-    def __init__(self, bkm, epi):
+    def __init__(self, bkm, epi, opts=()):
         self.bkm, self.epi = bkm, epi
+        self.o = parse_opts(opts)
+        self.BAR = self.o["bar"]
         self.a = Asm()
         self.gen = 0
         self.side = epi in ("resid", "mulaux", "dropres")
@@ -355,8 +371,6 @@ class Gen:
         self.loads_closed.update(live)
 
     # ---------------------------------------------------------------- one K-step
-    BAR = 3                                                   # phase-1 group in front of which the step's one barrier stands
-
     def step(self, stage, first=False, q=None, quota=0, q_from_phase=0):
         """first: accumulators start from 0 and the finished tile moves to a[128:255] in front of them.  q / quota: epilogue queue drained `quota`
         instructions per MFMA slot (from phase q_from_phase on)."""
@@ -383,14 +397,14 @@ class Gen:
                     put((0, i - 1, part), lambda i=i, part=part: moves(i, part))
         # ---- phase 1 fillers
         put((1, 0, 1), lambda: self.read_a(NI - 1, 1, stage, g0))
-        for j in range(NJ):
-            put((1, self.BAR, j), lambda j=j: self.read_b(j, 0, nxt, g0 + 1))
-        for i in range(4):
-            put((1, self.BAR + 1, i), lambda i=i: self.read_a(i, 0, nxt, g0 + 1))
-        put((1, 5, 0), lambda: self.read_a(4, 0, nxt, g0 + 1))
-        put((1, 6, 0), lambda: self.read_a(5, 0, nxt, g0 + 1))
-        put((1, 7, 0), lambda: self.read_a(6, 0, nxt, g0 + 1))
-        dma_slots = [(1, 3, 1), (1, 3, 3), (1, 4, 1), (1, 4, 3), (1, 5, 1), (1, 5, 2), (1, 5, 3), (1, 6, 1), (1, 6, 2), (1, 6, 3), (1, 7, 1), (1, 7, 2)]
+        for key, kind, n in self.next_frag_schedule():
+            if kind == "B":
+                put(key, lambda n=n: self.read_b(n, 0, nxt, g0 + 1))
+            else:
+                put(key, lambda n=n: self.read_a(n, 0, nxt, g0 + 1))
+        assert self.BAR + 1 <= 5                              # (A(kk0)[0..3] of the next step go into registers phase-1 groups 0-3 have finished with)
+        dma_slots = [(1, g_, sl) for g_ in range(self.BAR, NI) for sl in ((1, 3) if (g_ <= self.BAR + 1 and self.BAR < 4) else (1, 2, 3))][:12]
+        assert len(dma_slots) == 12
         for p, key in enumerate(dma_slots):
             put(key, lambda p=p: self.dma_piece(p, stage, g0 + 3))                      # K-step k + 3 into the stage this step has finished with
         # ---- the step
@@ -417,13 +431,20 @@ class Gen:
         a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
         a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
 
+    def next_frag_schedule(self):
+        """(MFMA slot, operand, fragment) of the NEXT K-step's first fragments, in issue order: behind the barrier B(kk0)[0..3], then A(kk0)[i] once phase-1
+        group i has been issued ([7]: first group of the next step)"""
+        sch = [((1, self.BAR, j), "B", j) for j in range(NJ)] + [((1, self.BAR + 1, i), "A", i) for i in range(4)] + \
+              [((1, 5, 0), "A", 4), ((1, 6, 0), "A", 5), ((1, 7, 0), "A", 6)]
+        return sorted(sch, key=lambda e: e[0])                # (stable: fragments sharing a slot keep this order)
+
     def first_frags(self, stage, gen):
-        for j in range(NJ):
-            self.read_b(j, 0, stage, gen)
-        for i in range(4):
-            self.read_a(i, 0, stage, gen)
-        for i in (4, 5, 6):
-            self.read_a(i, 0, stage, gen)
+        """the same reads in the same order without a K-step around them (kernel prologue)"""
+        for _, kind, n in self.next_frag_schedule():
+            if kind == "B":
+                self.read_b(n, 0, stage, gen)
+            else:
+                self.read_a(n, 0, stage, gen)
 
     # ---------------------------------------------------------------- the whole body
     def body(self, mimic=None):
@@ -591,6 +612,8 @@ class Gen:
         a(f"s_waitcnt vmcnt({min(63, self.younger(('dma', pgen)))})")
         a("s_barrier")
         self.first_frags(0, pgen)
+        n_tail = (2 * NJ if bkm else NJ) + 7                  # the next K-step's first fragments: what every step's text ends with
+        lds_tail = [(t[0],) + t[2:] for t in a.lds[-n_tail:]]
         self.gen = pgen
 
         # ---- tile loop
@@ -600,7 +623,7 @@ class Gen:
         # MFMA slots that drain the queue: the first K-step's second phase issues its loads (the first phase carries the accumulator moves), the
         # arithmetic and the stores go into the other two K-steps of the first triple and the three of the last
         n_slots = 5 * 64
-        quota = max(2, -(-(total - q.n_head) // (n_slots - 24)))            # (a margin of 24 slots: wait markers that turn into nothing still use their turn)
+        quota = max(self.o["quota"], -(-(total - q.n_head) // (n_slots - 24)))            # (a margin of 24 slots: wait markers that turn into nothing still use their turn)
         self.quota = quota
         a(f"{l_tile}:")
         a(f"s_sub_u32 s{S_CNT}, s{S_TRIP}, 3")
@@ -618,8 +641,7 @@ class Gen:
         self.step(1)
         self.step(2)
         second_vm = [("dma" if isinstance(t, tuple) and t[0] == "dma" else t) for t in a.vm[vm0:]]
-        n_tail = (2 * NJ if bkm else NJ) + 7                  # the next K-step's first fragments: what every step's text ends with
-        lds_tail = [(t[0],) + t[2:] for t in a.lds[-n_tail:]]
+        assert lds_tail == [(t[0],) + t[2:] for t in a.lds[-n_tail:]]          # (the prologue's order of the first fragments is every step's)
         a(f"s_cmp_eq_u32 s{S_CNT}, 0")
         a(f"s_cbranch_scc1 {l_last}")
         a(f"{l_mid}:")
@@ -675,11 +697,11 @@ class Gen:
         return a.l
 
 
-def generate(bkm, epi):
+def generate(bkm, epi, opts=()):
     """two passes: the first learns the last triple's VMEM sequence, the second replays it in the prologue"""
-    g1 = Gen(bkm, epi)
+    g1 = Gen(bkm, epi, opts)
     g1.body()
-    g2 = Gen(bkm, epi)
+    g2 = Gen(bkm, epi, opts)
     lines = g2.body(mimic=g1.last_triple_vm)
     return lines, g2
 
@@ -693,6 +715,7 @@ BODIES = [(False, e) for e in ("plain", "resid", "mulaux", "dropres", "gelu", "g
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
+    opts = tuple(sys.argv[2:])
     with open(out, "w") as f:
         f.write("// GENERATED by scripts/gen_w4n.py -- do not edit; the schedule is described there\n")
         f.write(f"#define W4N_N_OPERANDS {len(OPS)}\n")
@@ -700,7 +723,7 @@ def main():
         f.write("#define W4N_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(V_LAST + 1)] + [f'"a{i}"' for i in range(256)] +
                                                     [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"vcc"', '"scc"', '"m0"', '"memory"']) + "\n")
         for bkm, epi in BODIES:
-            lines, g = generate(bkm, epi)
+            lines, g = generate(bkm, epi, opts)
             lint(lines, (bkm, epi))
             name = f"W4N_BODY_{'KM' if bkm else 'KC'}_{epi.upper()}"
             f.write(f"#define {name} \\\n")

@@ -37,13 +37,13 @@ class Emu(E.Emu):
 _BODY_CACHE = {}
 
 
-def body_lines(bkm, epi):
-    if (bkm, epi) not in _BODY_CACHE:
-        _BODY_CACHE[(bkm, epi)] = G.generate(bkm, epi)[0]
-    return _BODY_CACHE[(bkm, epi)]
+def body_lines(bkm, epi, opts=()):
+    if (bkm, epi, opts) not in _BODY_CACHE:
+        _BODY_CACHE[(bkm, epi, opts)] = G.generate(bkm, epi, opts)[0]
+    return _BODY_CACHE[(bkm, epi, opts)]
 
 
-def run_case(bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False, lines=None):
+def run_case(bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False, lines=None, opts=()):
     """one workgroup walks every 256 x 128 tile of an M x N x K problem; returns (worst deviation from numpy in units of the tolerance, guards intact)"""
     rng = np.random.default_rng(seed + 3 * bkm + len(epi) + K)
     TM, TN = 256, 128
@@ -113,7 +113,7 @@ def run_case(bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False, lines=None):
     ops = dict(karg=np.zeros(4), ntiles=np.full(4, len(tiles)), m0A=w4 * 1024, m0B=G.B_BASE + w4 * 4096, dkey=np.full(4, dkey), dthr=np.full(4, thr),
                dinv=np.full(4, int(np.float32(65536.0 / (65536.0 - thr)).view(np.uint32))))
     if lines is None:
-        lines = body_lines(bkm, epi)
+        lines = body_lines(bkm, epi, tuple(opts))
     emu = Emu(lines, {k: np.asarray(v, dtype=np.uint64) for k, v in opv.items()}, ops, args, mem)
     emu.lds[:] = emu_lds
     emu.run(max_instr=6_000_000)

@@ -134,10 +134,10 @@ class Sim(H.Sim):
         return self.stats
 
 
-def check_all(shapes=((576, 1), (576, 3), (768, 2), (960, 2), (2304, 1)), verbose=False, bodies=None):
+def check_all(shapes=((576, 1), (576, 3), (768, 2), (960, 2), (2304, 1)), verbose=False, bodies=None, opts=()):
     n = 0
     for bkm, epi in (bodies or G.BODIES):
-        lines, _ = G.generate(bkm, epi)
+        lines, _ = G.generate(bkm, epi, opts)
         for K, ntiles in shapes:
             st = Sim(lines, K, ntiles, name=f"narrow {'KM' if bkm else 'KC'} {epi}").run()
             n += 1
