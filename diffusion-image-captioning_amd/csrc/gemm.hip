@@ -1957,6 +1957,7 @@ extern "C" int dic_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0x3FF;
     else if (!strcmp(name, "gemm_w4n")) g_w4n = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4n_mask")) g_w4n_mask = value & 0x3FF;
+    else if (!strcmp(name, "gemm_w4n_flat")) g_w4n_flat = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4n_kmax")) { if (value < 576) { dic_set_error("dic_set_option: gemm_w4n_kmax is at least 576 (the narrow bodies need nine K-steps)"); return 1007; } g_w4n_kmax = value; }
     else if (!strcmp(name, "gemm_w4a_rows")) { if (value != 0 && value != 224 && value != 256) { dic_set_error("dic_set_option: gemm_w4a_rows is 0 (per launch), 224 or 256"); return 1007; } g_w4a_rows = value; }
     else { dic_set_error("dic_set_option: unknown option"); return 1007; }

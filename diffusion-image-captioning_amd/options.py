@@ -59,6 +59,7 @@ class Options:
     gemm_w4n: bool = False           # the NARROW-tile asm GEMM (256 x 128 tiles, epilogue under the next tile's K loop: csrc/gemm_w4n.h) where eligible -- off until measured on hardware
     gemm_w4n_mask: int = 0x3FF       # which (layout, epilogue) forms may take it: the bits of gemm_w4a_mask
     gemm_w4n_kmax: int = 1024        # launches with K above this keep the 256 x 256 bodies
+    gemm_w4n_flat: bool = True       # K = 768 launches of the narrow GEMM take its loop-free bodies (False: the loop form everywhere -- A/B)
     gemm_two_heights: bool = False   # two tile heights per launch everywhere
     # ---- data parallel (parallel.py)
     dp_group: int = 3                # encoder layers per gradient slice / collective
@@ -89,7 +90,7 @@ LEGACY_ENV = {
 # switches deleted with their losing branch: setting one means the caller expects a code path that no longer exists -- refuse instead of ignoring
 DELETED_ENV = ("DIC_SIDE_BATCH", "DIC_SIDE_PRIO", "DIC_WGRAD_GROUP_HALVES", "DIC_PAIR_FOLDS", "DIC_MUL_AUX_TILE", "DIC_GELU_FWD_TILE", "DIC_GELU_BWD_TILE",
                "DIC_WGRAD_MAX_SPLIT", "DIC_WGRAD_TILE", "DIC_LO_MODE", "DIC_SPLIT_W", "DIC_SAMPLE_GRAPH_OFF", "DIC_GEMM_PERSIST", "DIC_GEMM_ROWS", "DIC_GEMM_PP")
-_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_w4a_rows", "gemm_w4n", "gemm_w4n_mask", "gemm_w4n_kmax", "gemm_two_heights")
+_LIB_OPTIONS = ("gemm_v1", "gemm_w4a", "gemm_w4a_mask", "gemm_w4a_rows", "gemm_w4n", "gemm_w4n_mask", "gemm_w4n_kmax", "gemm_w4n_flat", "gemm_two_heights")
 
 
 def _coerce(name: str, text: str):

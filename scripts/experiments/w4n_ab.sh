@@ -1,7 +1,7 @@
 #!/bin/bash
 # First hardware run of the NARROW-tile asm GEMM (csrc/gemm_w4n.h, option gemm_w4n; built and proven on the CPU only so far), on the GPU box:
 #   bash scripts/experiments/w4n_ab.sh            (through gpurun; ~12 minutes)
-# 1. parity: the narrow bodies against the wide ones bit for bit + float64 (tests/test_gpu_zz_w4n.py with --runxfail: 81 cases);
+# 1. parity: the narrow bodies against the wide ones bit for bit + float64 (tests/test_gpu_zz_w4n.py with --runxfail: 129 cases);
 # 2. per launch inside the step (scripts/gemm_in_step.py), option off / on;
 # 3. the step and the sampling pass, interleaved off / on, twice; then per (layout, epilogue) form: which forms pay (gemm_w4n_mask one bit at a time).
 R=$(cd "$(dirname "$0")/../.." && pwd); cd $R; O=$R/gpurun_out; mkdir -p $O
@@ -16,6 +16,8 @@ for i in 1 2; do
   echo "## pass, wide:    $(python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
   echo "## pass, narrow:  $(DIC_OPTIONS=gemm_w4n=1 python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
 done
+echo "## step, narrow, loop form everywhere (gemm_w4n_flat=0):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_flat=0 python bench.py --quick --no-roofline --steps 40 2>/dev/null | tail -1 | cut -c1-140)"
+echo "## pass, narrow, loop form everywhere (gemm_w4n_flat=0):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_flat=0 python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
 # which forms pay: bit 4 * b_km + v (v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual), bit 8 GELU, bit 9 GELU + GELU'
 for bit in 0 1 2 3 4 5 6 8 9; do
   m=$((1 << bit))

@@ -99,14 +99,32 @@ def parse_opts(opts):
     """measurement options (NOT in the shipped .inc; `python scripts/gen_w4n.py OUT bar=2 quota=4` writes a variant file for scripts/build_variant.sh):
          bar=g     the K-step's barrier stands in front of phase-1 group g (default 3; 2 ... 4)
          quota=n   at least n queued epilogue instructions per MFMA slot (default 2: light epilogues spread into the last triple; 4 keeps a plain /
-                   residual epilogue -- and all of its stores -- inside the tile's first triple)"""
-    d = dict(bar=3, quota=2)
+                   residual epilogue -- and all of its stores -- inside the tile's first triple)
+       and the FORM of the K loop (both forms are shipped: csrc/gemm_w4n.h takes the flat one where K allows):
+         flat=n    no loop: the tile's n K-steps (n = 12: K = 768, the model's only short K) are straight-line text and ALL of them but the first drain the epilogue queue
+                   -- with the loop form the clean middle K-steps idle at the DMA bound while the few that drain a GELU queue are issue-bound at twice that
+                   (scripts/w4n_issue_model.py)"""
+    d = dict(bar=3, quota=2, flat=0)
     for o in opts:
         k, _, v = o.partition("=")
         assert k in d, o
         d[k] = int(v)
-    assert 2 <= d["bar"] <= 4 and 1 <= d["quota"] <= 16
+    assert 2 <= d["bar"] <= 4 and 1 <= d["quota"] <= 16 and (d["flat"] == 0 or (d["flat"] % 3 == 0 and d["flat"] >= 9))
     return d
+
+
+class Pacer:
+    """How many queued instructions the next MFMA slot drains: the queue's `total` instructions spread evenly over `slots` slots (the loop-free form: the K-steps
+    then all cost the same instead of the first ones carrying a whole number per slot and the last ones nothing)."""
+
+    def __init__(self, total, slots):
+        self.total, self.slots, self.k, self.done = total, slots, 0, 0
+
+    def __call__(self):
+        self.k += 1
+        want = min(self.total, -(-self.total * self.k // self.slots))
+        n, self.done = want - self.done, want
+        return n
 
 
 class Gen:
@@ -427,7 +445,7 @@ class Gen:
                     for f in fill.get((ph, i, j), []):
                         f()
                     if q is not None and ph >= q_from_phase:
-                        self.drain(q, quota)
+                        self.drain(q, quota() if callable(quota) else quota)
         a(f"s_add_u32 s{S_KA}, s{S_KA}, 128")
         a(f"s_add_u32 s{S_KB}, s{S_KB}, s{S_KSTEPB}")
 
@@ -622,46 +640,60 @@ class Gen:
         total = len(q)
         # MFMA slots that drain the queue: the first K-step's second phase issues its loads (the first phase carries the accumulator moves), the
         # arithmetic and the stores go into the other two K-steps of the first triple and the three of the last
-        n_slots = 5 * 64
-        quota = max(self.o["quota"], -(-(total - q.n_head) // (n_slots - 24)))            # (a margin of 24 slots: wait markers that turn into nothing still use their turn)
-        self.quota = quota
+        flat = self.o["flat"]
+        n_slots = (flat - 1) * 64 if flat else 5 * 64
+        quota = max(self.o["quota"] if not flat else 1, -(-(total - q.n_head) // (n_slots - 24)))            # (a margin of 24 slots: wait markers that turn into nothing still use their turn)
+        self.quota = quota if not flat else round((total - q.n_head) / (n_slots - 16), 2)
         a(f"{l_tile}:")
-        a(f"s_sub_u32 s{S_CNT}, s{S_TRIP}, 3")
+        if not flat:
+            a(f"s_sub_u32 s{S_CNT}, s{S_TRIP}, 3")
         self.region += 1
         head = Queue()
         head.items, q.items = q.items[:q.n_head], q.items[q.n_head:]
         self.step(0, first=True, q=head, quota=-(-q.n_head // 32), q_from_phase=1)
         assert not head.items
-        self.step(1, q=q, quota=quota)
-        self.step(2, q=q, quota=quota)
-        self.close_loads()
-        self.region += 1
-        vm0 = len(a.vm)
-        self.step(0)
-        self.step(1)
-        self.step(2)
-        second_vm = [("dma" if isinstance(t, tuple) and t[0] == "dma" else t) for t in a.vm[vm0:]]
-        assert lds_tail == [(t[0],) + t[2:] for t in a.lds[-n_tail:]]          # (the prologue's order of the first fragments is every step's)
-        a(f"s_cmp_eq_u32 s{S_CNT}, 0")
-        a(f"s_cbranch_scc1 {l_last}")
-        a(f"{l_mid}:")
-        vm0 = len(a.vm)
-        self.step(0)
-        self.step(1)
-        self.step(2)
-        assert second_vm == [("dma" if isinstance(t, tuple) and t[0] == "dma" else t) for t in a.vm[vm0:]]          # the loop sees the history its first entry sees
-        assert lds_tail == [(t[0],) + t[2:] for t in a.lds[-n_tail:]]
-        a(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
-        a(f"s_cmp_eq_u32 s{S_CNT}, 0")
-        a(f"s_cbranch_scc0 {l_mid}")
-        a(f"{l_last}:")
-        next_to_cur()                                         # last triple: its DMA slots carry the next tile's first three K-steps
-        a(f"s_mov_b32 s{S_KA}, 0")
-        a(f"s_mov_b32 s{S_KB}, 0")
-        vm0 = len(a.vm)
-        self.step(0, q=q, quota=quota)
-        self.step(1, q=q, quota=quota)
-        self.step(2, q=q, quota=quota)
+        if flat:
+            # ---- loop-free form: K-steps 1 .. flat - 1 all drain the queue; the last three carry the next tile's first three K-steps in their DMA slots
+            quota = Pacer(len(q), n_slots - 16)               # (the last 16 slots stay free: a margin, and the tile's last stores are not its very last instructions)
+            for k in range(1, flat - 3):
+                self.step(k % 3, q=q, quota=quota)
+            next_to_cur()
+            a(f"s_mov_b32 s{S_KA}, 0")
+            a(f"s_mov_b32 s{S_KB}, 0")
+            vm0 = len(a.vm)
+            for k in range(flat - 3, flat):
+                self.step(k % 3, q=q, quota=quota)
+        else:
+            self.step(1, q=q, quota=quota)
+            self.step(2, q=q, quota=quota)
+            self.close_loads()
+            self.region += 1
+            vm0 = len(a.vm)
+            self.step(0)
+            self.step(1)
+            self.step(2)
+            second_vm = [("dma" if isinstance(t, tuple) and t[0] == "dma" else t) for t in a.vm[vm0:]]
+            assert lds_tail == [(t[0],) + t[2:] for t in a.lds[-n_tail:]]          # (the prologue's order of the first fragments is every step's)
+            a(f"s_cmp_eq_u32 s{S_CNT}, 0")
+            a(f"s_cbranch_scc1 {l_last}")
+            a(f"{l_mid}:")
+            vm0 = len(a.vm)
+            self.step(0)
+            self.step(1)
+            self.step(2)
+            assert second_vm == [("dma" if isinstance(t, tuple) and t[0] == "dma" else t) for t in a.vm[vm0:]]          # the loop sees the history its first entry sees
+            assert lds_tail == [(t[0],) + t[2:] for t in a.lds[-n_tail:]]
+            a(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+            a(f"s_cmp_eq_u32 s{S_CNT}, 0")
+            a(f"s_cbranch_scc0 {l_mid}")
+            a(f"{l_last}:")
+            next_to_cur()                                         # last triple: its DMA slots carry the next tile's first three K-steps
+            a(f"s_mov_b32 s{S_KA}, 0")
+            a(f"s_mov_b32 s{S_KB}, 0")
+            vm0 = len(a.vm)
+            self.step(0, q=q, quota=quota)
+            self.step(1, q=q, quota=quota)
+            self.step(2, q=q, quota=quota)
         assert not q.items, (len(q.items), total, quota)
         assert lds_tail == [(t[0],) + t[2:] for t in a.lds[-n_tail:]]
         last_vm = a.vm[vm0:]
@@ -722,14 +754,15 @@ def main():
         f.write("// operand order: " + " ".join(OPS) + "\n")
         f.write("#define W4N_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(V_LAST + 1)] + [f'"a{i}"' for i in range(256)] +
                                                     [f'"s{i}"' for i in S_EXTRA + list(range(S0, S_LAST + 1))] + ['"vcc"', '"scc"', '"m0"', '"memory"']) + "\n")
-        for bkm, epi in BODIES:
-            lines, g = generate(bkm, epi, opts)
-            lint(lines, (bkm, epi))
-            name = f"W4N_BODY_{'KM' if bkm else 'KC'}_{epi.upper()}"
-            f.write(f"#define {name} \\\n")
-            f.write(" \\\n".join('    "%s\\n\\t"' % x for x in lines))
-            f.write("\n")
-            print(f"{name}: {len(lines)} asm lines, epilogue queue drained {g.quota} per MFMA slot", file=sys.stderr)
+        for form, fopts in (("", ()), ("12", ("flat=12",))):          # the loop form (any K = 192 n >= 576) and the loop-free form for K = 768
+            for bkm, epi in BODIES:
+                lines, g = generate(bkm, epi, tuple(opts) + fopts)
+                lint(lines, (bkm, epi))
+                name = f"W4N_BODY{form}_{'KM' if bkm else 'KC'}_{epi.upper()}"
+                f.write(f"#define {name} \\\n")
+                f.write(" \\\n".join('    "%s\\n\\t"' % x for x in lines))
+                f.write("\n")
+                print(f"{name}: {len(lines)} asm lines, epilogue queue drained {g.quota} per MFMA slot", file=sys.stderr)
 
 
 if __name__ == "__main__":

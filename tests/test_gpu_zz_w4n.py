@@ -20,8 +20,8 @@ pytestmark = [pytest.mark.gpu] + ([] if HARDWARE_VERIFIED else
 
 @pytest.mark.parametrize("b_km", [0, 1])
 @pytest.mark.parametrize("kind", ["plain", "bias", "resid", "bias_resid", "mulaux", "bias_resid_drop", "bias_gelu", "bias_gelud"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 576), (768, 512, 768), (4352, 768, 768), (2304, 3072, 960), (1024, 2304, 2304)])
-def test_gemm_narrow_tile_asm_kernel_is_bit_identical_to_the_wide_one(L, M, N, K, kind, b_km):
+@pytest.mark.parametrize("M,N,K,flat", [(256, 256, 576, 1), (768, 512, 768, 1), (768, 512, 768, 0), (4352, 768, 768, 1), (4352, 3072, 768, 1), (4352, 2304, 768, 0), (2304, 3072, 960, 1), (1024, 2304, 2304, 1)])
+def test_gemm_narrow_tile_asm_kernel_is_bit_identical_to_the_wide_one(L, M, N, K, flat, kind, b_km):
     """dic_set_option("gemm_w4n", 1): launches the four-wave asm kernel accepts, with K a multiple of 192 in [576, gemm_w4n_kmax] and N a multiple of 128, run on
     the NARROW-tile bodies (csrc/gemm_w4n.h: 256 x 128 tiles, three LDS stages, the finished tile parked in a[128:255] while its epilogue is drained from the MFMA
     slots of the next tile's K loop).  Same MFMA order per accumulator, same epilogue arithmetic: the output must equal the wide bodies' BIT FOR BIT -- dropout
@@ -61,6 +61,7 @@ def test_gemm_narrow_tile_asm_kernel_is_bit_identical_to_the_wide_one(L, M, N, K
     try:
         prev = L.dic_gemm_set_w4a(1)
         assert L.dic_set_option(b"gemm_w4a_mask", 0x3FF) == 0 and L.dic_set_option(b"gemm_w4n_mask", 0x3FF) == 0 and L.dic_set_option(b"gemm_w4n_kmax", 4096) == 0
+        assert L.dic_set_option(b"gemm_w4n_flat", flat) == 0
         for narrow in (0, 1):
             Cfull = torch.full((M + 8, N), 7.0, dtype=torch.bfloat16, device="cuda")
             Cfull[:M].fill_(float("nan"))

@@ -587,8 +587,8 @@ def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic
 
 def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(tmp_path):
     """Round 6: the narrow-tile bodies (scripts/gen_w4n.py -> csrc/gemm_w4n_asm.inc; 256 x 128 tiles, three LDS stages, the finished tile's epilogue drained as
-    filler instructions under the next tile's K loop).  (1) the committed file is what the committed generator writes; 12 unrolled K-steps of 64 MFMAs and 13
-    barriers (one per K-step + the prologue's) per body.  (2) functional emulation (scripts/w4n_emulate.py): all nine bodies reproduce numpy on a problem with
+    filler instructions under the next tile's K loop; every body in a loop form for K = 192 n and a loop-free form for K = 768).  (1) the committed file is what
+    the committed generator writes; 12 K-steps of 64 MFMAs and 13 barriers (one per K-step + the prologue's) of text per body.  (2) functional emulation (scripts/w4n_emulate.py): all nine bodies reproduce numpy on a problem with
     a ragged second row tile and two column tiles, with zero and with one pass of the middle loop, guard bytes intact; a single-tile launch (prologue + post-loop
     epilogue only) too; mutations -- one accumulator move dropped, one fragment-read offset, one B piece's LDS target -- must change the result.  (3) symbolic
     execution (scripts/w4n_hazard_check.py): every counted wait, the barrier of every K-step and the accumulator hand-over (each of a[128:255] filled once and
@@ -607,8 +607,8 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_w4n.py"), str(out)], check=True, capture_output=True)
     want = open(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "gemm_w4n_asm.inc")).read()
     assert open(out).read() == want, "regenerate: python scripts/gen_w4n.py diffusion-image-captioning_amd/csrc/gemm_w4n_asm.inc"
-    bodies = re.findall(r"#define (W4N_BODY_\w+) \\\n((?:    \".*\n?)+)", want)
-    assert len(bodies) == 9
+    bodies = re.findall(r"#define (W4N_BODY(?:12)?_\w+) \\\n((?:    \".*\n?)+)", want)
+    assert len(bodies) == 18 and sum(n.startswith("W4N_BODY12_") for n, _ in bodies) == 9          # the loop form and the loop-free K = 768 form of every body
     for name, text in bodies:
         assert text.count("v_mfma_f32_16x16x32_bf16") == 12 * 64 and text.count("s_barrier") == 13, name
         assert text.count("v_accvgpr_mov_b32") == 2 * 128, name                         # the first K-step's hand-over + the one in front of the last tile's epilogue
@@ -620,6 +620,10 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
             assert worst <= 1.0 and guards, (bkm, epi, K, worst, guards)
     worst, guards = W.run_case(False, "gelud", 200, 128, 576)
     assert worst <= 1.0 and guards
+    for bkm, epi in G.BODIES:                                 # the loop-free form (what K = 768 launches take): several tiles per workgroup, and a single one
+        for M, N in ((336, 256), (200, 128)):
+            worst, guards = W.run_case(bkm, epi, M, N, 768, opts=("flat=12",))
+            assert worst <= 1.0 and guards, (bkm, epi, M, N, worst, guards)
     lines = W.body_lines(False, "resid")
 
     def emu_mutated(pred, mut):
@@ -640,8 +644,9 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
     assert emu_mutated(lambda l: l.startswith(f"s_add_u32 m0, s{G.S_M0B}, {16384 + 2048}"), lambda l: l.replace(str(16384 + 2048), str(16384 + 3072)))
     # (3) symbolic execution
     assert H.check_all() == 9 * 5
-    for bkm, epi in ((False, "plain"), (True, "mulaux"), (False, "gelud")):
-        lines = G.generate(bkm, epi)[0]
+    assert H.check_all(opts=("flat=12",), shapes=((768, 1), (768, 2), (768, 4))) == 9 * 3
+    for bkm, epi, fopts in ((False, "plain", ()), (True, "mulaux", ()), (False, "gelud", ()), (False, "gelud", ("flat=12",)), (True, "plain", ("flat=12",))):
+        lines = G.generate(bkm, epi, fopts)[0]
 
         def reported(pred, mut, nth):
             idx = [i for i, l in enumerate(lines) if pred(l)]
@@ -651,7 +656,7 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
                 del out_[idx[nth]]
             else:
                 out_[idx[nth]] = new
-            for K in (576, 768):
+            for K in ((768,) if fopts else (576, 768)):
                 try:
                     H.Sim(out_, K, 3).run()
                 except H.Violation:
@@ -754,7 +759,7 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, qkv_pred=True, cen=True, cen_operand=True, res32="auto", sample_raw=True, streamed_adamw=True,
-                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_w4n=False, gemm_w4n_mask=0x3FF, gemm_w4n_kmax=1024, gemm_two_heights=False, dp_group=3,
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_w4n=False, gemm_w4n_mask=0x3FF, gemm_w4n_kmax=1024, gemm_w4n_flat=True, gemm_two_heights=False, dp_group=3,
                    dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=600)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
