@@ -1956,7 +1956,7 @@ extern "C" int dic_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_w4a")) g_w4a = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4a_mask")) g_w4a_mask = value & 0x3FF;
     else if (!strcmp(name, "gemm_w4n")) g_w4n = value ? 1 : 0;
-    else if (!strcmp(name, "gemm_w4n_mask")) g_w4n_mask = value & 0x3FF;
+    else if (!strcmp(name, "gemm_w4n_mask")) g_w4n_mask = value & 0x7FF;
     else if (!strcmp(name, "gemm_w4n_flat")) g_w4n_flat = value ? 1 : 0;
     else if (!strcmp(name, "gemm_w4n_kmax")) { if (value < 576) { dic_set_error("dic_set_option: gemm_w4n_kmax is at least 576 (the narrow bodies need nine K-steps)"); return 1007; } g_w4n_kmax = value; }
     else if (!strcmp(name, "gemm_w4a_rows")) { if (value != 0 && value != 224 && value != 256) { dic_set_error("dic_set_option: gemm_w4a_rows is 0 (per launch), 224 or 256"); return 1007; } g_w4a_rows = value; }
@@ -2117,6 +2117,12 @@ static int dic_gemm_impl(int dtype, int a_km, int b_km, int epi, const DicGemmPa
     if (epi == DIC_EPI_CE_DLOGITS) DIC_REQUIRE(p.ldc % (dtype == DIC_BF16 ? 8 : 4) == 0 && p.ldc >= p.N && p.ldc <= ((p.N + BN - 1) / BN) * BN, "dic_gemm: dlogits ldc must cover N within the last tile");
     hipStream_t st = (hipStream_t)stream;
     if (w4a_mode() == 1) {
+        if (w4n_ce_ok(dtype, a_km, b_km, epi, p)) {
+            const int rc = launch_w4n_ce(p, st);
+            if (rc) return rc;
+            DIC_CHECK_LAUNCH();
+            return 0;
+        }
         const int w4nv = w4n_variant(dtype, a_km, b_km, epi, p);
         if (w4nv >= 0) {
             launch_w4n(p, b_km, w4nv, st);

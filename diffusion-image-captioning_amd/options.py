@@ -57,7 +57,7 @@ class Options:
                                      # lin2 in training) and the two-output GELU form: both tie with the 8-wave kernel in the step (profiles/r05_w4a_mask_ab.txt)
     gemm_w4a_rows: int = 0           # tile height of the asm GEMM: 0 = per launch (256 or 224 rows, by rounds x height), 224 / 256 = forced (A/B measurements)
     gemm_w4n: bool = False           # the NARROW-tile asm GEMM (256 x 128 tiles, epilogue under the next tile's K loop: csrc/gemm_w4n.h) where eligible -- off until measured on hardware
-    gemm_w4n_mask: int = 0x3FF       # which (layout, epilogue) forms may take it: the bits of gemm_w4a_mask
+    gemm_w4n_mask: int = 0x7FF       # which (layout, epilogue) forms may take it: the bits of gemm_w4a_mask + bit 10: the rounding-head forward (CE_EXP)
     gemm_w4n_kmax: int = 1024        # launches with K above this keep the 256 x 256 bodies
     gemm_w4n_flat: bool = True       # K = 768 launches of the narrow GEMM take its loop-free bodies (False: the loop form everywhere -- A/B)
     gemm_two_heights: bool = False   # two tile heights per launch everywhere

@@ -18,8 +18,8 @@ for i in 1 2; do
 done
 echo "## step, narrow, loop form everywhere (gemm_w4n_flat=0):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_flat=0 python bench.py --quick --no-roofline --steps 40 2>/dev/null | tail -1 | cut -c1-140)"
 echo "## pass, narrow, loop form everywhere (gemm_w4n_flat=0):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_flat=0 python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
-# which forms pay: bit 4 * b_km + v (v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual), bit 8 GELU, bit 9 GELU + GELU'
-for bit in 0 1 2 3 4 5 6 8 9; do
+# which forms pay: bit 4 * b_km + v (v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual), bit 8 GELU, bit 9 GELU + GELU', bit 10 the rounding-head forward (CE_EXP)
+for bit in 0 1 2 3 4 5 6 8 9 10; do
   m=$((1 << bit))
   echo "## step, narrow only for mask bit $bit:  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_mask=$m,gemm_w4a_mask=0x3ff python bench.py --quick --no-roofline --steps 40 2>/dev/null | tail -1 | cut -c1-140)"
 done

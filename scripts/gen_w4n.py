@@ -66,6 +66,15 @@ V_T2 = 224               # gelud: second output, 8 packed registers + 4 exchange
 V_LAST = W.V_LAST
 S_EPAIR = S_CURPAIR      # the FINISHED tile's first pair index (dropout mask of its epilogue)
 S_RUNPAIR = S_LDC2       # the running tile's (gen_w4a.py computes 2 ldc there and never uses it)
+# ---- the CE_EXP form (rounding-head forward: C = bf16(exp(acc + bias - c_row)), slab sums, target logit; k-contiguous B only).  It has no side input and no dropout:
+V_CROW = 128             # 8: the row reference points c[m] of the lane's row in each row block
+V_TG = 136               # 16: the rows' target ids (int64: lo, hi)
+V_MASK = 152             # 16: 1.0 / 0.0 per (fragment, element): column < N
+V_L2E, V_C2, V_SUM, V_TV, V_D, V_OWN, V_POFF, V_NL, V_ADR, V_S2 = 168, 170, 172, 176, 177, 178, 179, 180, 182, 184
+S_DLSE, S_DTL, S_DPART = 16, 36, 76      # buffer resources over the WHOLE lse / tgt_logit / partial arrays (constant for the kernel): s16..19 (dropout scalars), s36..39 (K, lda, ldb,
+                                          # ldc: prologue only), s76..79 (side-input descriptor)
+S_TGTP = S_R             # s32..33: the tgt pointer (csrc/gemm_w4n.h passes it in the side-input slot; read with global loads: no fourth resource is free)
+S_EPOFF, S_EROW, S_EN0, S_NP64, S_M1 = S_LDR8, S_NXPAIR, S_RBYTES, S_LDR2, S_N8     # finished tile: partial byte offset, first row, first column; np * 64; M - 1  (all dropout / side-input scalars)
 S_CNT = S_PAIRS          # middle-triple counter
 S_TRIP = S_NPAIRS        # K-steps / 3
 
@@ -138,6 +147,8 @@ class Gen:
         self.drop = epi == "dropres"
         self.gelu = epi in ("gelu", "gelud")
         self.two_out = epi == "gelud"
+        self.ce = epi == "ceexp"
+        assert not (self.ce and bkm)
         self.loads_closed = set()
         self.region = 0
         self.vm_region = []           # region of every VMEM operation (parallel to a.vm)
@@ -250,11 +261,50 @@ class Gen:
                     if n:
                         q(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDR8}")
                     q.vmem(("side", blk), f"buffer_load_dwordx4 v[{r}:{r + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen")
+        if self.ce:
+            # per row block: the rows' reference points (through the lse resource) and target ids (global loads: 64-bit address = tgt + 8 min(row, M - 1))
+            for i in range(NI):
+                q(f"s_lshl_b32 s{S_T}, s{S_EROW}, 2")
+                q(f"s_add_u32 s{S_T}, s{S_T}, {64 * i}")
+                q.vmem(("row", i), f"buffer_load_dword v{V_CROW + i}, v{V_RST}, s[{S_DLSE}:{S_DLSE + 3}], s{S_T} offen")
+                q(f"s_add_u32 s{S_T}, s{S_EROW}, {16 * i}")
+                q(f"v_lshrrev_b32 v{V_ADR}, 2, v{V_RST}")
+                q(f"v_add_u32 v{V_ADR}, s{S_T}, v{V_ADR}")
+                q(f"v_min_u32 v{V_ADR}, s{S_M1}, v{V_ADR}")
+                q(f"v_lshlrev_b32 v{V_ADR}, 3, v{V_ADR}")
+                q(f"v_mov_b32 v{V_ADR + 1}, s{S_TGTP + 1}")
+                q(f"v_add_co_u32 v{V_ADR}, vcc, s{S_TGTP}, v{V_ADR}")
+                q(f"v_addc_co_u32 v{V_ADR + 1}, vcc, 0, v{V_ADR + 1}, vcc")
+                q.vmem(("row", i), f"global_load_dwordx2 v[{V_TG + 2 * i}:{V_TG + 2 * i + 1}], v[{V_ADR}:{V_ADR + 1}], off")
         q.n_head = len(q)                                     # the load section: issued during the first K-step, consumed from the second on (a wait for
         q(f"s_mov_b32 s{S_SOFF}, 0")                          # these loads also waits for every OLDER operation -- the DMA pieces of the K-steps in flight)
         if self.epi != "mulaux":
             q.wait_vm("bias")
+        if self.ce:
+            # column masks of the finished tile: 1.0 where the column exists (n < N), else 0.0 -- E is written as zeros there and the slab sums skip it
+            q(f"v_add_u32 v{V_NL}, s{S_EN0}, v{V_PAIRB}")
+            for j in range(NJ):
+                for r in range(4):
+                    q(f"v_add_u32 v{V_D}, {32 * (j >> 1) + 4 * (j & 1) + r}, v{V_NL}")
+                    q(f"v_cmp_gt_u32 vcc, s{S_N}, v{V_D}")
+                    q(f"v_cndmask_b32 v{V_MASK + 4 * j + r}, 0, 1.0, vcc")
         for i in range(NI):
+            if self.ce:
+                q.wait_vm(("row", i))
+                q(f"v_mul_f32 v{V_C2}, 0x3fb8aa3b, v{V_CROW + i}")                     # c log2(e)
+                q(f"v_mov_b32 v{V_C2 + 1}, v{V_C2}")
+                q(f"v_sub_u32 v{V_D}, v{V_TG + 2 * i}, v{V_NL}")                       # target column relative to the lane's first column
+                q(f"v_and_b32 v{V_OWN}, 0xffffffd8, v{V_D}")                           # the lane owns relative columns 0..7 and 32..39 (and only for 0 <= tgt < 2^32)
+                q(f"v_or_b32 v{V_OWN}, v{V_OWN}, v{V_TG + 2 * i + 1}")
+                q(f"v_cmp_le_u32 vcc, s{S_N}, v{V_TG + 2 * i}")                        # ... and tgt < N (a padded column of the last tile is nobody's target)
+                q(f"v_cndmask_b32 v{V_S2}, 0, 1, vcc")
+                q(f"v_or_b32 v{V_OWN}, v{V_OWN}, v{V_S2}")
+                q(f"v_cmp_eq_u32 vcc, 0, v{V_OWN}")
+                q(f"v_mov_b32 v{V_OWN}, 0x80000000")
+                q(f"v_cndmask_b32 v{V_OWN}, v{V_OWN}, v{V_RST}, vcc")                  # store offset of the target logit: the row's, or out of every range
+                q(f"v_mov_b32 v{V_TV}, 0")
+                for r in range(4):
+                    q(f"v_mov_b32 v{V_SUM + r}, 0")
             if self.side:
                 q.wait_vm(("side", i))
                 # the lane's side chunks of this block: rows 0-7 / 8-15 in line order -> q' = 0 / 1 chunks of row t (swap with lane t ^ 8)
@@ -298,6 +348,22 @@ class Gen:
                     if self.epi != "mulaux":
                         q(f"v_pk_add_f32 v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{V_BIAS + 4 * j}:{V_BIAS + 4 * j + 1}]")
                         q(f"v_pk_add_f32 v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{V_BIAS + 4 * j + 2}:{V_BIAS + 4 * j + 3}]")
+                    if self.ce:
+                        cj = 32 * qp + 4 * e
+                        for r in range(4):                    # the target's logit, if this is its column
+                            q(f"v_cmp_eq_u32 vcc, {cj + r}, v{V_D}")
+                            q(f"v_cndmask_b32 v{V_TV}, v{V_TV}, v{T + 8 + r}, vcc")
+                        # exp2(min(x log2 e - c log2 e, 100)) (gemm.hip CE_EXP: the cap keeps a row's fp32 sums finite), zero beyond column N, summed unrounded
+                        q(f"v_pk_fma_f32 v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{V_L2E}:{V_L2E + 1}], v[{V_C2}:{V_C2 + 1}] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+                        q(f"v_pk_fma_f32 v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{V_L2E}:{V_L2E + 1}], v[{V_C2}:{V_C2 + 1}] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+                        for r in range(4):
+                            q(f"v_min_f32 v{T + 8 + r}, 0x42c80000, v{T + 8 + r}")
+                        for r in range(4):
+                            q(f"v_exp_f32 v{T + 8 + r}, v{T + 8 + r}")
+                        q(f"v_pk_mul_f32 v[{T + 8}:{T + 9}], v[{T + 8}:{T + 9}], v[{V_MASK + 4 * j}:{V_MASK + 4 * j + 1}]")
+                        q(f"v_pk_mul_f32 v[{T + 10}:{T + 11}], v[{T + 10}:{T + 11}], v[{V_MASK + 4 * j + 2}:{V_MASK + 4 * j + 3}]")
+                        q(f"v_pk_add_f32 v[{V_SUM}:{V_SUM + 1}], v[{V_SUM}:{V_SUM + 1}], v[{T + 8}:{T + 9}]")
+                        q(f"v_pk_add_f32 v[{V_SUM + 2}:{V_SUM + 3}], v[{V_SUM + 2}:{V_SUM + 3}], v[{T + 10}:{T + 11}]")
                     if self.drop:
                         # common.h dropout4 / pair_hash, bit for bit (gen_w4a.py): pair = (m N + n) / 2; one 32-bit hash decides two elements
                         P, H0, H1, TT = T + 16, T + 17, T + 18, T + 19
@@ -343,7 +409,7 @@ class Gen:
                 q(f"v_mov_b32_dpp v{T + r}, v{T + 4 + r} row_ror:8 row_mask:0xf bank_mask:0xc")
             for r in range(4):
                 q(f"v_mov_b32_dpp v{T + 4 + r}, v{T + 12 + r} row_ror:8 row_mask:0xf bank_mask:0x3")
-            nt = " nt" if self.gelu else ""
+            nt = " nt" if (self.gelu or self.ce) else ""
             q.vmem("store", f"buffer_store_dwordx4 v[{T}:{T + 3}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_SOFF} offen{nt}")
             q(f"s_add_u32 s{S_T}, s{S_SOFF}, s{S_LDC8}")
             q.vmem("store", f"buffer_store_dwordx4 v[{T + 4}:{T + 7}], v{V_CST}, s[{S_RSC}:{S_RSC + 3}], s{S_T} offen{nt}")
@@ -360,6 +426,28 @@ class Gen:
                 q.vmem("store", f"buffer_store_dwordx4 v[{U}:{U + 3}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen nt")
                 q(f"s_add_u32 s{S_T}, s{S_T}, s{S_LDR8}")
                 q.vmem("store", f"buffer_store_dwordx4 v[{U + 4}:{U + 7}], v{V_RST}, s[{S_RSR}:{S_RSR + 3}], s{S_T} offen nt")
+            if self.ce:
+                # the row's sum over this wave's 64 columns: the lane's 16 values, then the four lanes that share the row (16 and 32 lanes apart:
+                # v_permlane32_swap / v_permlane16_swap, as the 8-wave kernel does); lanes g = 0 store it into partial[m][slab]
+                q(f"v_add_f32 v{V_SUM}, v{V_SUM}, v{V_SUM + 1}")
+                q(f"v_add_f32 v{V_SUM + 2}, v{V_SUM + 2}, v{V_SUM + 3}")
+                q(f"v_add_f32 v{V_SUM}, v{V_SUM}, v{V_SUM + 2}")
+                q(f"v_mov_b32 v{V_S2}, v{V_SUM}")
+                q("s_nop 1")
+                q(f"v_permlane32_swap_b32 v{V_SUM}, v{V_S2}")
+                q("s_nop 1")
+                q(f"v_add_f32 v{V_SUM}, v{V_SUM}, v{V_S2}")
+                q(f"v_mov_b32 v{V_S2}, v{V_SUM}")
+                q("s_nop 1")
+                q(f"v_permlane16_swap_b32 v{V_SUM}, v{V_S2}")
+                q("s_nop 1")
+                q(f"v_add_f32 v{V_SUM}, v{V_SUM}, v{V_S2}")
+                q(f"s_mul_i32 s{S_T}, s{S_NP64}, {i}")
+                q(f"s_add_u32 s{S_T}, s{S_T}, s{S_EPOFF}")
+                q.vmem("store", f"buffer_store_dword v{V_SUM}, v{V_POFF}, s[{S_DPART}:{S_DPART + 3}], s{S_T} offen")
+                q(f"s_lshl_b32 s{S_T}, s{S_EROW}, 2")
+                q(f"s_add_u32 s{S_T}, s{S_T}, {64 * i}")
+                q.vmem("store", f"buffer_store_dword v{V_TV}, v{V_OWN}, s[{S_DTL}:{S_DTL + 3}], s{S_T} offen")
             q(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, s{S_LDC16}")
         return q
 
@@ -379,7 +467,7 @@ class Gen:
                     continue                                  # (covered by the wait that closed the first triple)
                 a(f"s_waitcnt vmcnt({min(63, self.younger(tag))})")
 
-    def close_loads(self, q_tags=("bias",) + tuple(("side", i) for i in range(NI))):
+    def close_loads(self, q_tags=("bias",) + tuple(("side", i) for i in range(NI)) + tuple(("row", i) for i in range(NI))):
         """end of a straight-line region: everything the queue has loaded so far is waited for here, so that no later region needs a count across the loop"""
         a = self.a
         live = [t for t in q_tags if t in a.vm and t not in self.loads_closed]
@@ -525,7 +613,7 @@ class Gen:
             bytes_of(S_BBYTES, S_Kd, S_LDB, S_N)
         else:
             bytes_of(S_BBYTES, S_N, S_LDB, S_Kd)
-        bytes_of(S_CBYTES, S_M, S_LDC, S_N)
+        bytes_of(S_CBYTES, S_M, S_LDC, S_LDC if self.ce else S_N)              # (CE_EXP writes zeros into columns [N, ldc) of every row)
         bytes_of(S_RBYTES, S_M, S_LDR, S_N)
         a(f"s_or_b32 s{S_T}, s{S_BIAS}, s{S_BIAS + 1}")
         a(f"s_cmp_eq_u32 s{S_T}, 0")
@@ -551,8 +639,52 @@ class Gen:
         for k in range(4):                                    # nothing is finished in front of the first tile: its "epilogue" loads zeros and stores nowhere
             a(f"s_mov_b32 s{S_RSC + k}, s{S_NULL + k}")
             a(f"s_mov_b32 s{S_RSBIAS + k}, s{S_NULL + k}")
-            a(f"s_mov_b32 s{S_RSR + k}, s{S_NULL + k}")
-        a(f"s_mov_b32 s{S_EPAIR}, 0")
+            if not self.ce:
+                a(f"s_mov_b32 s{S_RSR + k}, s{S_NULL + k}")
+        if not self.ce:
+            a(f"s_mov_b32 s{S_EPAIR}, 0")
+        else:
+            # ---- CE_EXP: three more pointers behind the common arguments (lse, partial, tgt_logit; tgt came in the side-input slot, np in ldr), constant resources
+            # over the whole arrays, lane constants.  The registers they take were the prologue's (K, lda, ldb, ldc) or belong to forms this one is not.
+            a(f"s_load_dwordx4 s[{S_RSA}:{S_RSA + 3}], {OP['karg']}, 104")
+            a(f"s_load_dwordx2 s[{S_RSB}:{S_RSB + 1}], {OP['karg']}, 120")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"s_sub_u32 s{S_M1}, s{S_M}, 1")
+            a(f"s_lshl_b32 s{S_NP64}, s{S_LDR}, 6")
+            a(f"s_lshl_b32 s{S_T}, s{S_M}, 2")                                # M * 4
+            a(f"s_mov_b32 s{S_DLSE}, s{S_RSA}")
+            a(f"s_and_b32 s{S_DLSE + 1}, s{S_RSA + 1}, 0xffff")
+            a(f"s_mov_b32 s{S_DLSE + 2}, s{S_T}")
+            a(f"s_mov_b32 s{S_DLSE + 3}, 0x00020000")
+            a(f"s_mov_b32 s{S_DPART}, s{S_RSA + 2}")
+            a(f"s_and_b32 s{S_DPART + 1}, s{S_RSA + 3}, 0xffff")
+            a(f"s_mul_i32 s{S_DPART + 2}, s{S_T}, s{S_LDR}")                  # M * np * 4
+            a(f"s_mov_b32 s{S_DPART + 3}, 0x00020000")
+            a(f"s_mov_b32 s{S_DTL}, s{S_RSB}")
+            a(f"s_and_b32 s{S_DTL + 1}, s{S_RSB + 1}, 0xffff")
+            a(f"s_mov_b32 s{S_DTL + 2}, s{S_T}")
+            a(f"s_mov_b32 s{S_DTL + 3}, 0x00020000")
+            a(f"s_or_b32 s{S_T}, s{S_TGTP}, s{S_TGTP + 1}")                  # no targets: nothing is picked, nothing is stored
+            a(f"s_cmp_eq_u32 s{S_T}, 0")
+            a(f"s_cselect_b32 s{S_DTL + 2}, 0, s{S_DTL + 2}")
+            a(f"s_or_b32 s{S_T}, s{S_RSB}, s{S_RSB + 1}")
+            a(f"s_cmp_eq_u32 s{S_T}, 0")
+            a(f"s_cselect_b32 s{S_DTL + 2}, 0, s{S_DTL + 2}")
+            a(f"v_mov_b32 v{V_L2E}, 0x3fb8aa3b")
+            a(f"v_mov_b32 v{V_L2E + 1}, 0x3fb8aa3b")
+            # partial[m][slab]: lane offset (row np + wn) * 4 for the lanes g = 0 (V_RST = 4 row, V_PAIRB = 64 wn + 8 g), out of every range for the others
+            a(f"v_mul_lo_u32 v{V_POFF}, v{V_RST}, s{S_LDR}")
+            a(f"v_lshrrev_b32 v{V_T}, 4, v{V_PAIRB}")
+            a(f"v_and_b32 v{V_T}, 4, v{V_T}")
+            a(f"v_add_u32 v{V_POFF}, v{V_POFF}, v{V_T}")
+            a(f"v_and_b32 v{V_T}, 0x38, v{V_PAIRB}")
+            a(f"v_cmp_eq_u32 vcc, 0, v{V_T}")
+            a(f"v_mov_b32 v{V_T}, 0x80000000")
+            a(f"v_cndmask_b32 v{V_POFF}, v{V_T}, v{V_POFF}, vcc")
+            # the phantom tile in front of the first one: offsets of 2^31 -- its loads read zeros, its sums and target logits are stored nowhere
+            a(f"s_mov_b32 s{S_EPOFF}, 0x80000000")
+            a(f"s_mov_b32 s{S_EROW}, 0x20000000")
+            a(f"s_mov_b32 s{S_EN0}, 0")
         a(f"s_mov_b32 s{S_TIDX}, 0")
 
         def load_next():
@@ -570,7 +702,8 @@ class Gen:
             a(f"v_readfirstlane_b32 s{S_NXC_OFF}, v{V_T + 6}")
             a(f"v_readfirstlane_b32 s{S_NXN0}, v{V_T + 7}")
             a(f"v_readfirstlane_b32 s{S_NXR_OFF}, v{V_T + 8}")
-            a(f"v_readfirstlane_b32 s{S_NXPAIR}, v{V_T + 9}")
+            if not self.ce:
+                a(f"v_readfirstlane_b32 s{S_NXPAIR}, v{V_T + 9}")
             a("s_nop 3")
             a(f"s_add_u32 s{S_NXA}, s{S_A}, s{S_T}")
             a(f"s_addc_u32 s{S_NXA + 1}, s{S_A + 1}, 0")
@@ -706,8 +839,16 @@ class Gen:
         desc(S_RSC, S_C, S_CBYTES, S_CUR_C_OFF)
         a(f"s_lshl_b32 s{S_T + 2}, s{S_CUR_N0}, 2")
         desc(S_RSBIAS, S_BIAS, S_BIASBYTES, S_T + 2)
-        desc(S_RSR, S_R, S_RBYTES, S_CUR_R_OFF)
-        a(f"s_mov_b32 s{S_EPAIR}, s{S_RUNPAIR}")
+        if not self.ce:
+            desc(S_RSR, S_R, S_RBYTES, S_CUR_R_OFF)
+            a(f"s_mov_b32 s{S_EPAIR}, s{S_RUNPAIR}")
+        else:                                                 # first row (the table's side-input slot carries it), first column, partial[m0][n0 / 64] of the finished tile
+            a(f"s_mov_b32 s{S_EROW}, s{S_CUR_R_OFF}")
+            a(f"s_mov_b32 s{S_EN0}, s{S_CUR_N0}")
+            a(f"s_mul_i32 s{S_T}, s{S_EROW}, s{S_LDR}")
+            a(f"s_lshr_b32 s{S_T + 1}, s{S_EN0}, 6")
+            a(f"s_add_u32 s{S_T}, s{S_T}, s{S_T + 1}")
+            a(f"s_lshl_b32 s{S_EPOFF}, s{S_T}, 2")
         a(f"s_sub_u32 s{S_TILE}, s{S_TILE}, 1")
         a(f"s_cmp_eq_u32 s{S_TILE}, 0")
         a(f"s_cbranch_scc1 {l_done}")
@@ -742,7 +883,7 @@ def lint(lines, name):
     W.lint(lines, name)
 
 
-BODIES = [(False, e) for e in ("plain", "resid", "mulaux", "dropres", "gelu", "gelud")] + [(True, e) for e in ("plain", "resid", "mulaux")]
+BODIES = [(False, e) for e in ("plain", "resid", "mulaux", "dropres", "gelu", "gelud", "ceexp")] + [(True, e) for e in ("plain", "resid", "mulaux")]
 
 
 def main():

@@ -11,6 +11,7 @@ k-row.
     python scripts/w4n_emulate.py            (every body, K = 576 / 768 / 960: zero, one and two passes of the middle loop)
 """
 import os
+import re
 import struct
 import sys
 
@@ -23,15 +24,62 @@ from w4a_emulate import NL, U32, bf16_round, bf16_to_f32, key_a, key_b, km_key, 
 
 
 class Emu(E.Emu):
+    """+ the instructions only the narrow bodies use: the accumulator move, and the CE_EXP form's row loads / compares / cross-lane row sums"""
     LDS_BYTES = G.LDS_BYTES
 
     def step(self, i):
         ln = self.lines[i]
-        if ln.startswith("v_accvgpr_mov_b32"):
-            d, s_ = [int(x.strip()[1:]) for x in ln.split(None, 1)[1].split(",")]
-            self.A[d] = self.A[s_].copy()
-            return i + 1
-        return super().step(i)
+        op, _, rest = ln.partition(" ")
+        args = [a.strip() for a in re.split(r",\s*(?![^\[]*\])", rest)] if rest else []
+        V = self.V
+        f32 = lambda tok: self.src(tok).view(np.float32)
+        if op == "v_accvgpr_mov_b32":
+            self.A[int(args[0][1:])] = self.A[int(args[1][1:])].copy()
+        elif op == "global_load_dwordx2":
+            d, _ = self.vrange(args[0])
+            a0, _ = self.vrange(args[1])
+            addr = V[a0].astype(np.int64) | (V[a0 + 1].astype(np.int64) << 32)
+            assert addr.min() >= 0 and addr.max() + 8 <= self.mem.size, "global load outside the emulated memory"
+            w = self.mem[addr[:, None] + np.arange(8)[None, :]].reshape(NL, 2, 4).view(U32).reshape(NL, 2)
+            V[d], V[d + 1] = w[:, 0].copy(), w[:, 1].copy()
+        elif op == "buffer_load_dword":
+            d = int(args[0][1:])
+            addr, off, nrec = self.buffer_addr(args, rest, 4)
+            V[d] = self.gather(addr, off + 4 <= nrec, 4).view(U32).reshape(NL)
+        elif op in ("v_min_f32", "v_add_f32"):
+            a_, b_ = f32(args[1]), f32(args[2])
+            V[int(args[0][1:])] = (np.minimum(a_, b_) if op == "v_min_f32" else (a_ + b_)).astype(np.float32).view(U32)
+        elif op == "v_min_u32":
+            V[int(args[0][1:])] = np.minimum(self.src(args[1]), self.src(args[2]))
+        elif op == "v_sub_u32":
+            V[int(args[0][1:])] = (self.src(args[1]).astype(np.int64) - self.src(args[2]).astype(np.int64)).astype(np.uint64).astype(U32)
+        elif op == "v_or_b32":
+            V[int(args[0][1:])] = self.src(args[1]) | self.src(args[2])
+        elif op in ("v_cmp_eq_u32", "v_cmp_gt_u32"):
+            a_, b_ = self.src(args[1]), self.src(args[2])
+            self.vcc = (a_ == b_) if op == "v_cmp_eq_u32" else (a_ > b_)
+        elif op == "v_add_co_u32":                            # dst, vcc, a, b
+            r = self.src(args[2]).astype(np.uint64) + self.src(args[3]).astype(np.uint64)
+            V[int(args[0][1:])] = (r & 0xFFFFFFFF).astype(U32)
+            self.vcc = (r >> 32) != 0
+        elif op == "v_addc_co_u32":                           # dst, vcc, a, b, vcc
+            r = self.src(args[2]).astype(np.uint64) + self.src(args[3]).astype(np.uint64) + self.vcc.astype(np.uint64)
+            V[int(args[0][1:])] = (r & 0xFFFFFFFF).astype(U32)
+            self.vcc = (r >> 32) != 0
+        elif op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32"):
+            # 32: lanes 32..63 of vdst <-> lanes 0..31 of vsrc;  16: the odd rows (16 lanes) of vdst <-> the even rows of vsrc -- per wave
+            d, s_ = int(args[0][1:]), int(args[1][1:])
+            vd, vs = V[d].copy().reshape(4, 64), V[s_].copy().reshape(4, 64)
+            nd, ns = vd.copy(), vs.copy()
+            if op == "v_permlane32_swap_b32":
+                nd[:, 32:], ns[:, :32] = vs[:, :32], vd[:, 32:]
+            else:
+                for r in (0, 2):
+                    nd[:, 16 * (r + 1):16 * (r + 2)], ns[:, 16 * r:16 * (r + 1)] = vs[:, 16 * r:16 * (r + 1)], vd[:, 16 * (r + 1):16 * (r + 2)]
+            V[d], V[s_] = nd.reshape(NL), ns.reshape(NL)
+        else:
+            return super().step(i)
+        return i + 1
 
 
 _BODY_CACHE = {}
@@ -154,12 +202,106 @@ def run_case(bkm, epi, M, N, K, seed=0, p_drop=0.1, verbose=False, lines=None, o
     return worst, guard_ok
 
 
+def run_case_ce(M, N, K, seed=0, verbose=False, lines=None, opts=()):
+    """The CE_EXP body (rounding-head forward): E = bf16(exp(A W^T + bias - c_row)) with zeros in columns [N, ldc), the unrounded sums per (row, 64-column slab),
+    the target's logit per row.  N is ragged (not a multiple of the 128-column tile), some targets are out of range; returns (worst deviation in units of the
+    tolerance, guards intact)."""
+    rng = np.random.default_rng(seed + K + N)
+    TM, TN = 256, 128
+    lda, ldb = K, K
+    ldc = (N + 127) // 128 * 128
+    npart = 4 * ((N + 255) // 256)
+    A = bf16_round(rng.standard_normal((M, K)).astype(np.float32) * 0.5)
+    Bm = bf16_round(rng.standard_normal((N, K)).astype(np.float32) * 0.25)
+    bias = rng.standard_normal(N).astype(np.float32)
+    logits = bf16_to_f32(A).astype(np.float64) @ bf16_to_f32(Bm).astype(np.float64).T + bias.astype(np.float64)
+    cref = (logits.max(axis=1) - rng.uniform(0.0, 3.0, M)).astype(np.float32)           # the caller's reference points: near the row maximum
+    tgt = rng.integers(0, N, M).astype(np.int64)
+    tgt[1], tgt[2], tgt[M - 1] = -1, N + 5, N - 1                                        # ignored rows and the last column
+    mem = np.full(32 << 20, 0xA5, dtype=np.uint8)
+    cur = [4096]
+
+    def place(arr_bytes):
+        a = cur[0]
+        mem[a:a + arr_bytes.size] = arr_bytes
+        cur[0] = (a + arr_bytes.size + 4096 + 255) & ~255
+        return a
+    pA = place(A.astype(np.uint16).view(np.uint8).reshape(-1))
+    pB = place(Bm.astype(np.uint16).view(np.uint8).reshape(-1))
+    C_rows = M + 8
+    pC = place(np.full(C_rows * ldc * 2, 0x5C, dtype=np.uint8))
+    pBias = place(bias.view(np.uint8).reshape(-1))
+    pLse = place(cref.view(np.uint8).reshape(-1))
+    pTgt = place(tgt.view(np.uint8).reshape(-1))
+    pPart = place(np.full(C_rows * npart * 4, 0x6D, dtype=np.uint8))
+    pTl = place(np.full(C_rows * 4, 0x7E, dtype=np.uint8))
+    args = struct.pack("<5Q8i", pA, pB, pC, pBias, pTgt, M, N, K, lda, ldb, ldc, npart, 0) + struct.pack("<QQqfi", 0, 0, 0, 0.0, 0) + struct.pack("<3Q", pLse, pPart, pTl)
+    assert len(args) == 128
+    tiles = [(bm, bn) for bm in range((M + TM - 1) // TM) for bn in range(ldc // TN)]
+    emu_lds = np.zeros(Emu.LDS_BYTES, dtype=np.uint8)
+    for k, (bm, bn) in enumerate(tiles):
+        m0, n0 = bm * TM, bn * TN
+        e = struct.pack("<4I", (m0 * lda * 2) & 0xFFFFFFFF, (n0 * ldb * 2) & 0xFFFFFFFF, ((m0 * ldc + n0) * 2) & 0xFFFFFFFF, n0)
+        emu_lds[G.TABLE_OFF + 16 * k: G.TABLE_OFF + 16 * k + 16] = np.frombuffer(e, dtype=np.uint8)
+        e2 = struct.pack("<2I", m0, 0)                                                   # CE_EXP: the side-input slot carries the tile's first row
+        o2 = G.TABLE_OFF + 16 * 512 + 16 * k
+        emu_lds[o2:o2 + 8] = np.frombuffer(e2, dtype=np.uint8)
+    tid = np.arange(NL)
+    lane, wave = tid & 63, tid >> 6
+    wm, wn, g, t = wave >> 1, wave & 1, lane >> 4, lane & 15
+    r8, chunk = lane >> 3, lane & 7
+    rowA0 = 8 * wave + r8
+    voA0 = rowA0 * lda * 2 + ((chunk ^ key_a(rowA0)) << 4)
+    voBbase = (32 * wave + r8) * ldb * 2
+    chunkx = chunk ^ ((r8 >> 1) & 1)
+    rowb = wn * 64 + 8 * (t >> 2) + (t & 3)
+    aB0 = G.B_BASE + rowb * 128 + ((g ^ key_b(rowb)) << 4)
+    rowa = wm * 128 + t
+    aA0 = rowa * 128 + ((g ^ key_a(rowa)) << 4)
+    lrow, lcol = wm * 128 + (t & 7), wn * 64 + 8 * (g + 4 * (t >> 3))
+    opv = dict(tbl=np.full(NL, G.TABLE_OFF), voA0=voA0, voBbase=voBbase, chunkx=chunkx, aA0=aA0, aB0=aB0, cst=(lrow * ldc + lcol) * 2, boff=(wn * 64 + 8 * g) * 4,
+               rst=(wm * 128 + t) * 4, pairb=wn * 64 + 8 * g)                            # CE_EXP: 4 x the lane's row, the lane's first column
+    w4 = np.arange(4)
+    ops = dict(karg=np.zeros(4), ntiles=np.full(4, len(tiles)), m0A=w4 * 1024, m0B=G.B_BASE + w4 * 4096, dkey=np.zeros(4), dthr=np.zeros(4), dinv=np.zeros(4))
+    if lines is None:
+        lines = body_lines(False, "ceexp", tuple(opts))
+    emu = Emu(lines, {k: np.asarray(v, dtype=np.uint64) for k, v in opv.items()}, ops, args, mem)
+    emu.lds[:] = emu_lds
+    emu.run(max_instr=8_000_000)
+    # ---- reference
+    e = np.exp2(np.minimum((logits - cref.astype(np.float64)[:, None]) * 1.4426950408889634, 100.0))
+    got_raw = mem[pC:pC + C_rows * ldc * 2].view(np.uint16).reshape(C_rows, ldc)
+    got = bf16_to_f32(got_raw[:M, :N].astype(U32)).astype(np.float64)
+    worst = float((np.abs(got - e) / (np.abs(e) * 2.0 ** -7 + 1e-6)).max())
+    zeros_ok = bool((got_raw[:M, N:] == 0).all())
+    guard_ok = bool((got_raw[M:] == 0x5C5C).all())
+    part = mem[pPart:pPart + C_rows * npart * 4].view(np.float32).reshape(C_rows, npart)
+    nslab = 2 * (ldc // TN)
+    want_p = np.zeros((M, nslab))
+    for sl in range(nslab):
+        want_p[:, sl] = e[:, 64 * sl:min(64 * sl + 64, N)].sum(axis=1) if 64 * sl < N else 0.0
+    worst = max(worst, float((np.abs(part[:M, :nslab] - want_p) / (np.abs(want_p) * 2e-5 + 1e-7)).max()))
+    guard_ok = guard_ok and bool((part[M:].view(np.uint32) == 0x6D6D6D6D).all()) and bool((part[:M, nslab:].view(np.uint32) == 0x6D6D6D6D).all())
+    tl = mem[pTl:pTl + C_rows * 4].view(np.float32)
+    valid = (tgt >= 0) & (tgt < N)
+    want_tl = logits[np.arange(M), np.clip(tgt, 0, N - 1)]
+    worst = max(worst, float((np.abs(tl[:M][valid] - want_tl[valid]) / (np.abs(want_tl[valid]) * 1e-5 + 1e-4)).max()))
+    guard_ok = guard_ok and bool((tl[:M][~valid].view(np.uint32) == 0x7E7E7E7E).all()) and bool((tl[M:].view(np.uint32) == 0x7E7E7E7E).all())
+    if verbose:
+        print(f"KC ceexp    M={M} N={N} K={K}: {len(tiles)} tiles, {emu.n} instructions, worst deviation {worst:.3f} of the tolerance, zeros beyond N {'ok' if zeros_ok else 'MISSING'}, "
+              f"guards {'intact' if guard_ok else 'OVERWRITTEN'}", flush=True)
+    return worst, guard_ok and zeros_ok
+
+
 if __name__ == "__main__":
     bad = 0
     shapes = [(336, 256, 576), (336, 256, 768)] if len(sys.argv) < 2 else [tuple(int(x) for x in sys.argv[1:4])]
     for bkm, epi in G.BODIES:
         for M, N, K in shapes:                                # two row tiles (the second ragged) x two column tiles
-            worst, guard_ok = run_case(bkm, epi, M, N, K, verbose=True)
+            if epi == "ceexp":
+                worst, guard_ok = run_case_ce(M, N + 44, K, verbose=True)          # (a ragged last column tile)
+            else:
+                worst, guard_ok = run_case(bkm, epi, M, N, K, verbose=True)
             bad += (worst > 1.0) or not guard_ok
     print("all narrow bodies reproduce numpy" if not bad else f"{bad} (body, shape) cases DIFFER")
     sys.exit(1 if bad else 0)

@@ -20,6 +20,7 @@ import gen_w4n as G  # noqa: E402
 
 DMA_CYCLES = 48 * 1024 / 36.0
 WIDE_KSTEP_MEASURED = 2600
+CE_8WAVE_TILE_MEASURED = int(799.7e-6 / 32 * 2.1e9)       # profiles/r05_single_stream_kernel_stats.csv, clock: profiles/r05_power_ab.txt
 
 
 def cost(ln):
@@ -76,7 +77,7 @@ def wide_epilogue(bkm, epi):
 
 if __name__ == "__main__":
     print("# Issue-cycle MODEL of the narrow-tile asm GEMM (scripts/w4n_issue_model.py): counted from the generated text, NOT measured.  Cycles per wave.")
-    print("# narrow K-step = max(1 024 MFMA-pipe cycles, %d DMA cycles (48 KB at 36 B/clk/CU), issue cycles of its text); wide K-step = %d (measured, DESIGN 7.2) + its epilogue's issue cycles" % (DMA_CYCLES, WIDE_KSTEP_MEASURED))
+    print("# narrow K-step = max(1 024 MFMA-pipe cycles, %d DMA cycles (48 KB at 36 B/clk/CU), issue cycles of its text); wide K-step = %d (measured, DESIGN 7.2) + its epilogue's issue cycles; ceexp: the 8-wave kernel's measured %d cycles per tile" % (DMA_CYCLES, WIDE_KSTEP_MEASURED, CE_8WAVE_TILE_MEASURED))
     print("# body           issue cycles of the 12 K-steps of a K = 768 tile (first triple | second | middle | last)                       256 x 128 tile   per 256 x 256   wide body, per 256 x 256   narrow / wide")
     for form, opts in (("loop form (first / second / middle / last triple; only the first and the last drain the epilogue queue)", ()),
                        ("loop-free form, K = 768 (flat=12: every K-step but the first drains the queue) -- what K = 768 launches take", ("flat=12",))):
@@ -84,8 +85,11 @@ if __name__ == "__main__":
         for bkm, epi in G.BODIES:
             steps, t = narrow(bkm, epi, opts)
             tile = sum(t)
-            we, _ = wide_epilogue(bkm, epi)
-            wide = 12 * WIDE_KSTEP_MEASURED + we
+            if epi == "ceexp":                                 # no wide asm body exists: the 8-wave kernel's launch, measured (799.7 us for 68 x 120 tiles of 256 x 256 = 32 rounds at 2.1 GHz)
+                wide = CE_8WAVE_TILE_MEASURED
+            else:
+                we, _ = wide_epilogue(bkm, epi)
+                wide = 12 * WIDE_KSTEP_MEASURED + we
             iss = " ".join(f"{s[0]:5d}" for s in steps)
             print(f"  {'KM' if bkm else 'KC'} {epi:8s}  {iss[:17]} | {iss[18:35]} | {iss[36:53]} | {iss[54:]}      {tile:8.0f}        {2 * tile:8.0f}        {wide:8d}                 {2 * tile / wide:.2f}")
     print("# launch level at 17 408 tokens on 256 CUs (tiles -> rounds of the persistent grid; the wide bodies at their per-launch height):")

@@ -119,3 +119,48 @@ def test_narrow_tile_asm_kernel_refuses_nothing_silently(L):
         L.dic_gemm_set_w4a(prev)
         L.dic_set_option(b"gemm_w4n", 0)
         dic.options.push_to_library(L)
+
+
+@pytest.mark.parametrize("M,V,flat", [(512, 3000, 1), (4352, 30522, 1), (1024, 30522, 0)])
+def test_rounding_head_forward_on_the_narrow_tile_kernel_matches_the_eight_wave_kernel(L, M, V, flat):
+    """DIC_EPI_CE_EXP (training forward of the rounding loss: E = bf16(exp(logit - c_row)), zeros in columns [V, ldE), unrounded sums per 64-column slab, the target's
+    logit) on the narrow bodies (gemm_w4n.h launch_w4n_ce) against the 8-wave kernel on the same operands.  The 8-wave kernel starts its accumulators from the bias, the
+    narrow body adds it behind the K loop, and the lanes add a row's 64 values up in another order: E within 2 bf16 ulp, sums to 1e-5, target logits to 1e-4 absolute.
+    Rows with a target outside [0, V) must keep their tgt_logit; the slab slots beyond ldE (cleared by the launcher) must be zero; guard rows must survive."""
+    g = torch.Generator().manual_seed(M + V)
+    K, ldE = 768, (V + 127) // 128 * 128
+    npart = L.dic_ce_n_partials(V, 256)
+    X = dev(torch.randn(M, K, generator=g) * 0.5, torch.bfloat16)
+    W = dev(torch.randn(V, K, generator=g) * 0.05, torch.bfloat16)
+    bias = dev(torch.randn(V + 256, generator=g) * 0.1)
+    logits = X.float() @ W.float().t() + bias[:V]
+    cref = dev((logits.max(dim=1).values - 2.0).contiguous())
+    tgt = torch.randint(0, V, (M,), generator=g)
+    tgt[1], tgt[2], tgt[M - 1] = -1, V + 5, V - 1
+    tgt = dev(tgt)
+    res = []
+    try:
+        prev = L.dic_gemm_set_w4a(1)
+        assert L.dic_set_option(b"gemm_w4n_mask", 0x7FF) == 0 and L.dic_set_option(b"gemm_w4n_flat", flat) == 0
+        for narrow in (0, 1):
+            E = torch.full((M + 8, ldE), 7.0, dtype=torch.bfloat16, device="cuda")
+            part = torch.full((M + 8, npart), 3.0, dtype=torch.float32, device="cuda")
+            tl = torch.full((M + 8,), 9.0, dtype=torch.float32, device="cuda")
+            assert L.dic_set_option(b"gemm_w4n", narrow) == 0
+            gemm(L, BF16, 0, 0, dic._lib.EPI_CE_EXP, A=p(X), B=p(W), C=p(E), M=M, N=V, K=K, lda=K, ldb=K, ldc=ldE, bias=p(bias), lse=p(cref), tgt=p(tgt), partial=p(part), tgt_logit=p(tl), tile=256)
+            torch.cuda.synchronize()
+            res.append((E, part, tl))
+    finally:
+        L.dic_gemm_set_w4a(prev)
+        L.dic_set_option(b"gemm_w4n", 0)
+        dic.options.push_to_library(L)
+    (E0, P0, T0), (E1, P1, T1) = res
+    assert bool((E1[M:] == 7.0).all()) and bool((P1[M:] == 3.0).all()) and bool((T1[M:] == 9.0).all())
+    assert bool((E1[:M, V:] == 0).all()) and bool((P1[:M, 2 * (ldE // 128):] == 0).all())
+    d = (E1[:M, :V].float() - E0[:M, :V].float()).abs()
+    assert int((d > E0[:M, :V].float().abs() * 2 ** -6 + 1e-6).sum()) == 0
+    assert relerr(P1[:M], P0[:M]) < 1e-5
+    valid = (tgt >= 0) & (tgt < V)
+    assert float((T1[:M][valid] - T0[:M][valid]).abs().max()) < 1e-4 and bool((T1[:M][~valid] == 9.0).all())
+    want = torch.exp(logits.double().cpu() - cref.double().cpu()[:, None])
+    assert relerr(E1[:M, :V].float(), want) < 6e-3
