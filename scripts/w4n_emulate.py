@@ -218,7 +218,7 @@ def run_case_ce(M, N, K, seed=0, verbose=False, lines=None, opts=()):
     cref = (logits.max(axis=1) - rng.uniform(0.0, 3.0, M)).astype(np.float32)           # the caller's reference points: near the row maximum
     tgt = rng.integers(0, N, M).astype(np.int64)
     tgt[1], tgt[2], tgt[M - 1] = -1, N + 5, N - 1                                        # ignored rows and the last column
-    mem = np.full(32 << 20, 0xA5, dtype=np.uint8)
+    mem = np.full(max(32 << 20, 2 * (M * K + N * K + (M + 8) * ldc) + 8 * (M + 8) * (npart + 4) + 4 * N + (1 << 20)), 0xA5, dtype=np.uint8)
     cur = [4096]
 
     def place(arr_bytes):
