@@ -439,9 +439,6 @@ __device__ __forceinline__ i32x4 take8(const i32x4& keep, const i32x4& from_part
 // waits for and BEFORE its first store: a wait for the bias / residual / pre-activation loads is a `vmcnt(0)` and would otherwise also
 // wait ~2.4 k cycles for that DMA (the s_memtime trace showed it in front of every epilogue), while behind the wait the DMA's latency
 // hides under the stores.
-#ifndef DIC_CE_EXP_ABL
-#define DIC_CE_EXP_ABL 0      // timing ablations of the CE_EXP epilogue (scripts/experiments/ce_exp_ablate.*): 1 no slab sums, 2 no target pick, 4 __expf(x - c), 8 no sum accumulation
-#endif
 template <class C, int EPI, bool PF, int CNT, bool BIAS_IN_ACC, class IssueNext, class Stamp>
 __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], const DicGemmParams& p, int m_first, int n_first, int lane, IssueNext&& issue_next_,
                                                 Stamp&& stamp) {
@@ -485,10 +482,6 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
     auto put_lines = [&](int i, const LineBuf& Lb, const i32x4& P0, const i32x4& P1) {
         const i32x4 D0 = take8<true>(P0, P1), D1 = take8<false>(P1, P0);      // rows 0-7: lanes t >= 8 carry lane t-8's second chunk; rows 8-15: lanes t < 8 carry lane t+8's first
         const unsigned o = Lb.off + (unsigned)(2 * i) * Lb.row8;
-#ifdef DIC_GEMM_ABL_NOSTORE     // timing ablation: the data still has to be produced
-        asm volatile("; no store %0 %1 %2" :: "v"(D0), "v"(D1), "v"(o));
-        return;
-#endif
         __builtin_amdgcn_raw_buffer_store_b128(D0, Lb.rs, (int)o, 0, AUX);
         __builtin_amdgcn_raw_buffer_store_b128(D1, Lb.rs, (int)(o + Lb.row8), 0, AUX);
     };
@@ -817,18 +810,11 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 const int n = nc[q];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#if DIC_CE_EXP_ABL & 4
-                    const float e0 = (n + r < p.N) ? __expf(x0[r] - r_c[i]) : 0.f;
-                    const float e1 = (n + 4 + r < p.N) ? __expf(x1[r] - r_c[i]) : 0.f;
-#else
                     // (exponent capped at 2^100: a logit more than 69 + shift nats above its row's reference point -- a per-token loss beyond ~109 with
                     //  the shift of 40 the engine uses -- saturates instead of overflowing the fp32 sums of this row and of E @ W)
                     const float e0 = (n + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fminf(__builtin_fmaf(x0[r], L2E, -c2), 100.f)) : 0.f;
                     const float e1 = (n + 4 + r < p.N) ? __builtin_amdgcn_exp2f(__builtin_fminf(__builtin_fmaf(x1[r], L2E, -c2), 100.f)) : 0.f;
-#endif
-#if !(DIC_CE_EXP_ABL & 8)
                     sm += e0 + e1;
-#endif
                     x0[r] = e0; x1[r] = e1;
                 }
                 P[q] = pack8f(x0, x1);
@@ -841,7 +827,6 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
         const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.partial + (size_t)m_first * np), 0,
                                                                              (int)(pbytes < 0 ? 0 : (pbytes > 0x7FFFFFFFll ? 0x7FFFFFFFll : pbytes)), 0x00020000);
         const unsigned poff = g == 0 ? ((unsigned)t * (unsigned)np + (unsigned)slot) * 4u : 0x80000000u;
-#if !(DIC_CE_EXP_ABL & 1)
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             // (inline asm: with the same value passed for both operands of __builtin_amdgcn_permlane32_swap this compiler adds result 0 to
@@ -853,9 +838,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
             const float s4 = b0 + b1;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s4), rsP, (int)(poff + (unsigned)(16 * i) * (unsigned)np * 4u), 0, 0);
         }
-#endif
         // the target's logit: a lane owns columns nc[0]..+7 and nc[1]..+7 of row t
-#if !(DIC_CE_EXP_ABL & 2)
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             const unsigned d0 = (unsigned)(r_tg[i] - nc[0]), d1 = (unsigned)(r_tg[i] - nc[1]);
@@ -873,7 +856,6 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[CNT][Geo<C>::FN], c
                 p.tgt_logit[m_first + 16 * i + t] = tv;
             }
         }
-#endif
     }
 }
 
@@ -1080,9 +1062,6 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         return r;
     };
     auto dma16 = [](unsigned voff, const i32x4& rsrc, unsigned lds_addr) {   // 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1 KiB)
-#ifdef DIC_GEMM_ABL_NODMA       // ablation builds (scripts/experiments/gemm_ablate.sh): results are garbage, only the timing is read
-        return;
-#endif
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
     };
     // every wave's DMA pieces of the stage being published have landed, and every wave is done reading the stage being recycled
@@ -1162,7 +1141,6 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
                 }
             }
         }
-#ifndef DIC_GEMM_PLAIN_READS
         // Fragment reads run DIC_GEMM_PF A fragments ahead of the MFMAs that consume them, with counted waits.  Left to the compiler every A
         // fragment is `ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs`: a wave alone keeps the matrix pipe below 50 % busy and the K-step ends
         // with the younger wave of each SIMD finishing on its own (s_memtime stamps: the older wave waits ~25 % of every K-step at the barrier).
@@ -1177,9 +1155,6 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         if constexpr (!BKM) { aB[0] = sbB + (unsigned)ofB[0]; aB[1] = sbB + ((unsigned)ofB[0] ^ 64u); }
         auto read_frag = [&](bf16x8& dst, bool km, unsigned addr, auto imm_c, auto rowb4_c) {
             constexpr int imm = decltype(imm_c)::value, hi = decltype(rowb4_c)::value;
-#ifdef DIC_GEMM_ABL_NOREAD
-            { i32x4 v; asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr)); dst = __builtin_bit_cast(bf16x8, v); return; }
-#endif
             if (!km) {
                 i32x4 v;
                 asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(v) : "v"(addr), "i"(imm));
@@ -1226,11 +1201,9 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
                 asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(fa[sidx % RING]) : "i"(after));
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifndef DIC_GEMM_ABL_NOMFMA
 #pragma unroll
             for (int j = 0; j < G::FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[sidx % RING], acc[i][j], 0, 0, 0);
-#endif
             // Where in the K-step the next stage's DMA is issued (DIC_GEMM_ISSUE_AT).  With operands resident in L2 / the infinity cache, issuing
             // behind the first few MFMA groups is 2-5 % faster (at the head of the K-step the ~8 x 60-180 issue cycles per wave sit in front of
             // the first MFMA of both waves of a SIMD); with operands coming from HBM -- the training step: every operand was just written by
@@ -1244,29 +1217,6 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         issue_b(std::integral_constant<int, 0>{});
         [&]<int... Is>(std::integer_sequence<int, Is...>) { (issue_a(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, (PFD < NS ? PFD : NS)>{});
         [&]<int... Is>(std::integer_sequence<int, Is...>) { (step(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, NS>{});
-#else
-        if (more_k) issue(stage ^ 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fb[G::FN];
-#pragma unroll
-            for (int j = 0; j < G::FN; ++j) fb[j] = frag(lb, offB(j, kk), BKM, ROWB_B);
-#pragma unroll
-            for (int ih = 0; ih < CNT; ih += 4) {            // A fragments four at a time: bounded register footprint at 8 fragments
-                bf16x8 fa[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ih + i < CNT) fa[i] = frag(la, offA(ih + i, kk), AKM, ROWB_A);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ih + i < CNT) {
-#pragma unroll
-                        for (int j = 0; j < G::FN; ++j)
-                            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[ih + i][j], 0, 0, 0);
-                    }
-            }
-        }
-#endif
     };
 
     // ---- persistent loop over (tile, K-slice) units: the grid is capped at the number of co-resident workgroups, so
@@ -1363,8 +1313,6 @@ __device__ __forceinline__ void gemm_bf16_body(DicGemmParams& p, const WgradGrou
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         DIC_STAMP();
         asm volatile("s_barrier" ::: "memory");
-#elif defined(DIC_GEMM_ABL_EARLY)    // timing ablation (results invalid): no wait for the previous tile's stores at the loop top
-        if (unit == (int)blockIdx.x) dma_barrier(); else barrier_lds_only();
 #else
         if (!k0_ready) dma_barrier();        // the tile's first K-step has landed (without XT: and the previous tile's output stores have drained)
 #endif
@@ -1747,7 +1695,6 @@ void launch_bf16(const DicGemmParams& q, hipStream_t st) {
     const int rows = AKM ? G::BM : pick_tile_rows(q.M, nbn_split, resident, G::BM, q.K);
     const int units = nbn_split * ((q.M + rows - 1) / rows);
     const int grid = ((persist_enabled() || q.cu_cap > 0) && units > resident) ? resident : units;
-#ifndef DIC_GEMM_MIN
     if constexpr (std::is_same_v<C, T256> && !AKM && !BKM && (E == DIC_EPI_AFFINE || E == DIC_EPI_BIAS_GELU || E == DIC_EPI_BIAS_GELU_D)) {
         if (q.split_k <= 1 && persist_enabled()) {
             const TwoHeights th = plan_two_heights(q.M, nbn_split, resident, q.K, rows);
@@ -1758,7 +1705,6 @@ void launch_bf16(const DicGemmParams& q, hipStream_t st) {
             }
         }
     }
-#endif
     if constexpr (AKM) {
         launch_bf16_cnt<C, AKM, BKM, E, G::FM>(q, st, grid);
     } else if constexpr (G::FM == 8) {
@@ -1812,7 +1758,6 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
     }
     switch (epi) {
         case DIC_EPI_AFFINE: launch_one<T, AKM, BKM, DIC_EPI_AFFINE>(st, p); break;
-#ifndef DIC_GEMM_MIN          // (measurement builds instantiate the plain forward GEMM only: scripts/experiments/pp_ablate.sh)
         case DIC_EPI_BIAS_GELU: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_BIAS_GELU>(st, p); break;
         case DIC_EPI_GELU_BWD: if constexpr (!AKM) launch_one<T, AKM, BKM, DIC_EPI_GELU_BWD>(st, p); break;
         case DIC_EPI_CE_PARTIAL: if constexpr (!AKM && !BKM) launch_one<T, AKM, BKM, DIC_EPI_CE_PARTIAL>(st, p); break;
@@ -1832,7 +1777,6 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
                 if (p.tile == 256) launch_bf16<T256, false, BKM, DIC_EPI_MUL_AUX>(p, st); else launch_bf16<T128, false, BKM, DIC_EPI_MUL_AUX>(p, st);
             }
             break;
-#endif
     }
     if (split > 1) {
         const long long n4 = (long long)p.M * p.ldc / 4, n4cs = p.colsum_out ? p.M / 4 : 0;
@@ -1848,10 +1792,8 @@ int launch_epi(const DicGemmParams& p, int epi, hipStream_t st) {
 template <typename T>
 int launch_layout(const DicGemmParams& p, int a_km, int b_km, int epi, hipStream_t st) {
     if (!a_km && !b_km) return launch_epi<T, false, false>(p, epi, st);
-#ifndef DIC_GEMM_MIN
     if (!a_km && b_km) return launch_epi<T, false, true>(p, epi, st);
     if (a_km && b_km) return launch_epi<T, true, true>(p, epi, st);
-#endif
     dic_set_error("dic_gemm: (A k-major, B k-contiguous) is not used by the path and not built");
     return 1003;
 }
