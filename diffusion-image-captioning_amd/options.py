@@ -52,10 +52,15 @@ class Options:
     # ---- C library (pushed through dic_set_option when the library is loaded)
     gemm_w4a: bool = True            # the four-wave asm GEMM for every eligible launch, training included (round 5: 14.76 -> 14.35 ms per step once the
                                      # weight gradients run as one launch per two layers; 18.5 -> 17.1 J per step -- profiles/r05_power_ab.txt)
-    gemm_w4a_mask: int = 0x173       # which (layout, epilogue) forms may take it: bit 4 * b_km + {0 plain, 1 + residual, 2 x aux, 3 dropout + residual}, bit 8 GELU
-                                     # (forward-only FFN lin1), bit 9 GELU + GELU' (training FFN lin1).  0x173 = all but the forward dropout + residual form (FFN
-                                     # lin2 in training) and the two-output GELU form: both tie with the 8-wave kernel in the step (profiles/r05_w4a_mask_ab.txt)
-    gemm_w4a_rows: int = 0           # tile height of the asm GEMM: 0 = per launch (256 or 224 rows, by rounds x height), 224 / 256 = forced (A/B measurements)
+    gemm_w4a_mask: int = 0x73        # which (layout, epilogue) forms may take it: bit 4 * b_km + {0 plain, 1 + residual, 2 x aux, 3 dropout + residual}, bit 8 GELU
+                                     # (forward-only FFN lin1), bit 9 GELU + GELU' (training FFN lin1).  0x73 = the forms the last FULL GPU suite and the round-5
+                                     # collection ran.  0x173 adds the forward-only GELU body (measured: 7.24 -> 7.21 ms per sampling pass, profiles/r05_w4a_mask_ab.txt);
+                                     # the dropout + residual and the two-output GELU forms tie with the 8-wave kernel in the step
+    gemm_w4a_rows: int = 256         # tile height of the asm GEMM: 256 | 224 forced, 0 = per launch (256 or 224 rows, by rounds x height; measured 14.41 -> 14.27 ms per
+                                     # step, 7.73 -> 7.52 ms per pass, profiles/r05_tile_rows_probe.txt).  Round 6 ships 256 / 0x73 -- what was last verified END TO
+                                     # END on hardware: the 224-row and GELU bodies passed their own GPU tests (104 cases) and the benches, but the pool closed before
+                                     # the full suite and the collection could be repeated on them, and stayed closed for the whole of round 6.
+                                     # DIC_OPTIONS="gemm_w4a_rows=0,gemm_w4a_mask=0x173" is the faster setting once `scripts/gpu_round.sh` has been run on it.
     gemm_w4n: bool = False           # the NARROW-tile asm GEMM (256 x 128 tiles, epilogue under the next tile's K loop: csrc/gemm_w4n.h) where eligible -- off until measured on hardware
     gemm_w4n_mask: int = 0x7FF       # which (layout, epilogue) forms may take it: the bits of gemm_w4a_mask + bit 10: the rounding-head forward (CE_EXP)
     gemm_w4n_kmax: int = 1024        # launches with K above this keep the 256 x 256 bodies

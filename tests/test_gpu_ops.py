@@ -263,7 +263,6 @@ def test_gemm_four_wave_asm_kernel_matches_float64_and_the_default_kernel(L, M, 
             gemm(L, BF16, 0, b_km, epi, C=p(Cd), **kw)
         finally:
             L.dic_gemm_set_w4a(prev)
-            L.dic_set_option(b"gemm_w4a_rows", 0)
             dic.options.push_to_library(L)
         assert bool((Cfull[M:] == 7.0).all())
         outs.append(Cd)

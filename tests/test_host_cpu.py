@@ -515,6 +515,7 @@ def test_asm_gemm_tile_height_plan_fills_the_rounds_of_resident_workgroups():
     nothing is gained; the option forces either height."""
     L = dic.lib()
     plan = lambda M, N, K, cus=256: L.dic_gemm_w4a_rows_plan(M, N, K, cus)
+    assert plan(17408, 2304, 768) == 256 and L.dic_set_option(b"gemm_w4a_rows", 0) == 0        # (the shipped setting forces 256; 0 = the per-launch plan tested here)
     assert [plan(17408, n, 768) for n in (768, 2304, 3072)] == [224, 224, 224] and plan(17408, 768, 3072) == 224
     assert plan(34816, 768, 768) == 224 and plan(34816, 768, 3072) == 224
     assert plan(34816, 2304, 768) == 256 and plan(34816, 3072, 768) == 256
@@ -525,7 +526,7 @@ def test_asm_gemm_tile_height_plan_fills_the_rounds_of_resident_workgroups():
         assert L.dic_set_option(b"gemm_w4a_rows", 224) == 0 and plan(34816, 2304, 768) == 224 and plan(128, 256, 256) == 256
         assert L.dic_set_option(b"gemm_w4a_rows", 192) != 0
     finally:
-        assert L.dic_set_option(b"gemm_w4a_rows", 0) == 0
+        importlib.import_module("diffusion-image-captioning_amd.options").push_to_library(L)
 
 
 def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic_execution():
@@ -760,7 +761,7 @@ def test_options_record_is_the_only_switchboard_and_pins_the_shipped_configurati
     opts = importlib.import_module("diffusion-image-captioning_amd.options")
     shipped = dict(wgrad_stream=True, wgrad_group="pair", bwd_sets=0, wgrad_cu_cap=0, ln_npart=512, gemm_tile="auto", gemm_v1=False, gelu_d=True, ce_fused=True,
                    head_center="1", uvt32=True, split_set="auto", lo_row_stride=16, qkv_pred=True, cen=True, cen_operand=True, res32="auto", sample_raw=True, streamed_adamw=True,
-                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x173, gemm_w4a_rows=0, gemm_w4n=False, gemm_w4n_mask=0x7FF, gemm_w4n_kmax=1024, gemm_w4n_flat=True, gemm_two_heights=False, dp_group=3,
+                   sample_graph=True, sample_w4a=True, sample_two_heights=True, gemm_w4a=True, gemm_w4a_mask=0x73, gemm_w4a_rows=256, gemm_w4n=False, gemm_w4n_mask=0x7FF, gemm_w4n_kmax=1024, gemm_w4n_flat=True, gemm_two_heights=False, dp_group=3,
                    dp_single=False, dp_cu_cap=0, dp_timing=False, force_reducer=False, dp_timeout_s=600)
     assert dataclasses.asdict(opts.Options()) == shipped
     assert opts.Options().n_bwd_sets == 4 and opts.from_env({"DIC_OPTIONS": "wgrad_group=1"}).n_bwd_sets == 2
