@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generator of the NARROW-tile four-wave GEMM bodies (csrc/gemm_w4n_asm.inc), round 6 -- DESIGN.md section 7.0001 built.
+"""Generator of the NARROW-tile four-wave GEMM bodies (csrc/gemm_w4n_asm.inc), round 6 -- DESIGN.md section 7.0001.  Proven on the CPU (scripts/w4n_emulate.py,
+scripts/w4n_hazard_check.py) and assembled by hipcc; NOT yet run on hardware when this was written (GPU use was closed): the library keeps it behind options.gemm_w4n.
 
 Why a second geometry.  The 256 x 256 bodies of scripts/gen_w4a.py spend, on a K = 768 problem, 12 K-steps at the L2 -> LDS latency floor of a
 two-stage pipeline and then an epilogue that NOTHING overlaps (one wave per SIMD, all 256 accumulation registers in use): 9 % of a tile for a plain
@@ -13,11 +14,16 @@ epilogue, 39-42 % for the GELU forms (profiles/r05_w4a_instruction_mix.txt).  He
     K-step k + 3 goes into the stage K-step k has just finished with -- two K-steps in flight instead of 1.2, and ONE barrier per K-step instead of two:
     "all my reads of stage s have returned (lgkmcnt 0) and my pieces of K-step k + 1 have landed (vmcnt N)" -> s_barrier -> K-step k + 1 is visible to
     everybody and stage s is free for everybody's DMA;
-  * the K loop is unrolled by three (first / second / middle ... / last triple; K a multiple of 192, >= 576).  The middle triple is the only loop and
-    carries no epilogue work, so its counted waits see the same VMEM history on every entry (asserted); every vmcnt is DERIVED from the order in which
-    the generator has issued loads, LDS-DMA pieces and stores (gfx950: one in-order counter);
-  * the last triple's DMA slots carry the NEXT tile's first three K-steps (descriptor swap), as in the wide bodies; the kernel prologue replays the last
-    triple's VMEM sequence (real pieces of tile 0, null stores for everything else) so that the first tile's waits see the history every later tile sees.
+  * two forms of the K loop.  LOOP form (any K = 192 n >= 576): unrolled by three -- first / second / middle ... / last triple.  The middle triple is the only loop and
+    carries no epilogue work, and the second triple is its twin, so the loop's counted waits see the same VMEM history on every entry (asserted); the queue drains in the
+    first and the last triple only.  FLAT form (`flat=12`: K = 768, the model's only short K; what csrc/gemm_w4n.h takes for it): twelve K-steps of straight-line text, the
+    queue paced evenly over all of them but the first (`Pacer`) -- scripts/w4n_issue_model.py shows why: with a GELU queue the loop form's five draining K-steps are
+    issue-bound at ~2 900 cycles while its clean ones idle at the DMA bound (0.86 of the wide bodies' cost), the flat form lands every K-step at the DMA bound (0.65).
+    Every vmcnt is DERIVED from the order in which the generator has issued loads, LDS-DMA pieces and stores (gfx950: one in-order counter);
+  * the last three K-steps' DMA slots carry the NEXT tile's first three K-steps (descriptor swap), as in the wide bodies; the kernel prologue replays the last
+    triple's VMEM sequence (real pieces of tile 0, null stores for everything else; two-pass generation) so that the first tile's waits see the history every later tile sees;
+  * epilogue forms: the wide bodies' six + `ceexp`, the rounding-head forward (DIC_EPI_CE_EXP: bf16(exp(acc + bias - c_row)), zeros beyond a ragged N, the unrounded sums per
+    64-column slab, the target's logit; per-row loads, v_permlane swaps and out-of-range lane offsets instead of EXEC masks -- see epilogue_queue).
 
 LDS (bytes): A stages [0, 32K), [32K, 64K), [64K, 96K); B stages [96K, 112K), [112K, 128K), [128K, 144K); tile table [144K, +16K).
 LDS images, swizzle keys, B-row permutation, MFMA operand order (D = Bfrag x Afrag), DPP exchange and full-line stores are those of gen_w4a.py / the 8-wave
@@ -646,7 +652,8 @@ class Gen:
         else:
             # ---- CE_EXP: three more pointers behind the common arguments (lse, partial, tgt_logit; tgt came in the side-input slot, np in ldr), constant resources
             # over the whole arrays, lane constants.  The registers they take were the prologue's (K, lda, ldb, ldc) or belong to forms this one is not.
-            a(f"s_load_dwordx4 s[{S_RSA}:{S_RSA + 3}], {OP['karg']}, 104")
+            a(f"s_load_dwordx2 s[{S_RSA}:{S_RSA + 1}], {OP['karg']}, 104")           # (three naturally aligned 8-byte loads: no assumption about the segment's alignment)
+            a(f"s_load_dwordx2 s[{S_RSA + 2}:{S_RSA + 3}], {OP['karg']}, 112")
             a(f"s_load_dwordx2 s[{S_RSB}:{S_RSB + 1}], {OP['karg']}, 120")
             a("s_waitcnt lgkmcnt(0)")
             a(f"s_sub_u32 s{S_M1}, s{S_M}, 1")
