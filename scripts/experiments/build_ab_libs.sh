@@ -7,6 +7,7 @@
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd); cd $R; mkdir -p abl
 python scripts/gen_w4a.py abl/w4a_var.inc block_waits early_side defer_stores 2> /dev/null
+echo "block_waits early_side defer_stores" > abl/w4a_var.opts
 python scripts/gen_w4n.py abl/w4n_bar2.inc bar=2 2> /dev/null
 python scripts/gen_w4n.py abl/w4n_bar4.inc bar=4 2> /dev/null
 python scripts/gen_w4n.py abl/w4n_quota4.inc quota=4 2> /dev/null

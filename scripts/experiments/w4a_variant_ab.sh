@@ -17,7 +17,13 @@ bad = sum((lambda r: r[0] > 1.0 or not r[1])(W.run_case(ni, bkm, epi, 32 * ni + 
 print("emulator:", "all bodies reproduce numpy" if not bad else f"{bad} bodies DIFFER")
 sys.exit(1 if bad else 0)
 PY
-bash scripts/build_variant.sh w4avar "-DW4A_ASM_INC=<w4a_var.inc> -I$R/abl" > /dev/null
+# (the variant library is normally built in the CPU container by scripts/experiments/build_ab_libs.sh and travels with the snapshot: rebuild only if it is missing, was built
+#  from other kernel sources or for other options -- 2.5 minutes of GPU-box time otherwise)
+if [ -f abl/libdic_w4avar.so ] && [ "$(cat abl/BUILT_FROM 2>/dev/null)" = "$(python -c 'import bench; print(bench.csrc_sha())')" ] && [ "$(cat abl/w4a_var.opts 2>/dev/null)" = "$OPTS" ]; then
+  echo "variant library: reusing abl/libdic_w4avar.so"
+else
+  bash scripts/build_variant.sh w4avar "-DW4A_ASM_INC=<w4a_var.inc> -I$R/abl" > /dev/null && echo "$OPTS" > abl/w4a_var.opts
+fi
 {
 echo "# asm GEMM generator options: $OPTS"
 DIC_HIP_LIB=$R/abl/libdic_w4avar.so python scripts/experiments/w4a_check.py 2>&1 | tail -1

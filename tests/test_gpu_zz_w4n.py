@@ -164,3 +164,47 @@ def test_rounding_head_forward_on_the_narrow_tile_kernel_matches_the_eight_wave_
     assert float((T1[:M][valid] - T0[:M][valid]).abs().max()) < 1e-4 and bool((T1[:M][~valid] == 9.0).all())
     want = torch.exp(logits.double().cpu() - cref.double().cpu()[:, None])
     assert relerr(E1[:M, :V].float(), want) < 6e-3
+
+
+def test_training_steps_with_the_narrow_tile_kernel_on_every_eligible_launch_match_the_shipped_configuration(L):
+    """End to end: two AdamW steps of the default engine (12 288 token rows = 48 x 256, 2 layers, the full 30 522-word rounding head, dropout ON) with options.gemm_w4n on
+    -- q|k|v, out-proj, FFN lin1 (+ GELU'), the K = 768 input gradients and the rounding-head forward then run on the narrow bodies -- against the same steps in the
+    shipped configuration.  Where the shipped step runs the wide asm bodies the narrow ones are bit-identical; the dropout + residual, GELU + GELU' and CE_EXP launches move
+    from the 8-wave kernel (bias in front of the K loop, another order of a row's slab sum): the four losses agree to 2e-5 and the parameters after two steps to 1e-5 of their
+    norm -- same dropout masks (one hash), same targets.  This is the test that exercises launch_w4n_ce inside the engine (np, ldE = vpad, the cleared slab slots)."""
+    import importlib
+    import numpy as np
+    opts = importlib.import_module("diffusion-image-captioning_amd.options")
+    synth = dic.synth
+    B, S, Lc, V, nl = 128, 1, 16, 30522, 2
+    dic.cfg.update(BATCH_SIZE=B, SAMPLE_SIZE=S, MAX_LENGTH=Lc, STEP_TOT=100, COSIN_SCHEDULE=False, ROUNDING_WEIGHT=0.5, VOCAB_SIZE=V,
+                   LOSS_FUNC="series_sum_sample_mean", CLIP_ADDING_METHOD="concat", CLASSIFIER_FREE_WEIGHT=0.0, X_0_PREDICTION=True)
+    dic.set_alpha_cumprod(None)
+    E = synth.vocab_embedding(V, 768, 0)
+    state = synth.denoiser_state(nl, 0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in synth.batch(B, Lc, V, 1).items()}
+    t = torch.from_numpy(synth.timesteps(S, 100, 0))
+    nz = [torch.from_numpy(synth.noise((B, Lc, 768), 3, f"eps{i}")) for i in range(2)]
+    out = []
+    try:
+        for narrow in (False, True):
+            opts.set_option("gemm_w4n", narrow)
+            opts.set_option("gemm_w4n_mask", 0x7FF)
+            model = dic.DistilBertModel(E, E, config=dict(n_layers=nl, dropout=0.1, attention_dropout=0.1), dtype="bf16", seed=0)
+            model.load_state(state)
+            trainer = dic.AdamW(model.parameters(), lr=1e-4)
+            losses = []
+            for _ in range(2):
+                losses.append([float(v) for v in dic.train_func(model, trainer, x, t=t, noises=nz)])
+            torch.cuda.synchronize()
+            # (k_lin.bias has an analytically zero gradient -- softmax shift invariance -- and Adam turns its round-off into +-lr noise: left out, as in smoke())
+            out.append((np.array(losses), [p_.detach().float().clone() for n_, p_ in model.named_parameters() if not n_.endswith("k_lin.bias")]))
+            del model, trainer
+            torch.cuda.empty_cache()
+    finally:
+        opts.set_option("gemm_w4n", False)
+        dic.options.push_to_library(L)
+    (l0, p0), (l1, p1) = out
+    assert np.isfinite(l1).all() and (np.abs(l1 - l0) <= 2e-5 * np.abs(l0)).all(), (l0, l1)
+    worst = max(float((a - b).norm() / (a.norm() + 1e-30)) for a, b in zip(p0, p1))
+    assert worst < 1e-5, worst
