@@ -1,7 +1,7 @@
 #!/bin/bash
 # First hardware run of the NARROW-tile asm GEMM (csrc/gemm_w4n.h, option gemm_w4n; built and proven on the CPU only so far), on the GPU box:
 #   bash scripts/experiments/w4n_ab.sh            (through gpurun; ~12 minutes)
-# 1. parity: the narrow bodies against the wide ones bit for bit + float64 (tests/test_gpu_zz_w4n.py with --runxfail: 129 cases);
+# 1. parity: the narrow bodies against the wide ones bit for bit + float64 (tests/test_gpu_zz_w4n.py with --runxfail: 133 cases);
 # 2. per launch inside the step (scripts/gemm_in_step.py), option off / on;
 # 3. the step and the sampling pass, interleaved off / on, twice; then per (layout, epilogue) form: which forms pay (gemm_w4n_mask one bit at a time).
 R=$(cd "$(dirname "$0")/../.." && pwd); cd $R; O=$R/gpurun_out; mkdir -p $O
@@ -25,7 +25,7 @@ for bit in 0 1 2 3 4 5 6 8 9 10; do
 done
 # generator options of the narrow bodies (variant libraries built by scripts/experiments/build_ab_libs.sh from the same sources)
 if [ "$(cat abl/BUILT_FROM 2>/dev/null)" = "$(python -c 'import bench; print(bench.csrc_sha())')" ]; then
-  for v in w4n_bar2 w4n_bar4 w4n_quota4; do
+  for v in w4n_pk1 w4n_bar2 w4n_bar4 w4n_quota4; do
     [ -f abl/libdic_$v.so ] || continue
     echo "## step, narrow, variant $v:  $(DIC_HIP_LIB=$R/abl/libdic_$v.so DIC_OPTIONS=gemm_w4n=1 python bench.py --quick --no-roofline --steps 40 2>/dev/null | tail -1 | cut -c1-140)"
     echo "## pass, narrow, variant $v:  $(DIC_HIP_LIB=$R/abl/libdic_$v.so DIC_OPTIONS=gemm_w4n=1 python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"

@@ -18,7 +18,8 @@ epilogue, 39-42 % for the GELU forms (profiles/r05_w4a_instruction_mix.txt).  He
     carries no epilogue work, and the second triple is its twin, so the loop's counted waits see the same VMEM history on every entry (asserted); the queue drains in the
     first and the last triple only.  FLAT form (`flat=12`: K = 768, the model's only short K; what csrc/gemm_w4n.h takes for it): twelve K-steps of straight-line text, the
     queue paced evenly over all of them but the first (`Pacer`) -- scripts/w4n_issue_model.py shows why: with a GELU queue the loop form's five draining K-steps are
-    issue-bound at ~2 900 cycles while its clean ones idle at the DMA bound (0.86 of the wide bodies' cost), the flat form lands every K-step at the DMA bound (0.65).
+    issue-bound at ~3 000 cycles while its clean ones idle at the DMA bound (0.89 of the wide bodies' cost), the flat form lands every K-step near the DMA bound (0.69;
+    0.85 in that script's stricter model).
     Every vmcnt is DERIVED from the order in which the generator has issued loads, LDS-DMA pieces and stores (gfx950: one in-order counter);
   * the last three K-steps' DMA slots carry the NEXT tile's first three K-steps (descriptor swap), as in the wide bodies; the kernel prologue replays the last
     triple's VMEM sequence (real pieces of tile 0, null stores for everything else; two-pass generation) so that the first tile's waits see the history every later tile sees;
@@ -118,14 +119,53 @@ def parse_opts(opts):
        and the FORM of the K loop (both forms are shipped: csrc/gemm_w4n.h takes the flat one where K allows):
          flat=n    no loop: the tile's n K-steps (n = 12: K = 768, the model's only short K) are straight-line text and ALL of them but the first drain the epilogue queue
                    -- with the loop form the clean middle K-steps idle at the DMA bound while the few that drain a GELU queue are issue-bound at twice that
-                   (scripts/w4n_issue_model.py)"""
-    d = dict(bar=3, quota=2, flat=0)
+                   (scripts/w4n_issue_model.py)
+         pk=1      keep the epilogue's packed fp32 arithmetic (v_pk_fma / v_pk_mul / v_pk_add_f32) as the wide bodies have it.  Default 0: every packed operation of the queue is
+                   emitted as its two scalar halves (same IEEE operation per element: same bits) -- /opt/skills/guides/MI355X_MICROARCH.md measures packed fp32 VALU operations
+                   BESIDE MFMAs at +22-26 cycles beyond their issue slot ("an anti-lever beside MFMAs"; a transcendental costs ~2 there).  In the wide bodies the epilogue runs
+                   alone and packing won 2 %; here the queue runs between MFMAs."""
+    d = dict(bar=3, quota=2, flat=0, pk=0)
     for o in opts:
         k, _, v = o.partition("=")
         assert k in d, o
         d[k] = int(v)
-    assert 2 <= d["bar"] <= 4 and 1 <= d["quota"] <= 16 and (d["flat"] == 0 or (d["flat"] % 3 == 0 and d["flat"] >= 9))
+    assert d["pk"] in (0, 1) and 2 <= d["bar"] <= 4 and 1 <= d["quota"] <= 16 and (d["flat"] == 0 or (d["flat"] % 3 == 0 and d["flat"] >= 9))
     return d
+
+
+def unpack_pk(text):
+    """One packed fp32 instruction of the queue -> its two scalar halves (low, high), or None if `text` is not one."""
+    import re
+    op, _, rest = text.partition(" ")
+    if op not in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):
+        return None
+    n_src = 3 if op == "v_pk_fma_f32" else 2
+    toks = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", rest)]
+    mods = " ".join(" ".join(t.split()[1:]) for t in toks)
+    toks = [t.split()[0] for t in toks]
+    dst, srcs = toks[0], toks[1:1 + n_src]
+
+    def flags(name):
+        m = re.search(name + r":\[([\d,]+)\]", mods)
+        return [int(x) for x in m.group(1).split(",")] if m else None
+    sel_hi, neg_lo, neg_hi = flags("op_sel_hi") or [1] * n_src, flags("neg_lo") or [0] * n_src, flags("neg_hi") or [0] * n_src
+    d0 = int(re.fullmatch(r"v\[(\d+):(\d+)\]", dst).group(1))
+    out = []
+    for half in (0, 1):
+        ops = []
+        for k, s_ in enumerate(srcs):
+            m = re.fullmatch(r"v\[(\d+):(\d+)\]", s_)
+            if m:
+                assert sel_hi[k] == 1, text           # (a register pair whose high half is taken from its low dword would make the two halves order-dependent)
+                tok = f"v{int(m.group(1)) + half}"
+            else:
+                tok = s_                              # an inline constant: the same value for both halves
+            ops.append(("-" if (neg_hi if half else neg_lo)[k] else "") + tok)
+        name = {"v_pk_add_f32": "v_add_f32", "v_pk_mul_f32": "v_mul_f32", "v_pk_fma_f32": "v_fma_f32"}[op]
+        if name != "v_fma_f32" and not ops[1].lstrip("-").startswith("v"):
+            ops = ops[::-1]                           # (VOP2: a constant may only be the first source)
+        out.append(f"{name} v{d0 + half}, " + ", ".join(ops))
+    return out
 
 
 class Pacer:
@@ -455,6 +495,12 @@ class Gen:
                 q(f"s_add_u32 s{S_T}, s{S_T}, {64 * i}")
                 q.vmem("store", f"buffer_store_dword v{V_TV}, v{V_OWN}, s[{S_DTL}:{S_DTL + 3}], s{S_T} offen")
             q(f"s_add_u32 s{S_SOFF}, s{S_SOFF}, s{S_LDC16}")
+        if not self.o["pk"]:                                  # the queue runs BETWEEN MFMAs: no packed fp32 arithmetic there (parse_opts)
+            items = []
+            for it in q.items:
+                halves = unpack_pk(it[1]) if it[0] == "ins" else None
+                items += [("ins", h) for h in halves] if halves else [it]
+            q.items = items
         return q
 
     def drain(self, q, n):

@@ -32,7 +32,9 @@ class Emu(E.Emu):
         op, _, rest = ln.partition(" ")
         args = [a.strip() for a in re.split(r",\s*(?![^\[]*\])", rest)] if rest else []
         V = self.V
-        f32 = lambda tok: self.src(tok).view(np.float32)
+        def f32(tok):                                         # a float source, with the VOP3 negation prefix the unpacked queue uses
+            tok = tok.strip()
+            return -self.src(tok[1:]).view(np.float32) if tok.startswith("-") else self.src(tok).view(np.float32)
         if op == "v_accvgpr_mov_b32":
             self.A[int(args[0][1:])] = self.A[int(args[1][1:])].copy()
         elif op == "global_load_dwordx2":
@@ -46,9 +48,13 @@ class Emu(E.Emu):
             d = int(args[0][1:])
             addr, off, nrec = self.buffer_addr(args, rest, 4)
             V[d] = self.gather(addr, off + 4 <= nrec, 4).view(U32).reshape(NL)
-        elif op in ("v_min_f32", "v_add_f32"):
+        elif op in ("v_min_f32", "v_add_f32", "v_mul_f32"):
             a_, b_ = f32(args[1]), f32(args[2])
-            V[int(args[0][1:])] = (np.minimum(a_, b_) if op == "v_min_f32" else (a_ + b_)).astype(np.float32).view(U32)
+            r_ = np.minimum(a_, b_) if op == "v_min_f32" else (a_ + b_) if op == "v_add_f32" else (a_ * b_)
+            V[int(args[0][1:])] = np.asarray(r_, dtype=np.float32).view(U32)
+        elif op == "v_fma_f32":                               # fused: one rounding
+            r_ = (f32(args[1]).astype(np.float64) * f32(args[2]).astype(np.float64) + f32(args[3]).astype(np.float64)).astype(np.float32)
+            V[int(args[0][1:])] = r_.view(U32)
         elif op == "v_min_u32":
             V[int(args[0][1:])] = np.minimum(self.src(args[1]), self.src(args[2]))
         elif op == "v_sub_u32":
