@@ -254,11 +254,16 @@ class Gen:
         pr = lambda r: f"v[{r}:{r + 1}]"
         gc = lambda n: pr(V_GC + 2 * n)
         R2 = range(len(X))
-        for k in R2:
-            q(f"v_and_b32 v{D[k]}, 0x7fffffff, v{X[k]}")
-            q(f"v_and_b32 v{D[k] + 1}, 0x7fffffff, v{X[k] + 1}")
-        for k in R2:
-            q(f"v_pk_fma_f32 {pr(D[k])}, {pr(D[k])}, {gc(GC_K1)}, 1.0 op_sel_hi:[1,1,0]")
+        if self.o["pk"]:
+            for k in R2:
+                q(f"v_and_b32 v{D[k]}, 0x7fffffff, v{X[k]}")
+                q(f"v_and_b32 v{D[k] + 1}, 0x7fffffff, v{X[k] + 1}")
+            for k in R2:
+                q(f"v_pk_fma_f32 {pr(D[k])}, {pr(D[k])}, {gc(GC_K1)}, 1.0 op_sel_hi:[1,1,0]")
+        else:                                                 # scalar queue: |u| is a source modifier of the fma (one VALU instruction less per element; same value)
+            for k in R2:
+                for h in range(2):
+                    q(f"v_fma_f32 v{D[k] + h}, |v{X[k] + h}|, v{V_GC + 2 * GC_K1 + h}, 1.0")
         for k in R2:
             q(f"v_pk_mul_f32 {pr(G[k])}, {pr(X[k])}, {pr(X[k])}")
         for k in R2:

@@ -34,7 +34,11 @@ class Emu(E.Emu):
         V = self.V
         def f32(tok):                                         # a float source, with the VOP3 negation prefix the unpacked queue uses
             tok = tok.strip()
-            return -self.src(tok[1:]).view(np.float32) if tok.startswith("-") else self.src(tok).view(np.float32)
+            if tok.startswith("-"):
+                return -f32(tok[1:])
+            if tok.startswith("|"):
+                return np.abs(self.src(tok.strip("|")).view(np.float32))
+            return self.src(tok).view(np.float32)
         if op == "v_accvgpr_mov_b32":
             self.A[int(args[0][1:])] = self.A[int(args[1][1:])].copy()
         elif op == "global_load_dwordx2":
