@@ -593,7 +593,7 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
     a ragged second row tile and two column tiles, with zero and with one pass of the middle loop, guard bytes intact; a single-tile launch (prologue + post-loop
     epilogue only) too; mutations -- one accumulator move dropped, one fragment-read offset, one B piece's LDS target -- must change the result.  (3) symbolic
     execution (scripts/w4n_hazard_check.py): every counted wait, the barrier of every K-step and the accumulator hand-over (each of a[128:255] filled once and
-    read once per tile) hold for K = 576 ... 2304 and 1-3 tiles; mutations -- every barrier dropped, lgkmcnt(0) removed from every barrier's wait, the barrier
+    read once per tile; no write into a wide store's data registers right behind it; 12 states between an MFMA and another reader of its result) hold for K = 576 ... 2304 and 1-3 tiles; mutations -- every barrier dropped, lgkmcnt(0) removed from every barrier's wait, the barrier
     waits' vmcnt weakened -- must be reported."""
     import re
     import subprocess
@@ -645,6 +645,17 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
     assert emu_mutated(lambda l: l.startswith("ds_read_b128 v[40:43]"), lambda l: re.sub(r"offset:(\d+)", lambda m: f"offset:{int(m.group(1)) + 2048}", l))
     assert emu_mutated(lambda l: l.startswith(f"s_add_u32 m0, s{G.S_M0B}, {16384 + 2048}"), lambda l: l.replace(str(16384 + 2048), str(16384 + 3072)))
     # (3) symbolic execution
+    st = "buffer_store_dwordx4 v[80:83], v122, s[68:71], s97 offen"              # R13 on a minimal sequence: reported without, accepted with, the pad
+
+    def runs(seq):
+        sim = H.Sim(seq, 768, 1)
+        try:
+            for k in range(len(seq)):
+                sim.step(k)
+        except H.Violation:
+            return False
+        return True
+    assert not runs([st, "v_mov_b32 v81, v0"]) and runs([st, "s_nop 1", "v_mov_b32 v81, v0"])
     assert H.check_all() == 10 * 5
     assert H.check_all(opts=("flat=12",), shapes=((768, 1), (768, 2), (768, 4))) == 10 * 3
     for bkm, epi, fopts in ((False, "plain", ()), (True, "mulaux", ()), (False, "gelud", ()), (False, "gelud", ("flat=12",)), (True, "plain", ("flat=12",)), (False, "ceexp", ("flat=12",))):
