@@ -62,7 +62,9 @@ class Options:
                                      # the full suite and the collection could be repeated on them, and stayed closed for the whole of round 6.
                                      # DIC_OPTIONS="gemm_w4a_rows=0,gemm_w4a_mask=0x173" is the faster setting once `scripts/gpu_round.sh` has been run on it.
     gemm_w4n: bool = False           # the NARROW-tile asm GEMM (256 x 128 tiles, epilogue under the next tile's K loop: csrc/gemm_w4n.h) where eligible -- off until measured on hardware
-    gemm_w4n_mask: int = 0x7FF       # which (layout, epilogue) forms may take it: the bits of gemm_w4a_mask + bit 10: the rounding-head forward (CE_EXP)
+    gemm_w4n_mask: int = 0x740       # which (layout, epilogue) forms may take it: the bits of gemm_w4a_mask + bit 10: the rounding-head forward (CE_EXP).  0x740 = the forms the issue
+                                     # model favours (profiles/r06_w4n_issue_model.txt): GELU, GELU + GELU', CE_EXP and the k-major x aux form (FFN lin2's input gradient); the light forms and
+                                     # everything that runs at N = 768 (one wide tile per CU already) stay on the wide bodies.  To be replaced by what scripts/experiments/w4n_ab.sh measures
     gemm_w4n_kmax: int = 1024        # launches with K above this keep the 256 x 256 bodies
     gemm_w4n_flat: bool = True       # K = 768 launches of the narrow GEMM take its loop-free bodies (False: the loop form everywhere -- A/B)
     gemm_two_heights: bool = False   # two tile heights per launch everywhere

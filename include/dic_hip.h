@@ -146,7 +146,7 @@ int dic_gemm_set_variant(int pp);
  * GEMM where eligible), "gemm_w4a_mask" (default 0x3FF; bit 4 * b_km + v allows epilogue form v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual; bit 8: BIAS_GELU / BIAS_GELU_D without aux, bit 9: BIAS_GELU_D with aux -- k-contiguous B only), "gemm_w4a_rows" (default 0: the asm kernel's tile height per launch -- 256 or 224 rows, whichever fills the rounds of resident workgroups better; 224 / 256 force one), "gemm_two_heights" (default 0), "gemm_rows" (default 1: per-launch tile heights), "gemm_persist" (default 1: persistent grids),
  * "gemm_v1" (default 0: bf16 on the register-staged fp32-style kernel), "gemm_w4n" (0 / 1, default 0; needs "gemm_w4a" = 1: launches inside the four-wave asm GEMM's scope -- with its K condition replaced by "a multiple of 192 in
  * [576, gemm_w4n_kmax]", "gemm_w4n_kmax" default 1024 -- run on its NARROW-tile form -- 256 x 128 tiles, the finished tile's epilogue drained under the next tile's K loop,
- * csrc/gemm_w4n.h; results are bit-identical to the wide bodies'), "gemm_w4n_mask" (default 0x7FF: the bits of "gemm_w4a_mask" + bit 10, the CE_EXP
+ * csrc/gemm_w4n.h; results are bit-identical to the wide bodies'), "gemm_w4n_mask" (default 0x740 = the heavy-epilogue forms; the bits of "gemm_w4a_mask" + bit 10, the CE_EXP
  * launch of the rounding head -- ldc = N rounded up to 128, tile 256),
  * "gemm_w4n_flat" (default 1: K = 768 launches take the loop-free narrow bodies, 0: the loop form everywhere).  Unknown name: 1007.                */
 int dic_set_option(const char* name, int value);

@@ -3,7 +3,7 @@
 #   bash scripts/experiments/w4n_ab.sh            (through gpurun; ~12 minutes)
 # 1. parity: the narrow bodies against the wide ones bit for bit + float64 (tests/test_gpu_zz_w4n.py with --runxfail: 133 cases);
 # 2. per launch inside the step (scripts/gemm_in_step.py), option off / on;
-# 3. the step and the sampling pass, interleaved off / on, twice; then per (layout, epilogue) form: which forms pay (gemm_w4n_mask one bit at a time).
+# 3. the step and the sampling pass, interleaved off / on (on = the default mask 0x740: the heavy-epilogue forms), twice; then per (layout, epilogue) form: which forms pay (gemm_w4n_mask one bit at a time).
 R=$(cd "$(dirname "$0")/../.." && pwd); cd $R; O=$R/gpurun_out; mkdir -p $O
 {
 echo "# narrow-tile asm GEMM: first hardware run   $(date -u +%FT%TZ)"
@@ -16,6 +16,8 @@ for i in 1 2; do
   echo "## pass, wide:    $(python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
   echo "## pass, narrow:  $(DIC_OPTIONS=gemm_w4n=1 python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
 done
+echo "## step, narrow on EVERY eligible form (gemm_w4n_mask=0x7ff):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_mask=0x7ff python bench.py --quick --no-roofline --steps 40 2>/dev/null | tail -1 | cut -c1-140)"
+echo "## pass, narrow on EVERY eligible form (gemm_w4n_mask=0x7ff):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_mask=0x7ff python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
 echo "## step, narrow, loop form everywhere (gemm_w4n_flat=0):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_flat=0 python bench.py --quick --no-roofline --steps 40 2>/dev/null | tail -1 | cut -c1-140)"
 echo "## pass, narrow, loop form everywhere (gemm_w4n_flat=0):  $(DIC_OPTIONS=gemm_w4n=1,gemm_w4n_flat=0 python bench.py --mode sample 2>/dev/null | tail -1 | cut -c1-170)"
 # which forms pay: bit 4 * b_km + v (v = 0 plain, 1 + residual, 2 x aux, 3 dropout + residual), bit 8 GELU, bit 9 GELU + GELU', bit 10 the rounding-head forward (CE_EXP)
