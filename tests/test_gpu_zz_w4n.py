@@ -204,6 +204,7 @@ def test_training_steps_with_the_narrow_tile_kernel_on_every_eligible_launch_mat
             torch.cuda.empty_cache()
     finally:
         opts.set_option("gemm_w4n", False)
+        opts.set_option("gemm_w4n_mask", opts.Options().gemm_w4n_mask)
         dic.options.push_to_library(L)
     (l0, p0), (l1, p1) = out
     assert np.isfinite(l1).all() and (np.abs(l1 - l0) <= 2e-5 * np.abs(l0)).all(), (l0, l1)
