@@ -17,7 +17,9 @@ taken, under the weakest assumption the ISA allows (a memory operation has compl
   R6-R10  the fixed-latency hazards gfx940-class hardware does NOT interlock, counted in wait states (one per instruction, n + 1 per `s_nop n`):
       an MFMA's accumulator read by v_accvgpr_read (>= 11: covers matrix operations of up to 8 passes), a VALU result read by a DPP instruction (>= 2),
       a transcendental's result read by another VALU instruction (>= 1), m0 written by the SALU and used by an LDS-DMA (>= 1), an SGPR written by
-      v_readfirstlane and used by a buffer instruction (>= 5).
+      v_readfirstlane and used by a buffer instruction (>= 5);
+  R13  (round 6, from /opt/skills/guides/cdna_hip_programming.md section 5.7) the data registers of a wide store (buffer_store_dwordx3 / x4) are not written within two wait states
+      behind it (the store reads them late; the generator pads with `s_nop 1`), and R6 asks for the guide's 12 states behind an MFMA instead of the ISA table's 11.
 
 Loads and stores retire in order per counter (gfx950: ONE in-order vmcnt for global loads, LDS-DMA and stores; LDS reads return in order), which is what
 the generator assumes; a counter of w bits cannot hold more than 2^w - 1 operations, so the oldest of more than that has completed.
@@ -69,6 +71,7 @@ class Sim:
         self.ws = 0                      # wait-state clock: instructions issued so far (s_nop n counts n + 1)
         self.acc_w, self.valu_w, self.trans_w, self.rfl_w = {}, {}, {}, {}   # register -> wait-state clock right after the instruction that wrote it
         self.m0_w = -100
+        self.store_w = {}                # VGPR -> wait-state clock right behind the wide store that reads it as data (R13)
 
     # ------------------------------------------------------------------ helpers
     def fail(self, i, msg):
@@ -116,6 +119,8 @@ class Sim:
 
     def write_v(self, i, regs):
         for r in regs:
+            if r in self.store_w and self.ws - self.store_w[r] < 2:
+                self.fail(i, f"R13: v{r} is written {self.ws - self.store_w[r]} wait states behind the dwordx4 store that reads it as data (2 required)")
             if r in self.pend:
                 self.fail(i, f"R1: overwrites v{r} while {self.pend[r]['what']} (line {self.pend[r]['line']}) is still to write it")
 
@@ -275,6 +280,9 @@ class Sim:
                 self.pend[r] = o
             return i + 1
         if op.startswith("buffer_store"):
+            if op in ("buffer_store_dwordx4", "buffer_store_dwordx3"):
+                for r in vregs(args[0]):
+                    self.store_w[r] = self.ws + 1
             self.read_v(i, vregs(args[0]) + vregs(args[1]))
             self.issue(self.vm, dict(line=i, what="a store", dst=[]), self.VM_MAX)
             return i + 1
@@ -302,7 +310,7 @@ class Sim:
             self.read_v(i, srcs)
             self.write_v(i, dst)
             if op == "v_accvgpr_read_b32":
-                self.gap(i, self.acc_w, [int(args[1][1:])], 11, "R6")
+                self.gap(i, self.acc_w, [int(args[1][1:])], 12, "R6")
             if "_dpp" in op:
                 self.gap(i, self.valu_w, vregs(args[1].split()[0]), 2, "R7")
             trans = op in ("v_rcp_f32", "v_exp_f32")

@@ -33,7 +33,6 @@ class Sim(H.Sim):
     def __init__(self, lines, K, ntiles, name=""):
         super().__init__(lines, 8, K, ntiles, name)
         self.reg = {(o, s_): dict(state="EMPTY", dma=[], reads=[], drained=0) for o in "AB" for s_ in (0, 1, 2)}
-        self.store_w = {}                  # VGPR -> wait-state clock right behind the wide store that reads it as data
         self.acc1_epoch = [0] * 128        # how many times a[128 + r] has been filled
         self.acc1_reads = [0] * 128        # reads since the last fill
         self.moves = 0
@@ -61,19 +60,10 @@ class Sim(H.Sim):
             elif rg["state"] == "READY" and all(o["done"] for o in rg["reads"]):
                 rg["drained"] = len(rg["reads"])
 
-    def write_v(self, i, regs):
-        super().write_v(i, regs)
-        for r in regs:                     # R13
-            if r in self.store_w and self.ws - self.store_w[r] < 2:
-                self.fail(i, f"R13: v{r} is written {self.ws - self.store_w[r]} wait states behind the dwordx4 store that reads it as data (2 required)")
-
     def step_(self, i):
         ln = self.lines[i]
         op, _, rest = ln.partition(" ")
         args = [a.strip() for a in rest.split(",")] if rest else []
-        if op in ("buffer_store_dwordx4", "buffer_store_dwordx3"):
-            for r in vregs(args[0]):
-                self.store_w[r] = self.ws + 1
         if op == "s_add_u32" and args and args[0] == "m0":
             self.n_instr += 1
             self.m0_w = self.ws + 1
@@ -149,8 +139,6 @@ class Sim(H.Sim):
             self.acc1_reads[a_ - 128] += 1
         return super().step_(i)
 
-    def gap(self, i, table, regs, need, rule):
-        super().gap(i, table, regs, 12 if (rule == "R6" and need == 11) else need, rule)
 
     def run(self):
         i, n = 0, len(self.lines)

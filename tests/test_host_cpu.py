@@ -578,7 +578,9 @@ def test_counted_waits_and_barriers_of_the_four_wave_gemm_are_proven_by_symbolic
             return False
         return True
     mf = "v_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[64:67], 0"
-    assert not runs([mf, "s_nop 5", "v_accvgpr_read_b32 v136, a0"]) and runs([mf, "s_nop 10", "v_accvgpr_read_b32 v136, a0"])
+    assert not runs([mf, "s_nop 10", "v_accvgpr_read_b32 v136, a0"]) and runs([mf, "s_nop 11", "v_accvgpr_read_b32 v136, a0"])      # (12 states: the guide's number for this MFMA)
+    wide_store = "buffer_store_dwordx4 v[128:131], v174, s[68:71], s98 offen"
+    assert not runs([wide_store, "v_mov_b32 v129, v0"]) and runs([wide_store, "s_nop 1", "v_mov_b32 v129, v0"])                       # R13
     dpp = "v_mov_b32_dpp v3, v1 row_ror:8 row_mask:0xf bank_mask:0xc"
     assert not runs(["v_mov_b32 v1, v2", "s_nop 0", dpp]) and runs(["v_mov_b32 v1, v2", "s_nop 1", dpp])
     assert not runs(["v_rcp_f32 v1, v1", "v_mul_f32 v2, v1, v1"]) and runs(["v_rcp_f32 v1, v1", "s_nop 0", "v_mul_f32 v2, v1, v1"])
