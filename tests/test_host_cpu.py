@@ -687,6 +687,30 @@ def test_narrow_tile_asm_gemm_is_generated_emulated_and_race_checked_on_the_cpu(
         assert caught >= 9, (bkm, epi, caught)                # (a barrier's wait that a stricter, older wait of the epilogue queue already covers is not reportable)
 
 
+def test_packed_fp32_instructions_of_the_narrow_queue_unpack_into_their_scalar_halves():
+    """scripts/gen_w4n.py unpack_pk: the narrow bodies drain their epilogue BETWEEN MFMAs, where packed fp32 VALU operations are a measured anti-lever, so every
+    v_pk_fma / v_pk_mul / v_pk_add_f32 of the queue is emitted as two scalar instructions.  The rewrite must keep the operand selection: op_sel_hi = 0 on an inline constant feeds
+    both halves, neg_lo / neg_hi become the scalar negation prefix, a constant first source of a VOP2 form stays first, anything else is left alone -- and the generated default
+    text holds no packed instruction at all."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import gen_w4n as G
+    finally:
+        sys.path.pop(0)
+    u = G.unpack_pk
+    assert u("v_pk_fma_f32 v[96:97], v[96:97], v[192:193], 1.0 op_sel_hi:[1,1,0]") == ["v_fma_f32 v96, v96, v192, 1.0", "v_fma_f32 v97, v97, v193, 1.0"]
+    assert u("v_pk_mul_f32 v[92:93], v[92:93], v[96:97] neg_lo:[0,1] neg_hi:[0,1]") == ["v_mul_f32 v92, v92, -v96", "v_mul_f32 v93, v93, -v97"]
+    assert u("v_pk_fma_f32 v[88:89], v[88:89], v[168:169], v[170:171] neg_lo:[0,0,1] neg_hi:[0,0,1]") == ["v_fma_f32 v88, v88, v168, -v170", "v_fma_f32 v89, v89, v169, -v171"]
+    assert u("v_pk_fma_f32 v[92:93], v[92:93], 0.5, 0.5 op_sel_hi:[1,0,0]") == ["v_fma_f32 v92, v92, 0.5, 0.5", "v_fma_f32 v93, v93, 0.5, 0.5"]
+    assert u("v_pk_add_f32 v[88:89], v[88:89], v[64:65]") == ["v_add_f32 v88, v88, v64", "v_add_f32 v89, v89, v65"]
+    assert u("v_mov_b32 v1, v2") is None and u("v_cvt_pk_bf16_f32 v80, v88, v89") is None
+    with pytest.raises(AssertionError):
+        u("v_pk_mul_f32 v[92:93], v[92:93], v[96:97] op_sel_hi:[1,0]")          # a register pair read low-low would make the halves order-dependent: refused
+    text = open(os.path.join(ROOT, "diffusion-image-captioning_amd", "csrc", "gemm_w4n_asm.inc")).read()
+    assert "v_pk_" not in text
+    assert any("v_pk_fma_f32" in ln for ln in G.generate(False, "gelu", ("flat=12", "pk=1"))[0])          # (the A/B variant keeps them)
+
+
 def _run_bench(argv, env_extra=None, timeout=600):
     import subprocess
     env = dict(os.environ, **(env_extra or {}))
